@@ -1,0 +1,190 @@
+"""Deterministic synthetic weights and inputs (no network: there are no checkpoints or datasets here).
+
+* :func:`synth_state_dict` fills a checkpoint-shaped state dict (key names = the reference's
+  ``model.safetensors`` layout, SURVEY.md section 8b / ``standalone.py:1452-1464``) from a counter-based
+  integer hash, so that the golden-vector generator (which runs the real reference in the build
+  container) and the GPU box regenerate bit-identical fp32 weights from ``(dims, seed)`` alone.  The
+  per-tensor scales are chosen so that activations, attention scores and logits are O(1): a far more
+  demanding numerical test than the 0.02-std Hugging Face initialisation, where every residual
+  branch is tiny.
+* :func:`synth_pair_batch` builds the BASELINE.json workload: one query shared by N contexts,
+  ``[CLS] + 24 query ids + [SEP] + (L-27) context ids + [SEP]`` per row.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .config import EncoderDims
+
+_MASK64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _tensor_stream(seed: int, tensor_tag: int, count: int) -> np.ndarray:
+    """``count`` floats uniform in [-1, 1), a pure function of (seed, tensor_tag, index)."""
+
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([np.uint64(seed) * np.uint64(0x1000003) + np.uint64(tensor_tag)], dtype=np.uint64))[0]
+        idx = np.arange(count, dtype=np.uint64) + base
+    bits = _splitmix64(idx) >> np.uint64(40)  # 24 random bits -> exactly representable in fp32
+    u = bits.astype(np.float32) * np.float32(1.0 / (1 << 24))
+    return u * np.float32(2.0) - np.float32(1.0)
+
+
+def _filled(seed: int, tag: int, shape: Sequence[int], scale: float, offset: float = 0.0) -> torch.Tensor:
+    count = int(np.prod(shape))
+    values = _tensor_stream(seed, tag, count) * np.float32(scale) + np.float32(offset)
+    return torch.from_numpy(values.reshape(tuple(shape)).astype(np.float32, copy=False)).clone()
+
+
+def state_dict_keys(dims: EncoderDims) -> list[tuple[str, tuple[int, ...]]]:
+    """Checkpoint tensor names and shapes, in the order the loader expects them."""
+
+    H, I, V, nl = dims.hidden_size, dims.intermediate_size, dims.vocab_size, dims.num_labels
+    keys: list[tuple[str, tuple[int, ...]]] = [
+        ("ranking_model.model.embeddings.tok_embeddings.weight", (V, H)),
+        ("ranking_model.model.embeddings.norm.weight", (H,)),
+    ]
+    for i in range(dims.num_layers):
+        p = f"ranking_model.model.layers.{i}"
+        if i != 0:
+            keys.append((f"{p}.attn_norm.weight", (H,)))
+        keys += [
+            (f"{p}.attn.Wqkv.weight", (3 * H, H)),
+            (f"{p}.attn.Wo.weight", (H, H)),
+            (f"{p}.mlp_norm.weight", (H,)),
+            (f"{p}.mlp.Wi.weight", (2 * I, H)),
+            (f"{p}.mlp.Wo.weight", (H, I)),
+        ]
+    keys += [
+        ("ranking_model.model.final_norm.weight", (H,)),
+        ("ranking_model.head.dense.weight", (H, H)),
+        ("ranking_model.head.norm.weight", (H,)),
+        ("ranking_model.classifier.weight", (nl, H)),
+        ("ranking_model.classifier.bias", (nl,)),
+        ("pruning_head.classifier.weight", (2, H)),
+        ("pruning_head.classifier.bias", (2,)),
+    ]
+    return keys
+
+
+def synth_state_dict(dims: EncoderDims, seed: int) -> dict[str, torch.Tensor]:
+    """fp32 CPU state dict with reference key names; identical bits for identical (dims, seed)."""
+
+    H, I = dims.hidden_size, dims.intermediate_size
+    s3 = math.sqrt(3.0)  # uniform(-a, a) has std a/sqrt(3)
+    out: dict[str, torch.Tensor] = {}
+    for tag, (name, shape) in enumerate(state_dict_keys(dims)):
+        if name.endswith("norm.weight"):
+            tensor = _filled(seed, tag, shape, 0.25, 1.0)
+        elif name.endswith("tok_embeddings.weight"):
+            tensor = _filled(seed, tag, shape, 1.0)
+        elif name.endswith("Wqkv.weight"):
+            tensor = _filled(seed, tag, shape, 1.5 * s3 / math.sqrt(H))
+        elif name.endswith("attn.Wo.weight") or name.endswith("Wi.weight") or name.endswith("dense.weight"):
+            tensor = _filled(seed, tag, shape, s3 / math.sqrt(H))
+        elif name.endswith("mlp.Wo.weight"):
+            tensor = _filled(seed, tag, shape, s3 / math.sqrt(I))
+        elif name.endswith("classifier.weight"):
+            tensor = _filled(seed, tag, shape, s3 / math.sqrt(H))
+        elif name.endswith("classifier.bias"):
+            tensor = _filled(seed, tag, shape, 0.5)
+        else:  # pragma: no cover - key list and branches are kept in sync
+            raise KeyError(name)
+        out[name] = tensor
+    return out
+
+
+def synth_pair_batch(
+    dims: EncoderDims,
+    n_pairs: int,
+    seq_len: int | Sequence[int],
+    *,
+    seed: int = 1234,
+    query_tokens: int = 24,
+) -> list[list[int]]:
+    """Token-id rows for ``n_pairs`` (query, context) pairs sharing ONE query."""
+
+    rng = np.random.default_rng(seed)
+    V = dims.vocab_size
+    margin = 1000 if V > 4000 else max(4, V // 8)
+    lo, hi = margin, V - margin
+    cls_id = dims.cls_token_id if dims.cls_token_id is not None else 1
+    sep_id = dims.sep_token_id if dims.sep_token_id is not None else 2
+    lengths = [int(seq_len)] * n_pairs if isinstance(seq_len, (int, np.integer)) else [int(v) for v in seq_len]
+    if len(lengths) != n_pairs:
+        raise ValueError("seq_len sequence must have n_pairs entries")
+    query = rng.integers(lo, hi, size=query_tokens).tolist()
+    rows: list[list[int]] = []
+    for length in lengths:
+        n_ctx = length - (query_tokens + 3)
+        if n_ctx < 1:
+            raise ValueError(f"seq_len {length} too short for {query_tokens} query tokens + 3 specials")
+        ctx = rng.integers(lo, hi, size=n_ctx).tolist()
+        rows.append([cls_id] + query + [sep_id] + ctx + [sep_id])
+    return rows
+
+
+def synth_varlen_lengths(n_tokens_target: int, *, seed: int = 1234) -> list[int]:
+    """Config C5: lengths from {128..2048} with probability proportional to 1/L until T ~ target."""
+
+    choices = np.array([128, 256, 384, 512, 768, 1024, 1536, 2048])
+    probs = (1.0 / choices) / (1.0 / choices).sum()
+    rng = np.random.default_rng(seed)
+    lengths: list[int] = []
+    total = 0
+    while total < n_tokens_target:
+        length = int(rng.choice(choices, p=probs))
+        lengths.append(length)
+        total += length
+    return lengths
+
+
+def pad_rows(rows: Sequence[Sequence[int]], pad_id: int = 0) -> tuple[torch.Tensor, torch.Tensor]:
+    """Right-pad id rows to a dense ``[B, Lmax]`` pair (input_ids, attention_mask), int64 like the reference."""
+
+    max_len = max((len(r) for r in rows), default=0)
+    ids = torch.full((len(rows), max_len), int(pad_id), dtype=torch.long)
+    mask = torch.zeros((len(rows), max_len), dtype=torch.long)
+    for i, row in enumerate(rows):
+        ids[i, : len(row)] = torch.tensor(list(row), dtype=torch.long)
+        mask[i, : len(row)] = 1
+    return ids, mask
+
+
+XSMALL = dict(vocab_size=102400, hidden_size=256, intermediate_size=1024, num_hidden_layers=10, num_attention_heads=4)
+BASE = dict(vocab_size=102400, hidden_size=512, intermediate_size=2048, num_hidden_layers=19, num_attention_heads=8)
+LARGE = dict(vocab_size=102400, hidden_size=768, intermediate_size=3072, num_hidden_layers=25, num_attention_heads=12)
+EN_GTE = dict(vocab_size=50368, hidden_size=768, intermediate_size=1152, num_hidden_layers=22, num_attention_heads=12)
+
+
+def named_dims(name: str, **overrides: int) -> EncoderDims:
+    """Model-card dimensions of the four published checkpoints (not in the reference tree)."""
+
+    table = {"xsmall": XSMALL, "base": BASE, "large": LARGE, "en-gte": EN_GTE}
+    cfg = dict(table[name])
+    cfg.update(
+        model_type="modernbert",
+        local_attention=128,
+        global_attn_every_n_layers=3,
+        global_rope_theta=160000.0,
+        local_rope_theta=10000.0,
+        max_position_embeddings=8192,
+        pad_token_id=3,
+        cls_token_id=1,
+        sep_token_id=2,
+    )
+    cfg.update(overrides)
+    return EncoderDims.from_base_model_config(cfg, num_labels=1)

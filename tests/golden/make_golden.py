@@ -1,0 +1,370 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Build-container only (needs /root/reference and the third-party ``transformers`` ModernBERT); the
+outputs (``*.npz`` + ``*.json``) are committed, this script documents how they were made.  Recipe =
+SURVEY.md Appendix B:
+
+  1. stub ``nltk`` so ``modeling_open_provence_standalone.py:44-50`` imports;
+  2. load that single file by path (never ``import open_provence``);
+  3. replace ``AutoTokenizer.from_pretrained`` by a char-code tokenizer (tests/helpers.py), as the
+     reference's own tests do (tests/test_modeling_open_provence.py:143-183);
+  4. build ``OpenProvenceConfig(base_model_config={modernbert dims})`` -> ``OpenProvenceModel``;
+  5. either keep the reference's own random init (weights stored in the fixture) or overwrite the
+     weights with ``open_provence_amd.synthetic.synth_state_dict(dims, seed)`` (only the seed is stored);
+  6. run ``model(input_ids, attention_mask)`` / ``model.process(...)`` on CPU fp32 and store inputs + outputs.
+
+Usage:  python tests/golden/make_golden.py [--only NAME ...]
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import json
+import sys
+import types
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parents[1]
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+from helpers import CharTokenizer, period_splitter  # noqa: E402
+
+from open_provence_amd.config import EncoderDims  # noqa: E402
+from open_provence_amd.synthetic import synth_state_dict  # noqa: E402
+
+REFERENCE_FILE = Path("/root/reference/open_provence/modeling_open_provence_standalone.py")
+
+
+def load_reference(emit_specials: bool = True):
+    if "nltk" not in sys.modules:
+        nltk = types.ModuleType("nltk")
+        nltk_tok = types.ModuleType("nltk.tokenize")
+
+        class _Punkt:  # never used: every call passes an explicit splitter / pre-split sentences
+            pass
+
+        nltk_tok.PunktSentenceTokenizer = _Punkt
+        nltk.tokenize = nltk_tok
+        nltk.data = types.SimpleNamespace(load=lambda *_a, **_k: (_ for _ in ()).throw(LookupError("stub")))
+        sys.modules["nltk"] = nltk
+        sys.modules["nltk.tokenize"] = nltk_tok
+    spec = importlib.util.spec_from_file_location("reference_standalone", REFERENCE_FILE)
+    module = importlib.util.module_from_spec(spec)
+    sys.modules["reference_standalone"] = module
+    spec.loader.exec_module(module)
+    module.AutoTokenizer.from_pretrained = staticmethod(lambda *_a, **_k: CharTokenizer(emit_specials=emit_specials))
+    return module
+
+
+def versions() -> dict[str, str]:
+    import transformers
+
+    return {
+        "torch": torch.__version__,
+        "transformers": transformers.__version__,
+        "reference_pins_transformers": "4.57.1 (uv.lock:3640-3641)",
+        "numpy": np.__version__,
+    }
+
+
+def build_model(ref, base_cfg: dict[str, Any], *, max_length: int, seed: int, weight_seed: int | None):
+    torch.manual_seed(seed)
+    cfg = ref.OpenProvenceConfig(
+        base_model_config=dict(base_cfg),
+        tokenizer_name_or_path="char-tokenizer",
+        pruning_config={"hidden_size": base_cfg["hidden_size"]},
+        max_length=max_length,
+        num_labels=1,
+    )
+    model = ref.OpenProvenceModel(cfg)
+    dims = EncoderDims.from_base_model_config(base_cfg, num_labels=1)
+    if weight_seed is not None:
+        state = synth_state_dict(dims, weight_seed)
+        missing, unexpected = model.load_state_dict(state, strict=False)
+        bad = [k for k in missing if "inv_freq" not in k]
+        assert not bad and not unexpected, (bad, unexpected)
+    model.eval()
+    return model, dims
+
+
+def make_rows(dims: EncoderDims, lengths: list[int], seed: int) -> tuple[torch.Tensor, torch.Tensor]:
+    from open_provence_amd.synthetic import pad_rows, synth_pair_batch
+
+    rows = synth_pair_batch(dims, len(lengths), lengths, seed=seed, query_tokens=8 if min(lengths) < 40 else 24)
+    return pad_rows(rows, pad_id=dims.pad_token_id or 0)
+
+
+def base_cfg(**kw: Any) -> dict[str, Any]:
+    cfg = {
+        "model_type": "modernbert",
+        "max_position_embeddings": 8192,
+        "local_attention": 128,
+        "global_attn_every_n_layers": 3,
+        "global_rope_theta": 160000.0,
+        "local_rope_theta": 10000.0,
+        "pad_token_id": 0,
+        "cls_token_id": 1,
+        "sep_token_id": 2,
+        "bos_token_id": 1,
+        "eos_token_id": 2,
+    }
+    cfg.update(kw)
+    return cfg
+
+
+def forward_fixture(
+    name: str,
+    cfg: dict[str, Any],
+    lengths: list[int],
+    *,
+    weight_seed: int | None,
+    hidden_stride: int | None,
+    init_seed: int = 0,
+    input_seed: int = 1234,
+) -> None:
+    ref = load_reference()
+    model, dims = build_model(ref, cfg, max_length=max(lengths), seed=init_seed, weight_seed=weight_seed)
+    ids, mask = make_rows(dims, lengths, input_seed)
+    with torch.no_grad():
+        out = model(input_ids=ids, attention_mask=mask)
+    arrays: dict[str, np.ndarray] = {
+        "input_ids": ids.numpy(),
+        "attention_mask": mask.numpy(),
+        "ranking_logits": out.ranking_logits.float().numpy(),
+        "pruning_logits": out.pruning_logits.float().numpy(),
+    }
+    hs = out.hidden_states
+    if hidden_stride:
+        for i, h in enumerate(hs):
+            arrays[f"hidden_{i}"] = h[:, ::hidden_stride, :].float().numpy()
+    if weight_seed is None:
+        for k, v in model.state_dict().items():
+            if "inv_freq" in k:
+                continue
+            arrays[f"w::{k}"] = v.float().numpy()
+    meta = {
+        "name": name,
+        "base_model_config": cfg,
+        "num_labels": 1,
+        "lengths": lengths,
+        "input_seed": input_seed,
+        "hidden_stride": hidden_stride,
+        "n_hidden_states": len(hs),
+        "attn_implementation": getattr(model.ranking_model.config, "_attn_implementation", None),
+        "layer_types": list(model.ranking_model.config.layer_types),
+        "generator": "tests/golden/make_golden.py (reference OpenProvenceModel.forward, CPU fp32)",
+        "versions": versions(),
+    }
+    if weight_seed is not None:
+        meta["weight_seed"] = weight_seed
+    np.savez_compressed(HERE / f"{name}.npz", **arrays)
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=2, sort_keys=True))
+    print(f"[golden] {name}: rank={arrays['ranking_logits'].ravel()[:4]} prune-absmax={np.abs(arrays['pruning_logits']).max():.3f}")
+
+
+PROCESS_CASES: list[dict[str, Any]] = [
+    dict(
+        case="str_single",
+        question="what is a cat?",
+        context="Cats are small animals. They purr a lot! Dogs bark. The sky is blue. Cats like fish.",
+        kwargs=dict(threshold=0.5),
+    ),
+    dict(
+        case="list_docs_reorder",
+        question="how tall is the tower?",
+        context=[
+            "The tower is 300 m tall. It was built in 1889. Many people visit it.",
+            "Bread is made from flour. Water is wet.",
+            ["Pre split one. ", "Pre split two about the tower. ", "   ", "Pre split three."],
+        ],
+        kwargs=dict(threshold=0.45, reorder=True, top_k=2),
+    ),
+    dict(
+        case="aligned_titles",
+        question=["first question here?", "second question about rivers?"],
+        context=[
+            "Alpha sentence one. Alpha sentence two is longer than one. Alpha three.",
+            "Rivers flow to the sea. Mountains are tall. Rivers carry water and silt.",
+        ],
+        kwargs=dict(threshold=0.5, title=["Alpha Title", "River Title"], always_select_title=True),
+    ),
+    dict(
+        case="nested_explicit_titles",
+        question=["q one?", "q two?"],
+        context=[
+            ["Doc a first. Doc a second. Doc a third.", ["Sent x. ", "Sent y. "]],
+            ["Doc b only sentence here."],
+        ],
+        kwargs=dict(threshold=0.5, title=[["T-a", "T-x"], ["T-b"]], use_best_reranker_score=False),
+    ),
+    dict(
+        case="long_document_multiblock",
+        question="find the needle?",
+        context=" ".join(f"Sentence number {i} talks about topic {i % 7} in some detail." for i in range(40)),
+        kwargs=dict(threshold=0.5),
+    ),
+    dict(
+        case="first_line_title",
+        question="what about the header?",
+        context="Header Line\nBody sentence one. Body sentence two. Body three is here.",
+        kwargs=dict(threshold=0.5, first_line_as_title=True, always_select_title=True),
+    ),
+    dict(
+        case="respect_boundaries_strip",
+        question="boundaries?",
+        context="  A short one.   Another sentence that is a bit longer than the first one.  End. ",
+        kwargs=dict(threshold=0.5, respect_sentence_boundaries=True, strip_sentences=True),
+    ),
+    dict(
+        case="zero_score_disabled",
+        question="nothing relevant?",
+        context="abc. def. ghi.",
+        kwargs=dict(threshold=0.999, zero_score_when_empty=False),
+    ),
+]
+
+
+def _jsonable(value: Any) -> Any:
+    if isinstance(value, dict):
+        return {k: _jsonable(v) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [_jsonable(v) for v in value]
+    if isinstance(value, (np.floating, np.integer)):
+        return value.item()
+    return value
+
+
+def process_fixture(name: str, cfg: dict[str, Any], *, weight_seed: int, max_length: int, emit_specials: bool, stub: bool) -> None:
+    """G3: full process() through the reference.  ``stub=True`` replaces forward by a deterministic
+    position-dependent logit pattern so host semantics are pinned independently of encoder numerics
+    (same trick as the reference's tests/test_modeling_open_provence.py:940-949)."""
+
+    ref = load_reference(emit_specials=emit_specials)
+    model, _dims = build_model(ref, cfg, max_length=max_length, seed=0, weight_seed=weight_seed)
+    if stub:
+
+        def stub_forward(input_ids=None, attention_mask=None, **_kw):
+            b, length = input_ids.shape
+            pos = torch.arange(length, dtype=torch.float32)[None, :].expand(b, length)
+            tok = input_ids.to(torch.float32)
+            keep = torch.sin(0.37 * pos + 0.011 * tok) * 3.0
+            prune = torch.stack([torch.zeros_like(keep), keep], dim=-1)
+            rank = (input_ids.sum(dim=1, keepdim=True).to(torch.float32) % 17.0) / 4.0 - 2.0
+            return {"ranking_logits": rank, "pruning_logits": prune}
+
+        model.forward = stub_forward  # type: ignore[method-assign]
+    cases_out = []
+    for case in PROCESS_CASES:
+        kwargs = dict(case["kwargs"])
+        with torch.no_grad():
+            result = model.process(
+                question=case["question"],
+                context=case["context"],
+                sentence_splitter=period_splitter,
+                show_progress=False,
+                return_sentence_metrics=True,
+                return_sentence_texts=True,
+                batch_size=4,
+                **kwargs,
+            )
+        result.pop("timing")
+        result.pop("performance_trace")
+        cases_out.append({"case": case["case"], "question": case["question"], "context": case["context"], "kwargs": kwargs, "expected": _jsonable(result)})
+    meta = {
+        "name": name,
+        "base_model_config": cfg,
+        "num_labels": 1,
+        "weight_seed": weight_seed,
+        "max_length": max_length,
+        "emit_specials": emit_specials,
+        "stub_forward": stub,
+        "cases": cases_out,
+        "generator": "tests/golden/make_golden.py (reference OpenProvenceModel.process, CPU fp32)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: {len(cases_out)} process() cases")
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--only", nargs="*", default=None)
+    args = parser.parse_args()
+
+    def want(name: str) -> bool:
+        return args.only is None or name in args.only
+
+    # G0: the survey's probe config (head_dim 16) -- oracle-only (the HIP kernels need head_dim 64).
+    if want("g0_tiny_hd16"):
+        forward_fixture(
+            "g0_tiny_hd16",
+            base_cfg(vocab_size=512, hidden_size=64, intermediate_size=96, num_hidden_layers=4, num_attention_heads=4, local_attention=16),
+            [128, 100, 128, 77],
+            weight_seed=None,
+            hidden_stride=5,
+        )
+    # G0b: head_dim 64, the reference's OWN random init (weights stored), window 16 so that the
+    # sliding mask bites at L=128.
+    if want("g0b_hd64_refinit"):
+        forward_fixture(
+            "g0b_hd64_refinit",
+            base_cfg(vocab_size=256, hidden_size=128, intermediate_size=128, num_hidden_layers=4, num_attention_heads=2, local_attention=16),
+            [128, 100, 128, 33],
+            weight_seed=None,
+            hidden_stride=5,
+        )
+    # G0c: same shape, synthetic O(1) weights (seed only).
+    if want("g0c_hd64_synth"):
+        forward_fixture(
+            "g0c_hd64_synth",
+            base_cfg(vocab_size=256, hidden_size=128, intermediate_size=128, num_hidden_layers=4, num_attention_heads=2, local_attention=16),
+            [128, 100, 128, 33, 17, 64],
+            weight_seed=11,
+            hidden_stride=5,
+        )
+    # G1: xsmall shape (config C2 dims), ragged rows, synthetic weights.
+    if want("g1_xsmall"):
+        forward_fixture(
+            "g1_xsmall",
+            base_cfg(vocab_size=102400, hidden_size=256, intermediate_size=1024, num_hidden_layers=10, num_attention_heads=4),
+            [512, 512, 400, 512, 129, 512, 64, 333],
+            weight_seed=21,
+            hidden_stride=61,
+        )
+    # G1m: mean pooling + 2 labels variant on a short stack.
+    if want("g1m_meanpool"):
+        forward_fixture(
+            "g1m_meanpool",
+            base_cfg(vocab_size=4096, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4, classifier_pooling="mean"),
+            [200, 256, 31],
+            weight_seed=23,
+            hidden_stride=None,
+        )
+    # G2: en-gte width (H=768, I=1152, 12 heads) truncated to 3 layers, mixed lengths up to 2048.
+    if want("g2_gte_varlen"):
+        forward_fixture(
+            "g2_gte_varlen",
+            base_cfg(vocab_size=50368, hidden_size=768, intermediate_size=1152, num_hidden_layers=3, num_attention_heads=12),
+            [2048, 128, 1024, 384, 1536, 256],
+            weight_seed=31,
+            hidden_stride=None,
+        )
+    g3_cfg = base_cfg(vocab_size=256, hidden_size=128, intermediate_size=128, num_hidden_layers=4, num_attention_heads=2, local_attention=32)
+    if want("g3_process_stub"):
+        process_fixture("g3_process_stub", g3_cfg, weight_seed=41, max_length=96, emit_specials=True, stub=True)
+    if want("g3_process_stub_manual_specials"):
+        process_fixture("g3_process_stub_manual_specials", g3_cfg, weight_seed=41, max_length=96, emit_specials=False, stub=True)
+    if want("g3_process_model"):
+        process_fixture("g3_process_model", g3_cfg, weight_seed=41, max_length=96, emit_specials=True, stub=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""Shared test helpers (test infrastructure, not product code)."""
+
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import torch
+
+REPO_ROOT = Path(__file__).resolve().parents[1]
+GOLDEN_DIR = REPO_ROOT / "tests" / "golden"
+if str(REPO_ROOT) not in sys.path:
+    sys.path.insert(0, str(REPO_ROOT))
+
+
+class CharTokenizer:
+    """One token per character (id = code point); implements exactly the tokenizer surface the
+    ``process()`` pipeline touches (reference call sites: standalone.py:664-672, 862-866, 2114-2152,
+    2462, 3494).  ``emit_specials=False`` mimics tokenizers such as gte-ModernBERT whose
+    ``build_inputs_with_special_tokens`` drops CLS/SEP, which forces the manual special-token path
+    (standalone.py:1501-1538, 2123-2135)."""
+
+    sep_token = "|"
+    pad_token_id = 0
+    cls_token_id = 1
+    sep_token_id = 2
+    model_max_length = 512
+
+    def __init__(self, emit_specials: bool = True) -> None:
+        self.emit_specials = emit_specials
+        self.special_tokens_map: dict[str, Any] = {}
+
+    def _ids(self, text: str) -> list[int]:
+        return [ord(ch) for ch in text]
+
+    def __call__(
+        self,
+        text,
+        add_special_tokens: bool = True,
+        return_attention_mask: bool = True,
+        padding: bool = False,
+        truncation: bool = False,
+        max_length: int | None = None,
+        return_tensors: str | None = None,
+        **_: Any,
+    ):
+        single = isinstance(text, str)
+        items = [text] if single else list(text)
+        rows = [self._ids(item) for item in items]
+        if add_special_tokens:
+            rows = [[self.cls_token_id, *row, self.sep_token_id] for row in rows]
+        if truncation and max_length is not None:
+            rows = [row[:max_length] for row in rows]
+        masks = [[1] * len(row) for row in rows]
+        if padding and rows:
+            width = max(len(row) for row in rows)
+            masks = [m + [0] * (width - len(m)) for m in masks]
+            rows = [row + [self.pad_token_id] * (width - len(row)) for row in rows]
+        out: dict[str, Any] = {"input_ids": rows}
+        if return_attention_mask:
+            out["attention_mask"] = masks
+        if return_tensors == "pt":
+            out = {k: torch.tensor(v, dtype=torch.long) for k, v in out.items()}
+        return out
+
+    def encode(self, text: str, add_special_tokens: bool = False) -> list[int]:
+        ids = self._ids(text)
+        return [self.cls_token_id, *ids, self.sep_token_id] if add_special_tokens else ids
+
+    def decode(self, tokens, skip_special_tokens: bool = True, clean_up_tokenization_spaces: bool = False) -> str:
+        specials = {self.pad_token_id, self.cls_token_id, self.sep_token_id} if skip_special_tokens else set()
+        return "".join(chr(int(t)) for t in tokens if int(t) not in specials)
+
+    def batch_decode(self, batch, skip_special_tokens: bool = True, clean_up_tokenization_spaces: bool = False):
+        return [self.decode(tokens, skip_special_tokens=skip_special_tokens) for tokens in batch]
+
+    def build_inputs_with_special_tokens(self, tokens_a, tokens_b=None):
+        tokens_b = list(tokens_b or [])
+        if not self.emit_specials:
+            return [*tokens_a, *tokens_b]
+        if tokens_b:
+            return [self.cls_token_id, *tokens_a, self.sep_token_id, *tokens_b, self.sep_token_id]
+        return [self.cls_token_id, *tokens_a, self.sep_token_id]
+
+    def create_token_type_ids_from_sequences(self, tokens_a, tokens_b=None):
+        tokens_b = list(tokens_b or [])
+        if not self.emit_specials:
+            return [0] * len(tokens_a) + [1] * len(tokens_b)
+        if tokens_b:
+            return [0] * (len(tokens_a) + 2) + [1] * (len(tokens_b) + 1)
+        return [0] * (len(tokens_a) + 2)
+
+
+def period_splitter(text: str) -> list[str]:
+    """Sentence = run of characters up to and including '.', '!' or '?' plus trailing spaces/newlines."""
+
+    out: list[str] = []
+    start = 0
+    i = 0
+    n = len(text)
+    while i < n:
+        if text[i] in ".!?":
+            j = i + 1
+            while j < n and text[j] in " \n":
+                j += 1
+            out.append(text[start:j])
+            start = j
+            i = j
+        else:
+            i += 1
+    if start < n:
+        out.append(text[start:])
+    return out
+
+
+def load_golden(name: str) -> tuple[dict[str, np.ndarray], dict[str, Any]]:
+    """Return (arrays, meta) of fixture ``tests/golden/<name>.npz`` + ``<name>.json``."""
+
+    arrays = dict(np.load(GOLDEN_DIR / f"{name}.npz", allow_pickle=False))
+    with open(GOLDEN_DIR / f"{name}.json", "r", encoding="utf-8") as handle:
+        meta = json.load(handle)
+    return arrays, meta
+
+
+def dims_from_meta(meta: dict[str, Any]):
+    from open_provence_amd.config import EncoderDims
+
+    return EncoderDims.from_base_model_config(meta["base_model_config"], num_labels=meta.get("num_labels", 1))
+
+
+def state_from_fixture(arrays: dict[str, np.ndarray], meta: dict[str, Any]) -> dict[str, torch.Tensor]:
+    """Stored weights (keys prefixed ``w::``) or regenerated from ``meta['weight_seed']``."""
+
+    if "weight_seed" in meta:
+        from open_provence_amd.synthetic import synth_state_dict
+
+        return synth_state_dict(dims_from_meta(meta), int(meta["weight_seed"]))
+    return {k[3:]: torch.from_numpy(v.copy()) for k, v in arrays.items() if k.startswith("w::")}
+
+
+def rows_from_fixture(arrays: dict[str, np.ndarray]) -> list[list[int]]:
+    ids = arrays["input_ids"]
+    mask = arrays["attention_mask"]
+    return [ids[i, : int(mask[i].sum())].tolist() for i in range(ids.shape[0])]
