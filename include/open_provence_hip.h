@@ -1,0 +1,141 @@
+/*
+ * open_provence_hip.h -- C ABI of libopenprovence_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of hotchpotch/open_provence: the batched (query, context) cross-encoder
+ * forward.  Each entry point names the reference interface it replaces (paths relative to the
+ * reference tree; "standalone.py" = open_provence/modeling_open_provence_standalone.py; "HF" = the
+ * third-party transformers ModernBERT the reference instantiates at standalone.py:1341).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns OP_OK (0) or a negative OP_ERR_* code and never throws;
+ *     the message is available from op_last_error(handle) (or op_last_error(NULL) when no
+ *     handle exists yet);
+ *   - one handle per device; calls on one handle must be serialised by the caller; the forward is
+ *     asynchronous with respect to the given HIP stream;
+ *   - the caller owns every I/O buffer and the workspace; the library owns only its re-packed weights.
+ */
+#ifndef OPEN_PROVENCE_HIP_H
+#define OPEN_PROVENCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OP_ABI_VERSION 1
+#define OP_MAX_LAYERS 128
+
+typedef struct op_handle op_handle;
+
+enum op_status {
+  OP_OK = 0,
+  OP_ERR_INVALID = -1,     /* bad argument                                   */
+  OP_ERR_UNSUPPORTED = -2, /* configuration the kernels do not implement     */
+  OP_ERR_HIP = -3,         /* HIP runtime failure (message has the HIP text) */
+  OP_ERR_STATE = -4,       /* call order (e.g. forward before all weights)   */
+  OP_ERR_WORKSPACE = -5,   /* workspace too small / misaligned               */
+  OP_ERR_NOMEM = -6
+};
+
+enum op_dtype { OP_DTYPE_F32 = 0, OP_DTYPE_BF16 = 1, OP_DTYPE_F16 = 2 };
+
+/* Arithmetic of the MFMA contractions (accumulation is always fp32; LayerNorm, softmax, GELU,
+ * RoPE and the residual stream are always fp32):
+ *   OP_PRECISION_BF16X3  each operand is carried as a (hi, lo) bf16 pair and every product is
+ *                        hi*hi + lo*hi + hi*lo on the bf16 MFMA pipe (~16 mantissa bits): the
+ *                        mode that meets the 1e-3 parity bar against the fp32 CPU reference;
+ *   OP_PRECISION_BF16    single-pass bf16 operands (what the reference itself computes with on a
+ *                        GPU: standalone.py:219-233 picks bf16), ~1e-2 on logits.            */
+enum op_precision { OP_PRECISION_BF16X3 = 0, OP_PRECISION_BF16 = 1 };
+
+enum op_pooling { OP_POOL_CLS = 0, OP_POOL_MEAN = 1 };
+
+/* Mirrors the fields of HF ModernBertConfig that change the arithmetic
+ * (transformers/models/modernbert/configuration_modernbert.py:77-162) plus
+ * OpenProvenceConfig.num_labels (standalone.py:1279). */
+typedef struct op_config {
+  uint32_t struct_bytes; /* = sizeof(op_config), checked */
+  int32_t device_id;
+  int32_t vocab_size;
+  int32_t hidden_size;
+  int32_t intermediate_size;
+  int32_t num_layers;
+  int32_t num_heads; /* head_dim = hidden_size / num_heads must be 64 */
+  int32_t num_labels;
+  int32_t local_attention; /* full window; keys with |q-k| <= local_attention/2 are visible */
+  int32_t max_position_embeddings;
+  int32_t pooling;   /* enum op_pooling */
+  int32_t precision; /* enum op_precision */
+  float norm_eps;
+  float global_rope_theta;
+  float local_rope_theta;
+  int32_t chunk_rows; /* rows of the packed batch processed per pass (0 = library default) */
+  uint8_t layer_is_global[OP_MAX_LAYERS]; /* 1 = full attention, 0 = sliding window */
+} op_config;
+
+int op_abi_version(void);
+
+/* Replaces: OpenProvencePreTrainedModel.__init__ building the backbone from
+ * config.base_model_config (standalone.py:1340-1342, 1354-1375). */
+int op_create(const op_config* cfg, op_handle** out);
+
+/* Replaces: PreTrainedModel.load_state_dict on the reference's checkpoint keys
+ * (standalone.py:1448-1464; key list in SURVEY.md section 8b).  `name` is the checkpoint key with or
+ * without the "ranking_model." prefix (legacy checkpoints omit it).  `data` may be a host or a
+ * device pointer; the tensor is copied and re-packed (bf16 hi/lo planes, GeGLU row interleave),
+ * the caller keeps ownership of the source. */
+int op_load_weight(op_handle* h, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);
+
+/* OP_OK when every tensor of the model has been loaded; otherwise OP_ERR_STATE and
+ * op_last_error() lists the missing keys. */
+int op_weights_ready(op_handle* h);
+
+/* Bytes of caller-provided device workspace needed by op_forward_packed for a batch of `n_seqs`
+ * sequences, `total_tokens` tokens, longest sequence `max_seqlen`. */
+size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int max_seqlen);
+
+/* Replaces: OpenProvenceModel.forward (standalone.py:1666-1739) = HF
+ * ModernBertForSequenceClassification.forward + OpenProvenceHead.forward (standalone.py:434-448),
+ * on the UNPADDED batch: ids_dev[total_tokens] are the attention_mask==1 tokens of all rows laid
+ * end to end, cu_seqlens[n_seqs+1] their prefix offsets.  cu_seqlens_host may be NULL (the library
+ * then reads cu_seqlens_dev back, which synchronises the stream once).
+ *   prune_logits_dev [total_tokens, 2]  fp32   (pruning_logits at attention_mask==1 positions)
+ *   rank_logits_dev  [n_seqs, num_labels] fp32 (ranking_logits)
+ * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream). */
+int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_seqlens_dev,
+                      const int32_t* cu_seqlens_host, int n_seqs, int total_tokens, int max_seqlen,
+                      float* prune_logits_dev, float* rank_logits_dev, void* workspace_dev,
+                      size_t workspace_bytes, void* hip_stream);
+
+/* Test hook.  Replaces: output_hidden_states=True of the reference forward (standalone.py:1689,
+ * 1727).  When `hidden_dev` is non-NULL the next forwards also write the (num_layers+1) hidden
+ * states, fp32 [num_layers+1, total_tokens, hidden]; entry num_layers is the post-final_norm
+ * tensor, as in HF.  Pass NULL to switch capturing off. */
+int op_debug_capture_hidden(op_handle* h, float* hidden_dev);
+
+/* Measurement hook: when enabled every kernel launch of the forward is bracketed by HIP events
+ * on the launch stream; op_profile_read returns accumulated milliseconds and launch counts per
+ * kernel kind (names via op_profile_kind_name) and resets nothing; op_profile_reset clears. */
+typedef struct op_profile_entry {
+  int32_t kind;
+  int32_t launches;
+  double total_ms;
+} op_profile_entry;
+int op_profile_enable(op_handle* h, int enabled);
+int op_profile_read(op_handle* h, op_profile_entry* entries, int max_entries); /* returns count, syncs */
+int op_profile_reset(op_handle* h);
+const char* op_profile_kind_name(int kind);
+
+/* Replaces: nothing in the reference (it has no multi-GPU path); helper for SURVEY.md section 8e. */
+int op_device_count(int* count);
+
+void op_destroy(op_handle* h);
+const char* op_last_error(const op_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPEN_PROVENCE_HIP_H */

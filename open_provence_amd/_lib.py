@@ -1,0 +1,144 @@
+"""ctypes binding of ``libopenprovence_hip.so`` (C ABI: ``include/open_provence_hip.h``).
+
+The library is built in-tree by :func:`open_provence_amd.build_ext.build` (hipcc, gfx950).  There is no
+fallback of any kind: if the shared object is missing, or there is no HIP device, the product path
+raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+OP_MAX_LAYERS = 128
+OP_ABI_VERSION = 1
+
+OP_OK = 0
+OP_DTYPE_F32, OP_DTYPE_BF16, OP_DTYPE_F16 = 0, 1, 2
+OP_PRECISION_BF16X3, OP_PRECISION_BF16 = 0, 1
+OP_POOL_CLS, OP_POOL_MEAN = 0, 1
+
+LIB_NAME = "libopenprovence_hip.so"
+
+# every symbol include/open_provence_hip.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = (
+    "op_abi_version",
+    "op_create",
+    "op_load_weight",
+    "op_weights_ready",
+    "op_workspace_bytes",
+    "op_forward_packed",
+    "op_debug_capture_hidden",
+    "op_profile_enable",
+    "op_profile_read",
+    "op_profile_reset",
+    "op_profile_kind_name",
+    "op_device_count",
+    "op_destroy",
+    "op_last_error",
+)
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP library is missing, failed to load, or returned an error code."""
+
+
+class OpConfig(ctypes.Structure):
+    _fields_ = [
+        ("struct_bytes", ctypes.c_uint32),
+        ("device_id", ctypes.c_int32),
+        ("vocab_size", ctypes.c_int32),
+        ("hidden_size", ctypes.c_int32),
+        ("intermediate_size", ctypes.c_int32),
+        ("num_layers", ctypes.c_int32),
+        ("num_heads", ctypes.c_int32),
+        ("num_labels", ctypes.c_int32),
+        ("local_attention", ctypes.c_int32),
+        ("max_position_embeddings", ctypes.c_int32),
+        ("pooling", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+        ("norm_eps", ctypes.c_float),
+        ("global_rope_theta", ctypes.c_float),
+        ("local_rope_theta", ctypes.c_float),
+        ("chunk_rows", ctypes.c_int32),
+        ("layer_is_global", ctypes.c_uint8 * OP_MAX_LAYERS),
+    ]
+
+
+class OpProfileEntry(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("launches", ctypes.c_int32), ("total_ms", ctypes.c_double)]
+
+
+def library_path() -> Path:
+    override = os.environ.get("OPEN_PROVENCE_HIP_LIB")
+    if override:
+        return Path(override)
+    return Path(__file__).resolve().parent / LIB_NAME
+
+
+_LIB: ctypes.CDLL | None = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load (once) and type the shared library; raises :class:`HipLibraryError` when it is absent."""
+
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise HipLibraryError(
+            f"{path} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the forward path."
+        )
+    try:
+        lib = ctypes.CDLL(str(path))
+    except OSError as exc:
+        raise HipLibraryError(f"failed to load {path}: {exc}") from exc
+
+    vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.op_abi_version.restype = ci
+    lib.op_abi_version.argtypes = []
+    lib.op_create.restype = ci
+    lib.op_create.argtypes = [ctypes.POINTER(OpConfig), ctypes.POINTER(vp)]
+    lib.op_load_weight.restype = ci
+    lib.op_load_weight.argtypes = [vp, ctypes.c_char_p, vp, ci, ctypes.POINTER(ctypes.c_int64), ci]
+    lib.op_weights_ready.restype = ci
+    lib.op_weights_ready.argtypes = [vp]
+    lib.op_workspace_bytes.restype = cs
+    lib.op_workspace_bytes.argtypes = [vp, ci, ci, ci]
+    lib.op_forward_packed.restype = ci
+    lib.op_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, cs, vp]
+    lib.op_debug_capture_hidden.restype = ci
+    lib.op_debug_capture_hidden.argtypes = [vp, vp]
+    lib.op_profile_enable.restype = ci
+    lib.op_profile_enable.argtypes = [vp, ci]
+    lib.op_profile_read.restype = ci
+    lib.op_profile_read.argtypes = [vp, ctypes.POINTER(OpProfileEntry), ci]
+    lib.op_profile_reset.restype = ci
+    lib.op_profile_reset.argtypes = [vp]
+    lib.op_profile_kind_name.restype = ctypes.c_char_p
+    lib.op_profile_kind_name.argtypes = [ci]
+    lib.op_device_count.restype = ci
+    lib.op_device_count.argtypes = [ctypes.POINTER(ci)]
+    lib.op_destroy.restype = None
+    lib.op_destroy.argtypes = [vp]
+    lib.op_last_error.restype = ctypes.c_char_p
+    lib.op_last_error.argtypes = [vp]
+
+    version = lib.op_abi_version()
+    if version != OP_ABI_VERSION:
+        raise HipLibraryError(f"{path} has ABI version {version}, the Python layer expects {OP_ABI_VERSION}; rebuild")
+    _LIB = lib
+    return lib
+
+
+def last_error(lib: ctypes.CDLL, handle) -> str:
+    raw = lib.op_last_error(handle)
+    return raw.decode("utf-8", "replace") if raw else ""
+
+
+def check(lib: ctypes.CDLL, handle, code: int, what: str) -> None:
+    if code != OP_OK:
+        raise HipLibraryError(f"{what} failed with code {code}: {last_error(lib, handle)}")

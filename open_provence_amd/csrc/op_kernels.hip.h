@@ -1,0 +1,889 @@
+// op_kernels.hip.h -- CDNA4 (gfx950) device code of the OpenProvence forward path.
+//
+// Packed ("unpadded") row layout: the tokens of a chunk of sequences are laid end to end, each
+// sequence starting at a multiple of ROW_ALIGN rows; `row_pos[r] < 0` marks an alignment row.  All
+// activations are [rows, features] row-major.  The fp32 residual stream `x` is the only fp32
+// activation; every MFMA operand is stored as bf16 planes: `*_hi` = RNE(bf16(v)) and (BF16X3 mode)
+// `*_lo` = RNE(bf16(v - hi)), so that  a*b ~= a_hi*b_hi + a_lo*b_hi + a_hi*b_lo  on the bf16 MFMA pipe
+// with fp32 accumulation (~2^-16 relative) -- what the 1e-3 parity bar against the fp32 CPU
+// reference needs (single-pass bf16 is ~1e-2, SURVEY.md headline fact 5).
+//
+// Arithmetic restated from (third-party) HF ModernBERT, transformers 5.15.0:
+//   embeddings+LN  modeling_modernbert.py:52-71     GeGLU MLP  :74-91      RoPE :94-219
+//   attention      :166-185, :222-301               layer      :304-333    heads :481-490, :569-622
+// and the reference's OpenProvenceHead (open_provence/modeling_open_provence_standalone.py:434-448).
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace opk {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t u16;
+
+constexpr int ROW_ALIGN = 16;   // sequence starts are multiples of this many rows
+constexpr int GEMM_BM = 128;    // rows (tokens) per GEMM tile
+constexpr int GEMM_BN = 128;    // output features per GEMM tile
+constexpr int GEMM_BK = 32;     // one 16x16x32 MFMA step
+constexpr int GEMM_LDS = 48;    // LDS row stride in bf16 elements (32 + 16 pad: conflict-free b128 reads)
+constexpr int ATT_BQ = 64;      // queries per attention block (4 waves x 16)
+constexpr int ATT_BK = 64;      // keys per tile
+constexpr int ATT_LDS = 80;     // LDS row stride in bf16 elements (64 + 16 pad)
+constexpr int HEAD_DIM = 64;
+constexpr int ROPE_HALF = 32;
+
+// ----------------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ u16 f2bf(float x) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs only)
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+template <bool SPLIT>
+__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
+  u16 h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = f2bf(v[i]);
+    l[i] = SPLIT ? f2bf(v[i] - bf2f(h[i])) : (u16)0;
+  }
+  hi.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+  hi.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+  lo.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
+  lo.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+}
+
+union FragU {
+  uint4 u;
+  bf16x8 v;
+};
+__device__ __forceinline__ bf16x8 as_frag(uint4 u) {
+  FragU f;
+  f.u = u;
+  return f.v;
+}
+__device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return as_frag(*reinterpret_cast<const uint4*>(p)); }
+
+// D = X * Y + C on one wave.  X fragment: row (lane & 15), k-group (lane >> 4) holds 8 consecutive k.
+// Y fragment: column (lane & 15), same k-group.  D: column (lane & 15), rows 4*(lane >> 4) + r.
+__device__ __forceinline__ f32x4 mfma16(bf16x8 x, bf16x8 y, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ----------------------------------------------------------------------------------------------
+// row map: sequence offsets (aligned) and per-row (seq, pos, token index)
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void seq_offsets_kernel(const int32_t* __restrict__ cu, int s0, int ns,
+                                                           int32_t* __restrict__ roff) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ns; base += 1024) {
+    const int i = base + tid;
+    int v = 0;
+    if (i < ns) {
+      const int len = cu[s0 + i + 1] - cu[s0 + i];
+      v = (len + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+    }
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = tid >= off ? sh[tid - off] : 0;
+      __syncthreads();
+      sh[tid] += t;
+      __syncthreads();
+    }
+    const int incl = sh[tid];
+    const int c = carry;
+    if (i < ns) roff[i] = c + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = c + incl;
+    __syncthreads();
+  }
+  if (tid == 0) roff[ns] = carry;
+}
+
+__global__ void row_map_kernel(const int32_t* __restrict__ cu, int s0, int ns, const int32_t* __restrict__ roff,
+                               int r_pad, int32_t* __restrict__ row_seq, int32_t* __restrict__ row_pos,
+                               int32_t* __restrict__ row_tok) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= r_pad) return;
+  const int total = roff[ns];
+  if (r >= total) {
+    row_seq[r] = -1;
+    row_pos[r] = -1;
+    row_tok[r] = -1;
+    return;
+  }
+  int lo = 0, hi = ns - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (roff[mid] <= r) lo = mid; else hi = mid - 1;
+  }
+  const int pos = r - roff[lo];
+  const int start = cu[s0 + lo];
+  const int len = cu[s0 + lo + 1] - start;
+  row_seq[r] = lo;
+  if (pos < len) {
+    row_pos[r] = pos;
+    row_tok[r] = start + pos;
+  } else {
+    row_pos[r] = -1;
+    row_tok[r] = -1;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm family: one wave per row, float4 per lane-chunk, H <= 1024, H % 4 == 0
+// ----------------------------------------------------------------------------------------------
+constexpr int LN_MAX_CHUNKS = 4;  // float4 chunks per lane: H <= 4 * 64 * 4 = 1024
+
+struct RowVec {
+  float4 v[LN_MAX_CHUNKS];
+};
+
+__device__ __forceinline__ void row_load(const float* __restrict__ src, int H, int lane, RowVec& rv) {
+  const int nchunk = H >> 2;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int c = lane + 64 * k;
+    rv.v[k] = (c < nchunk) ? reinterpret_cast<const float4*>(src)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// y = (x - mean) / sqrt(var + eps) * w   (biased variance, as torch.nn.LayerNorm)
+__device__ __forceinline__ void row_layer_norm(RowVec& rv, const float* __restrict__ w, int H, int lane, float eps) {
+  const int nchunk = H >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) s += (rv.v[k].x + rv.v[k].y) + (rv.v[k].z + rv.v[k].w);
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+      const float a = rv.v[k].x - mean, b = rv.v[k].y - mean, cc = rv.v[k].z - mean, d = rv.v[k].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+      const float4 ww = reinterpret_cast<const float4*>(w)[c];
+      rv.v[k].x = (rv.v[k].x - mean) * rstd * ww.x;
+      rv.v[k].y = (rv.v[k].y - mean) * rstd * ww.y;
+      rv.v[k].z = (rv.v[k].z - mean) * rstd * ww.z;
+      rv.v[k].w = (rv.v[k].w - mean) * rstd * ww.w;
+    }
+  }
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ void row_store_planes(const RowVec& rv, u16* __restrict__ hi, u16* __restrict__ lo, int H,
+                                                 int lane) {
+  const int nchunk = H >> 2;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+      const float v[4] = {rv.v[k].x, rv.v[k].y, rv.v[k].z, rv.v[k].w};
+      uint2 h2, l2;
+      split4<SPLIT>(v, h2, l2);
+      reinterpret_cast<uint2*>(hi)[c] = h2;
+      if (SPLIT) reinterpret_cast<uint2*>(lo)[c] = l2;
+    }
+  }
+}
+
+__device__ __forceinline__ void row_store_f32(const RowVec& rv, float* __restrict__ dst, int H, int lane) {
+  const int nchunk = H >> 2;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) reinterpret_cast<float4*>(dst)[c] = rv.v[k];
+  }
+}
+
+// x0 = LN(E[id]) -> residual stream (fp32) and, because layer 0 has attn_norm = Identity
+// (modeling_modernbert.py:309-312), directly the Wqkv operand planes.  Alignment rows get zeros.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids,
+                                                       const int32_t* __restrict__ row_tok,
+                                                       const float* __restrict__ table, const float* __restrict__ lnw,
+                                                       float eps, int H, int r_pad, int vocab, float* __restrict__ x,
+                                                       u16* __restrict__ a_hi, u16* __restrict__ a_lo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= r_pad) return;
+  const int tok = row_tok[row];
+  RowVec rv;
+  if (tok < 0) {
+#pragma unroll
+    for (int k = 0; k < LN_MAX_CHUNKS; ++k) rv.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    int id = ids[tok];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    row_load(table + (size_t)id * H, H, lane, rv);
+    row_layer_norm(rv, lnw, H, lane, eps);
+  }
+  row_store_f32(rv, x + (size_t)row * H, H, lane);
+  row_store_planes<SPLIT>(rv, a_hi + (size_t)row * H, a_lo + (size_t)row * H, H, lane);
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ lnw, float eps,
+                                                 int H, int r_pad, u16* __restrict__ a_hi, u16* __restrict__ a_lo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= r_pad) return;
+  RowVec rv;
+  row_load(x + (size_t)row * H, H, lane, rv);
+  row_layer_norm(rv, lnw, H, lane, eps);
+  row_store_planes<SPLIT>(rv, a_hi + (size_t)row * H, a_lo + (size_t)row * H, H, lane);
+}
+
+// test hook: copy the residual stream rows of real tokens to the caller's packed [T, H] layout
+__global__ __launch_bounds__(256) void capture_rows_kernel(const float* __restrict__ x,
+                                                           const int32_t* __restrict__ row_tok, int H, int r_pad,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= r_pad) return;
+  const int tok = row_tok[row];
+  if (tok < 0) return;
+  RowVec rv;
+  row_load(x + (size_t)row * H, H, lane, rv);
+  row_store_f32(rv, out + (size_t)tok * H, H, lane);
+}
+
+// final_norm + OpenProvenceHead Linear(H, 2) on every real token (standalone.py:446-448); keeps the
+// normalised row for the ranking head (CLS row or, for mean pooling, every row -- written over x).
+__global__ __launch_bounds__(256) void final_ln_prune_kernel(float* __restrict__ x, const float* __restrict__ lnw,
+                                                             float eps, int H, int r_pad,
+                                                             const int32_t* __restrict__ row_tok,
+                                                             const int32_t* __restrict__ row_seq,
+                                                             const int32_t* __restrict__ row_pos,
+                                                             const float* __restrict__ pw, const float* __restrict__ pb,
+                                                             float* __restrict__ prune_out, int keep_all_rows,
+                                                             float* __restrict__ cls, float* __restrict__ capture) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= r_pad) return;
+  const int tok = row_tok[row];
+  if (tok < 0) return;
+  RowVec rv;
+  row_load(x + (size_t)row * H, H, lane, rv);
+  row_layer_norm(rv, lnw, H, lane, eps);
+  const int nchunk = H >> 2;
+  float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+      const float4 w0 = reinterpret_cast<const float4*>(pw)[c];
+      const float4 w1 = reinterpret_cast<const float4*>(pw + H)[c];
+      d0 += (rv.v[k].x * w0.x + rv.v[k].y * w0.y) + (rv.v[k].z * w0.z + rv.v[k].w * w0.w);
+      d1 += (rv.v[k].x * w1.x + rv.v[k].y * w1.y) + (rv.v[k].z * w1.z + rv.v[k].w * w1.w);
+    }
+  }
+  d0 = wave_sum(d0);
+  d1 = wave_sum(d1);
+  if (lane == 0) {
+    prune_out[(size_t)tok * 2 + 0] = d0 + pb[0];
+    prune_out[(size_t)tok * 2 + 1] = d1 + pb[1];
+  }
+  if (keep_all_rows) row_store_f32(rv, x + (size_t)row * H, H, lane);
+  if (row_pos[row] == 0) row_store_f32(rv, cls + (size_t)row_seq[row] * H, H, lane);
+  if (capture) row_store_f32(rv, capture + (size_t)tok * H, H, lane);
+}
+
+// ModernBertPredictionHead + classifier on the pooled row (modeling_modernbert.py:481-490, 609-622):
+// logits = classifier(LN(gelu(dense(pooled)))).  One block per sequence; dense weight stored
+// transposed [k][n] so that thread n reads coalesced.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void rank_head_kernel(const float* __restrict__ cls, const float* __restrict__ y,
+                                                        const int32_t* __restrict__ cu, int s0,
+                                                        const int32_t* __restrict__ roff, int mean_pool, int H, int nl,
+                                                        const float* __restrict__ dense_t,
+                                                        const float* __restrict__ head_norm, float eps,
+                                                        const float* __restrict__ cls_w, const float* __restrict__ cls_b,
+                                                        float* __restrict__ rank_out) {
+  __shared__ float pooled[1024];
+  __shared__ float z[1024];
+  __shared__ float red[4];
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int len = cu[s0 + s + 1] - cu[s0 + s];
+  if (len <= 0) {
+    if (tid < nl) rank_out[(size_t)(s0 + s) * nl + tid] = 0.f;
+    return;
+  }
+  for (int k = tid; k < H; k += 256) {
+    float v;
+    if (mean_pool) {
+      const float* base = y + (size_t)roff[s] * H + k;
+      float acc = 0.f;
+      for (int p = 0; p < len; ++p) acc += base[(size_t)p * H];
+      v = acc / (float)len;
+    } else {
+      v = cls[(size_t)s * H + k];
+    }
+    pooled[k] = v;
+  }
+  __syncthreads();
+  float lsum = 0.f;
+  for (int n = tid; n < H; n += 256) {
+    float acc = 0.f;
+    for (int k = 0; k < H; ++k) acc = fmaf(pooled[k], dense_t[(size_t)k * H + n], acc);
+    const float gl = gelu_erf(acc);
+    z[n] = gl;
+    lsum += gl;
+  }
+  const float mean = block_sum_256(lsum, red) / (float)H;
+  float lq = 0.f;
+  for (int n = tid; n < H; n += 256) {
+    const float d = z[n] - mean;
+    lq += d * d;
+  }
+  const float var = block_sum_256(lq, red) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int c = 0; c < nl; ++c) {
+    float part = 0.f;
+    for (int n = tid; n < H; n += 256) part += (z[n] - mean) * rstd * head_norm[n] * cls_w[(size_t)c * H + n];
+    const float tot = block_sum_256(part, red);
+    if (tid == 0) rank_out[(size_t)(s0 + s) * nl + c] = tot + cls_b[c];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// weight re-packing (runs once per tensor at load time)
+// ----------------------------------------------------------------------------------------------
+__global__ void convert_to_f32_kernel(const void* __restrict__ src, int dtype, size_t n, float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (dtype == 0) {
+    dst[i] = reinterpret_cast<const float*>(src)[i];
+  } else if (dtype == 1) {
+    dst[i] = bf2f(reinterpret_cast<const u16*>(src)[i]);
+  } else {
+    dst[i] = __half2float(reinterpret_cast<const __half*>(src)[i]);
+  }
+}
+
+// dst planes [rows][cols]; source row for destination row r is perm(r): identity, or the GeGLU
+// interleave that puts the 32 "input" rows and the 32 matching "gate" rows of Wi in one 64-row slab.
+__global__ void split_planes_kernel(const float* __restrict__ src, int rows, int cols, int geglu_half,
+                                    u16* __restrict__ hi, u16* __restrict__ lo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  int sr = r;
+  if (geglu_half > 0) {
+    const int b = r >> 6, j = r & 63;
+    sr = (j < 32) ? (b * 32 + j) : (geglu_half + b * 32 + (j - 32));
+  }
+  const float v = src[(size_t)sr * cols + c];
+  const u16 h = f2bf(v);
+  hi[i] = h;
+  lo[i] = f2bf(v - bf2f(h));
+}
+
+__global__ void transpose_f32_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  dst[(size_t)c * rows + r] = src[i];
+}
+
+// ----------------------------------------------------------------------------------------------
+// GEMM  C[m, n] = sum_k A[m, k] * W[n, k]   (A = activation planes, W = nn.Linear weight planes)
+// 128 x 128 tile, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 accumulators.
+// "Swapped" orientation (X = W rows, Y = A rows) leaves every lane with 4 consecutive OUTPUT
+// FEATURES of one token, so all epilogues store 8-byte (bf16 planes) / 16-byte (fp32) pieces of a
+// token row; the V projection uses the plain orientation to emit V transposed ([feature][row]).
+// ----------------------------------------------------------------------------------------------
+enum GemmEpilogue {
+  EPI_QK_ROPE = 0,  // RoPE + (q * head_dim^-0.5) -> q / k planes                HF :188-219, :271-285
+  EPI_V_T = 1,      // V transposed planes [H][R_pad]
+  EPI_RESIDUAL = 2, // x += C  (attention Wo, MLP Wo)                            HF :331-332
+  EPI_GEGLU = 3     // gelu_erf(input) * gate -> h planes                        HF :89-91
+};
+
+struct GemmParams {
+  const u16* a_hi;
+  const u16* a_lo;
+  const u16* w_hi;
+  const u16* w_lo;
+  int K;        // reduction length (multiple of 32)
+  int n_tiles;  // N / 128
+  int m_tiles;  // R_pad / 128
+  float* x;     // EPI_RESIDUAL: [R_pad][ld_out] fp32, updated in place
+  u16* o0_hi;   // QK: q planes   V_T: vt planes   GEGLU: h planes
+  u16* o0_lo;
+  u16* o1_hi;   // QK: k planes
+  u16* o1_lo;
+  int ld_out;   // row stride (elements) of the output: H (QK, RESIDUAL), I (GEGLU), R_pad (V_T)
+  int hidden;   // H (QK: column where the k block starts)
+  const int32_t* row_pos;
+  const float* rope_cos;  // [max_pos][32]
+  const float* rope_sin;
+  int max_pos;
+};
+
+template <int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) u16 sA[2][GEMM_BM * GEMM_LDS];
+  __shared__ __attribute__((aligned(16))) u16 sW[2][GEMM_BN * GEMM_LDS];
+
+  // XCD-aware tile order: consecutive tiles (same token rows, different feature tiles) share an XCD
+  // and therefore its L2 copy of the A rows.  Bijective for any grid size.
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7;
+  const int qd = nwg >> 3, rem = nwg & 7;
+  const int wgid = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+  const int n_tile = wgid % p.n_tiles;
+  const int m_tile = wgid / p.n_tiles;
+  const int m0 = m_tile * GEMM_BM;
+  const int n0 = n_tile * GEMM_BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave & 1;   // token half of the tile
+  const int wn = wave >> 1;  // feature half of the tile
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+  const int K = p.K;
+
+  // staging: each plane tile is 128 rows x 32 k = 512 pieces of 16 B; thread handles pieces tid, tid+256
+  const int srow = tid >> 2;
+  const int skc = (tid & 3) * 8;
+  const u16* ga_hi = p.a_hi + (size_t)(m0 + srow) * K + skc;
+  const u16* ga_lo = p.a_lo + (size_t)(m0 + srow) * K + skc;
+  const u16* gw_hi = p.w_hi + (size_t)(n0 + srow) * K + skc;
+  const u16* gw_lo = p.w_lo + (size_t)(n0 + srow) * K + skc;
+  const size_t half_rows = (size_t)64 * K;
+  const int soff0 = srow * GEMM_LDS + skc;
+  const int soff1 = (srow + 64) * GEMM_LDS + skc;
+
+  // staging registers are plain scalars (arrays captured by lambdas end up in scratch memory)
+  uint4 ra_hi0, ra_hi1, rw_hi0, rw_hi1;
+  uint4 ra_lo0 = make_uint4(0, 0, 0, 0), ra_lo1 = ra_lo0, rw_lo0 = ra_lo0, rw_lo1 = ra_lo0;
+#define OPK_GLOAD(kt_)                                                       \
+  do {                                                                       \
+    const int ko_ = (kt_) * GEMM_BK;                                          \
+    ra_hi0 = *reinterpret_cast<const uint4*>(ga_hi + ko_);                    \
+    ra_hi1 = *reinterpret_cast<const uint4*>(ga_hi + half_rows + ko_);        \
+    rw_hi0 = *reinterpret_cast<const uint4*>(gw_hi + ko_);                    \
+    rw_hi1 = *reinterpret_cast<const uint4*>(gw_hi + half_rows + ko_);        \
+    if (SPLIT) {                                                             \
+      ra_lo0 = *reinterpret_cast<const uint4*>(ga_lo + ko_);                  \
+      ra_lo1 = *reinterpret_cast<const uint4*>(ga_lo + half_rows + ko_);      \
+      rw_lo0 = *reinterpret_cast<const uint4*>(gw_lo + ko_);                  \
+      rw_lo1 = *reinterpret_cast<const uint4*>(gw_lo + half_rows + ko_);      \
+    }                                                                        \
+  } while (0)
+#define OPK_LSTORE()                                              \
+  do {                                                            \
+    *reinterpret_cast<uint4*>(&sA[0][soff0]) = ra_hi0;            \
+    *reinterpret_cast<uint4*>(&sA[0][soff1]) = ra_hi1;            \
+    *reinterpret_cast<uint4*>(&sW[0][soff0]) = rw_hi0;            \
+    *reinterpret_cast<uint4*>(&sW[0][soff1]) = rw_hi1;            \
+    if (SPLIT) {                                                  \
+      *reinterpret_cast<uint4*>(&sA[1][soff0]) = ra_lo0;          \
+      *reinterpret_cast<uint4*>(&sA[1][soff1]) = ra_lo1;          \
+      *reinterpret_cast<uint4*>(&sW[1][soff0]) = rw_lo0;          \
+      *reinterpret_cast<uint4*>(&sW[1][soff1]) = rw_lo1;          \
+    }                                                             \
+  } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / GEMM_BK;
+  OPK_GLOAD(0);
+  OPK_LSTORE();
+  __syncthreads();
+
+  const int a_frag = (wm * 64 + l15) * GEMM_LDS + g * 8;
+  const int w_frag = (wn * 64 + l15) * GEMM_LDS + g * 8;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) OPK_GLOAD(kt + 1);
+    bf16x8 wf_hi[4], af_hi[4], wf_lo[4], af_lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wf_hi[i] = lds_frag(&sW[0][w_frag + i * 16 * GEMM_LDS]);
+      af_hi[i] = lds_frag(&sA[0][a_frag + i * 16 * GEMM_LDS]);
+      if (SPLIT) {
+        wf_lo[i] = lds_frag(&sW[1][w_frag + i * 16 * GEMM_LDS]);
+        af_lo[i] = lds_frag(&sA[1][a_frag + i * 16 * GEMM_LDS]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (EPI == EPI_V_T) {  // rows = tokens (j), cols = features (i)
+          if (SPLIT) {
+            acc[i][j] = mfma16(af_lo[j], wf_hi[i], acc[i][j]);
+            acc[i][j] = mfma16(af_hi[j], wf_lo[i], acc[i][j]);
+          }
+          acc[i][j] = mfma16(af_hi[j], wf_hi[i], acc[i][j]);
+        } else {  // rows = features (i), cols = tokens (j)
+          if (SPLIT) {
+            acc[i][j] = mfma16(wf_lo[i], af_hi[j], acc[i][j]);
+            acc[i][j] = mfma16(wf_hi[i], af_lo[j], acc[i][j]);
+          }
+          acc[i][j] = mfma16(wf_hi[i], af_hi[j], acc[i][j]);
+        }
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      OPK_LSTORE();
+      __syncthreads();
+    }
+  }
+#undef OPK_GLOAD
+#undef OPK_LSTORE
+
+  // ------------------------------------------------------------------------------------------
+  // epilogues
+  // ------------------------------------------------------------------------------------------
+  if (EPI == EPI_V_T) {
+    // acc[i][j][r]: token m0 + wm*64 + 16j + 4g + r, feature n0 + wn*64 + 16i + l15
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = n0 + wn * 64 + i * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + g * 4;
+        const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        uint2 h2, l2;
+        split4<SPLIT>(v, h2, l2);
+        const size_t off = (size_t)f * p.ld_out + m;
+        *reinterpret_cast<uint2*>(p.o0_hi + off) = h2;
+        if (SPLIT) *reinterpret_cast<uint2*>(p.o0_lo + off) = l2;
+      }
+    }
+    return;
+  }
+
+  // swapped orientation: acc[i][j][r]: feature n0 + wn*64 + 16i + 4g + r, token m0 + wm*64 + 16j + l15
+  if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + l15;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = n0 + wn * 64 + i * 16 + g * 4;
+        float4* px = reinterpret_cast<float4*>(p.x + (size_t)m * p.ld_out + f);
+        float4 r4 = *px;
+        r4.x += acc[i][j][0];
+        r4.y += acc[i][j][1];
+        r4.z += acc[i][j][2];
+        r4.w += acc[i][j][3];
+        *px = r4;
+      }
+    }
+    return;
+  }
+
+  if (EPI == EPI_GEGLU) {
+    // weight rows were interleaved at load time: within this wave's 64 features, i = 0,1 are 32
+    // "input" columns and i = 2,3 the 32 matching "gate" columns (Wi.chunk(2), HF :90).
+    const int out_col0 = (n0 >> 1) + wn * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + l15;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(acc[i][j][r]) * acc[i + 2][j][r];
+        uint2 h2, l2;
+        split4<SPLIT>(v, h2, l2);
+        const size_t off = (size_t)m * p.ld_out + out_col0 + i * 16 + g * 4;
+        *reinterpret_cast<uint2*>(p.o0_hi + off) = h2;
+        if (SPLIT) *reinterpret_cast<uint2*>(p.o0_lo + off) = l2;
+      }
+    }
+    return;
+  }
+
+  if (EPI == EPI_QK_ROPE) {
+    // this wave's 64 features are exactly one head of q (columns < hidden) or of k.
+    const int col = n0 + wn * 64;
+    const bool is_q = col < p.hidden;
+    u16* out_hi = is_q ? p.o0_hi : p.o1_hi;
+    u16* out_lo = is_q ? p.o0_lo : p.o1_lo;
+    const int out_col = is_q ? col : col - p.hidden;
+    const float qscale = is_q ? 0.125f : 1.0f;  // head_dim^-0.5, exact power of two
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + l15;
+      int pos = p.row_pos[m];
+      pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        // d = 16i + 4g + r pairs with d + 32 (rotate_half: first half / second half, HF :188-192)
+        const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + (size_t)pos * ROPE_HALF + i * 16 + g * 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + (size_t)pos * ROPE_HALF + i * 16 + g * 4);
+        const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
+        const float sn[4] = {s4.x, s4.y, s4.z, s4.w};
+        float lo_half[4], hi_half[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x1 = acc[i][j][r], x2 = acc[i + 2][j][r];
+          lo_half[r] = (x1 * cs[r] - x2 * sn[r]) * qscale;
+          hi_half[r] = (x2 * cs[r] + x1 * sn[r]) * qscale;
+        }
+        uint2 h2, l2;
+        const size_t off = (size_t)m * p.ld_out + out_col + i * 16 + g * 4;
+        split4<SPLIT>(lo_half, h2, l2);
+        *reinterpret_cast<uint2*>(out_hi + off) = h2;
+        if (SPLIT) *reinterpret_cast<uint2*>(out_lo + off) = l2;
+        split4<SPLIT>(hi_half, h2, l2);
+        *reinterpret_cast<uint2*>(out_hi + off + 32) = h2;
+        if (SPLIT) *reinterpret_cast<uint2*>(out_lo + off + 32) = l2;
+      }
+    }
+    return;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Attention over the packed layout.  One block = 64 queries of one (sequence, head); each of the 4
+// waves owns 16 queries.  Scores are computed TRANSPOSED (S^T = K Q^T) so that a lane owns ONE query
+// column: the online softmax needs two cross-lane steps per tile, P never leaves registers, and
+// O^T = V^T P^T consumes it directly as the MFMA Y operand.  K rows are stored in LDS in a permuted
+// order chosen so that the 8 keys a lane holds after S^T are 8 CONSECUTIVE keys -> the V^T operand is
+// one 16-byte LDS read.  window < 0: full attention; else keys with |q - k| <= window
+// (masking_utils.py:141-150), always intersected with key < len (the padding mask).
+// ----------------------------------------------------------------------------------------------
+struct AttnParams {
+  const u16* q_hi;
+  const u16* q_lo;
+  const u16* k_hi;
+  const u16* k_lo;
+  const u16* vt_hi;  // [H][r_pad]
+  const u16* vt_lo;
+  u16* o_hi;
+  u16* o_lo;
+  const int32_t* cu;
+  int s0;
+  const int32_t* roff;
+  int H;
+  int r_pad;
+  int window;
+};
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) u16 sK[2][ATT_BK * ATT_LDS];
+  __shared__ __attribute__((aligned(16))) u16 sV[2][HEAD_DIM * ATT_LDS];
+
+  const int s = blockIdx.z;
+  const int head = blockIdx.y;
+  const int q0 = blockIdx.x * ATT_BQ;
+  const int seq_start = p.cu[p.s0 + s];
+  const int len = p.cu[p.s0 + s + 1] - seq_start;
+  if (q0 >= len) return;
+  const int r0 = p.roff[s];
+  const int alloc = p.roff[s + 1] - r0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+  const int H = p.H;
+  const int hcol = head * HEAD_DIM;
+
+  const int qbase = q0 + wave * 16;
+  const bool active = qbase < alloc;  // alloc is a multiple of 16: whole wave in or out
+  const int qpos = qbase + l15;
+  const size_t qrow = (size_t)(r0 + (active ? qpos : q0));
+
+  bf16x8 qf_hi[2], qf_lo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf_hi[ks] = as_frag(*reinterpret_cast<const uint4*>(p.q_hi + qrow * H + hcol + ks * 32 + g * 8));
+    if (SPLIT) qf_lo[ks] = as_frag(*reinterpret_cast<const uint4*>(p.q_lo + qrow * H + hcol + ks * 32 + g * 8));
+  }
+
+  int kt_lo = 0, kt_hi = (len - 1) / ATT_BK;
+  if (p.window >= 0) {
+    const int lo_key = q0 - p.window;
+    kt_lo = lo_key > 0 ? lo_key / ATT_BK : 0;
+    const int hi_key = q0 + ATT_BQ - 1 + p.window;
+    const int hi_t = hi_key / ATT_BK;
+    kt_hi = hi_t < kt_hi ? hi_t : kt_hi;
+  }
+
+  float m_run = -1e30f;
+  float l_run = 0.f;
+  f32x4 oacc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) oacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: tile = 64 rows x 64 elements = 512 pieces of 16 B per plane; thread handles 2
+  const int prow = tid >> 3;          // 0..31 (+32 for the second piece)
+  const int pcol = (tid & 7) * 8;
+  auto kperm = [](int key) { return (key & 32) | (((key >> 2) & 1) << 4) | (((key >> 3) & 3) << 2) | (key & 3); };
+
+  for (int kt = kt_lo; kt <= kt_hi; ++kt) {
+    const int kbase = kt * ATT_BK;
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = prow + 32 * u;
+      const size_t grow = (size_t)(r0 + kbase + row) * H + hcol + pcol;
+      const int kdst = kperm(row) * ATT_LDS + pcol;
+      *reinterpret_cast<uint4*>(&sK[0][kdst]) = *reinterpret_cast<const uint4*>(p.k_hi + grow);
+      const size_t gv = (size_t)(hcol + row) * p.r_pad + r0 + kbase + pcol;
+      const int vdst = row * ATT_LDS + pcol;
+      *reinterpret_cast<uint4*>(&sV[0][vdst]) = *reinterpret_cast<const uint4*>(p.vt_hi + gv);
+      if (SPLIT) {
+        *reinterpret_cast<uint4*>(&sK[1][kdst]) = *reinterpret_cast<const uint4*>(p.k_lo + grow);
+        *reinterpret_cast<uint4*>(&sV[1][vdst]) = *reinterpret_cast<const uint4*>(p.vt_lo + gv);
+      }
+    }
+    __syncthreads();
+
+    // S^T tile: rows = keys (4 fragments of 16 LDS rows), column = this lane's query
+    f32x4 sacc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) sacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int off = (m * 16 + l15) * ATT_LDS + ks * 32 + g * 8;
+        const bf16x8 kh = lds_frag(&sK[0][off]);
+        if (SPLIT) {
+          const bf16x8 kl = lds_frag(&sK[1][off]);
+          sacc[m] = mfma16(kl, qf_hi[ks], sacc[m]);
+          sacc[m] = mfma16(kh, qf_lo[ks], sacc[m]);
+        }
+        sacc[m] = mfma16(kh, qf_hi[ks], sacc[m]);
+      }
+    }
+
+    // element (m, r) of this lane: key = kbase + 32*(m>>1) + 8*g + 4*(m&1) + r
+    float tile_max = -1e30f;
+    bool valid[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kbase + 32 * (m >> 1) + 8 * g + 4 * (m & 1) + r;
+        bool ok = key < len;
+        if (p.window >= 0) {
+          const int d = key - qpos;
+          ok = ok && (d <= p.window) && (d >= -p.window);
+        }
+        valid[m][r] = ok;
+        if (ok) tile_max = fmaxf(tile_max, sacc[m][r]);
+      }
+    }
+    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 16, 64));
+    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
+    const float m_new = fmaxf(m_run, tile_max);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    float pv[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = valid[m][r] ? __expf(sacc[m][r] - m_new) : 0.f;
+        pv[m][r] = e;
+        psum += e;
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      oacc[n][0] *= alpha;
+      oacc[n][1] *= alpha;
+      oacc[n][2] *= alpha;
+      oacc[n][3] *= alpha;
+    }
+
+    // O^T += V^T P^T, two k-steps of 32 keys; lane's k-slots = keys 32t + 8g + (0..7)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float v8[8] = {pv[2 * t][0],     pv[2 * t][1],     pv[2 * t][2],     pv[2 * t][3],
+                           pv[2 * t + 1][0], pv[2 * t + 1][1], pv[2 * t + 1][2], pv[2 * t + 1][3]};
+      uint2 h0, l0, h1, l1;
+      split4<SPLIT>(v8, h0, l0);
+      split4<SPLIT>(v8 + 4, h1, l1);
+      const bf16x8 ph = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
+      const bf16x8 pl = as_frag(make_uint4(l0.x, l0.y, l1.x, l1.y));
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int off = (n * 16 + l15) * ATT_LDS + t * 32 + g * 8;
+        const bf16x8 vh = lds_frag(&sV[0][off]);
+        if (SPLIT) {
+          const bf16x8 vl = lds_frag(&sV[1][off]);
+          oacc[n] = mfma16(vl, ph, oacc[n]);
+          oacc[n] = mfma16(vh, pl, oacc[n]);
+        }
+        oacc[n] = mfma16(vh, ph, oacc[n]);
+      }
+    }
+  }
+
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (active) {
+    // oacc[n][r]: d = 16n + 4g + r of query qpos
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const float v[4] = {oacc[n][0] * inv, oacc[n][1] * inv, oacc[n][2] * inv, oacc[n][3] * inv};
+      uint2 h2, l2;
+      split4<SPLIT>(v, h2, l2);
+      const size_t off = qrow * H + hcol + n * 16 + g * 4;
+      *reinterpret_cast<uint2*>(p.o_hi + off) = h2;
+      if (SPLIT) *reinterpret_cast<uint2*>(p.o_lo + off) = l2;
+    }
+  }
+}
+
+}  // namespace opk

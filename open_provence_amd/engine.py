@@ -1,0 +1,238 @@
+"""``HipEncoder``: one handle of ``libopenprovence_hip.so`` bound to one GPU.
+
+PyTorch-ROCm is used here for exactly three things -- owning device buffers (ids, outputs, workspace),
+naming the current HIP stream, and reading checkpoint tensors -- never for arithmetic on the forward
+path.  Everything numerical happens inside ``op_forward_packed`` (``include/open_provence_hip.h``).
+"""
+
+from __future__ import annotations
+
+import ctypes
+from contextlib import contextmanager
+from typing import Iterator, Mapping, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EncoderDims
+from .packing import pack_rows
+
+_PRECISIONS = {"bf16x3": _lib.OP_PRECISION_BF16X3, "bf16": _lib.OP_PRECISION_BF16}
+_DTYPES = {torch.float32: _lib.OP_DTYPE_F32, torch.bfloat16: _lib.OP_DTYPE_BF16, torch.float16: _lib.OP_DTYPE_F16}
+
+
+def require_gpu(device: torch.device | str | int | None = None) -> torch.device:
+    """Resolve a HIP device or fail loudly (the product has no CPU path)."""
+
+    if not torch.cuda.is_available():
+        raise _lib.HipLibraryError(
+            "No HIP device visible to PyTorch-ROCm: the OpenProvence MI355X path runs only on a GPU "
+            "(there is no CPU fallback; the CPU restatement under oracle/ is test infrastructure)."
+        )
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+    if dev.type != "cuda":
+        raise _lib.HipLibraryError(f"device {dev} is not a HIP device")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+class HipEncoder:
+    """ModernBERT cross-encoder + pruning/ranking heads as hand-written gfx950 kernels."""
+
+    def __init__(
+        self,
+        dims: EncoderDims,
+        *,
+        device: torch.device | str | int | None = None,
+        precision: str = "bf16x3",
+        chunk_rows: int | None = None,
+    ) -> None:
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self.lib = _lib.load_library()
+        self.device = require_gpu(device)
+        self.dims = dims
+        self.precision = precision
+        if dims.num_layers > _lib.OP_MAX_LAYERS:
+            raise ValueError("too many layers")
+        cfg = _lib.OpConfig()
+        cfg.struct_bytes = ctypes.sizeof(_lib.OpConfig)
+        cfg.device_id = int(self.device.index)
+        cfg.vocab_size = dims.vocab_size
+        cfg.hidden_size = dims.hidden_size
+        cfg.intermediate_size = dims.intermediate_size
+        cfg.num_layers = dims.num_layers
+        cfg.num_heads = dims.num_heads
+        cfg.num_labels = dims.num_labels
+        cfg.local_attention = dims.local_attention
+        cfg.max_position_embeddings = dims.max_position_embeddings
+        cfg.pooling = _lib.OP_POOL_MEAN if dims.classifier_pooling == "mean" else _lib.OP_POOL_CLS
+        cfg.precision = _PRECISIONS[precision]
+        cfg.norm_eps = dims.norm_eps
+        cfg.global_rope_theta = dims.global_rope_theta
+        cfg.local_rope_theta = dims.local_rope_theta
+        cfg.chunk_rows = int(chunk_rows or 0)
+        for i, flag in enumerate(dims.layer_is_global):
+            cfg.layer_is_global[i] = 1 if flag else 0
+        handle = ctypes.c_void_p()
+        code = self.lib.op_create(ctypes.byref(cfg), ctypes.byref(handle))
+        _lib.check(self.lib, None, code, "op_create")
+        self._handle = handle
+        self._workspace: torch.Tensor | None = None
+        self._capture: torch.Tensor | None = None
+        self._capture_result: torch.Tensor | None = None
+
+    # -- lifecycle -------------------------------------------------------------------------------
+    def close(self) -> None:
+        handle = getattr(self, "_handle", None)
+        if handle is not None and handle.value:
+            self.lib.op_destroy(handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_weight(self, name: str, tensor: torch.Tensor) -> None:
+        t = tensor.detach()
+        if t.dtype not in _DTYPES:
+            t = t.to(torch.float32)
+        t = t.contiguous()
+        shape = (ctypes.c_int64 * max(t.ndim, 1))(*([int(s) for s in t.shape] or [1]))
+        code = self.lib.op_load_weight(
+            self._handle, name.encode("utf-8"), ctypes.c_void_p(t.data_ptr()), _DTYPES[t.dtype], shape, max(t.ndim, 1)
+        )
+        _lib.check(self.lib, self._handle, code, f"op_load_weight({name})")
+
+    def load_state_dict(self, state: Mapping[str, torch.Tensor]) -> None:
+        """Checkpoint keys as in the reference's ``model.safetensors`` (``ranking_model.*`` /
+        ``pruning_head.*``; legacy checkpoints without the prefix are accepted, standalone.py:1452-1464).
+        Non-persistent buffers (``inv_freq``) and training-only tensors are skipped."""
+
+        for name, tensor in state.items():
+            if "inv_freq" in name or name.endswith("pooling_weights.weight") or name.endswith("pooling_weights.bias"):
+                continue
+            self.load_weight(name, tensor)
+        _lib.check(self.lib, self._handle, self.lib.op_weights_ready(self._handle), "op_weights_ready")
+
+    # -- forward ---------------------------------------------------------------------------------
+    def _ensure_workspace(self, n_seqs: int, total_tokens: int, max_seqlen: int) -> torch.Tensor:
+        need = int(self.lib.op_workspace_bytes(self._handle, n_seqs, total_tokens, max_seqlen))
+        if need <= 0:
+            raise _lib.HipLibraryError("op_workspace_bytes returned 0")
+        ws = self._workspace
+        if ws is None or ws.numel() < need:
+            self._workspace = None
+            ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._workspace = ws
+        return ws
+
+    def forward_packed(
+        self,
+        ids: torch.Tensor,
+        cu_seqlens: torch.Tensor,
+        cu_seqlens_host: np.ndarray,
+        max_seqlen: int,
+    ) -> tuple[torch.Tensor, torch.Tensor]:
+        """``ids[T]`` / ``cu_seqlens[B+1]`` int32 on this device -> (prune_logits[T, 2], rank_logits[B, nl]) fp32.
+
+        Asynchronous on the current torch stream of ``self.device``."""
+
+        if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
+            raise TypeError("ids and cu_seqlens must be int32")
+        if ids.device != self.device or cu_seqlens.device != self.device:
+            raise ValueError(f"ids/cu_seqlens must live on {self.device}")
+        total = int(ids.numel())
+        n_seqs = int(cu_seqlens.numel()) - 1
+        cu_host = np.ascontiguousarray(cu_seqlens_host, dtype=np.int32)
+        if cu_host.shape[0] != n_seqs + 1:
+            raise ValueError("cu_seqlens_host length mismatch")
+        prune = torch.empty((total, 2), dtype=torch.float32, device=self.device)
+        rank = torch.empty((n_seqs, self.dims.num_labels), dtype=torch.float32, device=self.device)
+        if n_seqs == 0:
+            return prune, rank
+        ws = self._ensure_workspace(n_seqs, total, int(max_seqlen))
+        base = ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        capture_ptr = None
+        if self._capture is not None:
+            self._capture = torch.zeros(
+                (self.dims.num_layers + 1, total, self.dims.hidden_size), dtype=torch.float32, device=self.device
+            )
+            capture_ptr = ctypes.c_void_p(self._capture.data_ptr())
+            _lib.check(self.lib, self._handle, self.lib.op_debug_capture_hidden(self._handle, capture_ptr), "capture")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            code = self.lib.op_forward_packed(
+                self._handle,
+                ctypes.c_void_p(ids.data_ptr()),
+                ctypes.c_void_p(cu_seqlens.data_ptr()),
+                cu_host.ctypes.data_as(ctypes.c_void_p),
+                n_seqs,
+                total,
+                int(max_seqlen),
+                ctypes.c_void_p(prune.data_ptr()),
+                ctypes.c_void_p(rank.data_ptr()),
+                ctypes.c_void_p(aligned),
+                ctypes.c_size_t(ws.numel() - (aligned - base)),
+                ctypes.c_void_p(stream),
+            )
+        _lib.check(self.lib, self._handle, code, "op_forward_packed")
+        return prune, rank
+
+    def forward_rows(self, rows: Sequence[Sequence[int]]) -> tuple[torch.Tensor, torch.Tensor, np.ndarray]:
+        """Convenience: host id rows -> one H2D copy -> forward.  Returns (prune[T,2], rank[B,nl], cu_host)."""
+
+        ids_np, cu_np, max_len = pack_rows(rows)
+        ids = torch.from_numpy(ids_np).to(self.device, non_blocking=False)
+        cu = torch.from_numpy(cu_np).to(self.device, non_blocking=False)
+        prune, rank = self.forward_packed(ids, cu, cu_np, max_len)
+        return prune, rank, cu_np
+
+    # -- test / measurement hooks ------------------------------------------------------------------
+    @contextmanager
+    def capture_hidden(self) -> Iterator[None]:
+        """While active, each forward also stores the N+1 hidden states; read :attr:`captured`."""
+
+        self._capture = torch.empty(0)
+        try:
+            yield
+        finally:
+            self.lib.op_debug_capture_hidden(self._handle, None)
+            self._capture_result = self._capture
+            self._capture = None
+
+    @property
+    def captured(self) -> torch.Tensor:
+        return self._capture_result
+
+    def profile_enable(self, enabled: bool) -> None:
+        _lib.check(self.lib, self._handle, self.lib.op_profile_enable(self._handle, 1 if enabled else 0), "profile")
+
+    def profile_reset(self) -> None:
+        _lib.check(self.lib, self._handle, self.lib.op_profile_reset(self._handle), "profile_reset")
+
+    def profile_read(self) -> dict[str, dict[str, float]]:
+        """Kernel kind -> {launches, total_ms, avg_ms}; HIP events recorded on the launch stream."""
+
+        entries = (_lib.OpProfileEntry * 32)()
+        n = self.lib.op_profile_read(self._handle, entries, 32)
+        if n < 0:
+            _lib.check(self.lib, self._handle, n, "op_profile_read")
+        out: dict[str, dict[str, float]] = {}
+        for i in range(n):
+            e = entries[i]
+            name = self.lib.op_profile_kind_name(e.kind).decode()
+            out[name] = {
+                "launches": int(e.launches),
+                "total_ms": float(e.total_ms),
+                "avg_ms": float(e.total_ms) / max(int(e.launches), 1),
+            }
+        return out

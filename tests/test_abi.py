@@ -1,0 +1,69 @@
+"""The C-ABI library must load on a CPU-only box and export every symbol include/open_provence_hip.h
+declares; without a GPU its entry points must fail loudly (no fallback), never compute."""
+
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+from open_provence_amd import _lib
+
+HEADER = Path(__file__).resolve().parents[1] / "include" / "open_provence_hip.h"
+
+
+def declared_functions() -> list[str]:
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(op_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == sorted(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(hip_library):
+    for name in declared_functions():
+        assert hasattr(hip_library, name), name
+    assert hip_library.op_abi_version() == _lib.OP_ABI_VERSION
+
+
+def test_config_struct_size_is_checked(hip_library):
+    cfg = _lib.OpConfig()
+    cfg.struct_bytes = 12  # wrong on purpose
+    handle = ctypes.c_void_p()
+    code = hip_library.op_create(ctypes.byref(cfg), ctypes.byref(handle))
+    assert code == -1 and not handle.value
+    assert "struct_bytes" in _lib.last_error(hip_library, None)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure(hip_library):
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims
+
+    with pytest.raises(_lib.HipLibraryError, match="no CPU fallback"):
+        HipEncoder(named_dims("xsmall", vocab_size=1024))
+    cfg = _lib.OpConfig()
+    cfg.struct_bytes = ctypes.sizeof(_lib.OpConfig)
+    cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size = 256, 128, 128
+    cfg.num_layers, cfg.num_heads, cfg.num_labels = 2, 2, 1
+    cfg.local_attention, cfg.max_position_embeddings = 128, 512
+    cfg.norm_eps, cfg.global_rope_theta, cfg.local_rope_theta = 1e-5, 160000.0, 10000.0
+    handle = ctypes.c_void_p()
+    code = hip_library.op_create(ctypes.byref(cfg), ctypes.byref(handle))
+    assert code == -3 and not handle.value
+    assert "no CPU fallback" in _lib.last_error(hip_library, None)
+
+
+def test_unsupported_head_dim_is_rejected_before_touching_the_device(hip_library):
+    cfg = _lib.OpConfig()
+    cfg.struct_bytes = ctypes.sizeof(_lib.OpConfig)
+    cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size = 256, 64, 96
+    cfg.num_layers, cfg.num_heads, cfg.num_labels = 2, 4, 1
+    cfg.local_attention, cfg.max_position_embeddings = 16, 512
+    handle = ctypes.c_void_p()
+    code = hip_library.op_create(ctypes.byref(cfg), ctypes.byref(handle))
+    assert code == -2
+    assert "head_dim" in _lib.last_error(hip_library, None)
