@@ -1,0 +1,1145 @@
+"""``OpenProvenceModel`` -- the drop-in for the reference's inference class on MI355X.
+
+Same public surface as ``open_provence/modeling_open_provence_standalone.py`` (class, method and keyword
+names, result keys, error behaviour) for the path BASELINE.json names:
+
+* ``forward(input_ids, attention_mask, ...)``   ref: standalone.py:1666-1739
+* ``process(question, context, ...)``           ref: standalone.py:3314-3808
+* ``get_raw_predictions(_batch)`` / ``predict_with_thresholds``   ref: :1741-1881
+* ``from_pretrained(path, device=, max_length=, torch_dtype=)``   ref: :1557-1664
+* ``OpenProvenceForSequenceClassification`` / ``OpenProvenceForTokenClassification``  ref: :3814-3906
+
+The arithmetic is NOT here: ``forward`` packs the batch and calls the C ABI
+(``include/open_provence_hip.h``) through :class:`open_provence_amd.engine.HipEncoder`.  Without the HIP
+library or without a GPU, construction raises -- there is no fallback.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import json
+import logging
+import os
+import warnings
+from collections.abc import Callable, Iterable, Mapping, Sequence
+from dataclasses import dataclass
+from pathlib import Path
+from time import perf_counter
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import pipeline as pl
+from .config import DEFAULT_PROCESS_THRESHOLD, EncoderDims, OpenProvenceConfig
+from .engine import HipEncoder, require_gpu
+from .packing import pack_padded, pack_rows, unpack_to_padded
+from .pipeline import ContextState, FragmentRecord, RawPrediction
+from .splitters import SentenceSplitter, resolve_sentence_splitter
+
+LOGGER = logging.getLogger(__name__)
+
+DEFAULT_SPLITTER_LANGUAGE = "auto"
+OpenProvenceRawPrediction = RawPrediction
+
+_PROGRESS_BAR_ENABLED = True
+
+
+def enable_progress_bar() -> None:
+    global _PROGRESS_BAR_ENABLED
+    _PROGRESS_BAR_ENABLED = True
+
+
+def disable_progress_bar() -> None:
+    global _PROGRESS_BAR_ENABLED
+    _PROGRESS_BAR_ENABLED = False
+
+
+def is_progress_bar_enabled() -> bool:
+    return _PROGRESS_BAR_ENABLED
+
+
+@dataclass(frozen=True)
+class ProcessPerformanceTrace:
+    """Stage timers returned by every ``process()`` call (ref: standalone.py:377-404).  Unlike the
+    reference, ``inference_seconds`` is measured with a device synchronisation on both sides."""
+
+    preprocess_seconds: float = 0.0
+    assembly_seconds: float = 0.0
+    inference_seconds: float = 0.0
+    postprocess_seconds: float = 0.0
+    total_seconds: float = 0.0
+    sentence_collect_seconds: float = 0.0
+    sentence_normalize_seconds: float = 0.0
+    tokenize_seconds: float = 0.0
+    fragment_split_seconds: float = 0.0
+    fragment_decode_seconds: float = 0.0
+
+    def as_dict(self) -> dict[str, float]:
+        return {name: float(getattr(self, name)) for name in self.__dataclass_fields__}
+
+
+class OpenProvenceOutput(dict):
+    """Forward result usable both as a Mapping and through attributes, exposing the reference's fields:
+    ``logits`` (= ``ranking_logits``), ``ranking_logits``, ``pruning_logits``, ``loss``, ``hidden_states``."""
+
+    def __getattr__(self, name: str) -> Any:
+        try:
+            return self[name]
+        except KeyError as exc:
+            raise AttributeError(name) from exc
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        self[name] = value
+
+
+def _precision_from_dtype(dtype: Any) -> str:
+    """``torch_dtype`` of the reference API -> MFMA operand mode.  fp32 / None -> the parity-grade split
+    mode; bf16 / fp16 -> single-pass bf16 operands (what those dtypes mean on the reference's GPU path)."""
+
+    if dtype is None:
+        return "bf16x3"
+    if isinstance(dtype, torch.dtype):
+        if dtype == torch.float32:
+            return "bf16x3"
+        if dtype in (torch.bfloat16, torch.float16):
+            return "bf16"
+        raise TypeError(f"Unsupported dtype value: {dtype!r}")
+    text = str(dtype).strip().lower()
+    if text in {"auto", "float32", "fp32", "32", "bf16x3"}:
+        return "bf16x3"
+    if text in {"bfloat16", "bf16", "float16", "fp16", "half"}:
+        return "bf16"
+    raise TypeError(f"Unsupported dtype value: {dtype!r}")
+
+
+def _load_checkpoint_tensors(directory: Path) -> dict[str, torch.Tensor]:
+    from safetensors.torch import load_file
+
+    single = directory / "model.safetensors"
+    if single.exists():
+        return load_file(str(single))
+    index = directory / "model.safetensors.index.json"
+    if index.exists():
+        with open(index, "r", encoding="utf-8") as handle:
+            shards = sorted(set(json.load(handle)["weight_map"].values()))
+        state: dict[str, torch.Tensor] = {}
+        for shard in shards:
+            state.update(load_file(str(directory / shard)))
+        return state
+    legacy = directory / "pytorch_model.bin"
+    if legacy.exists():
+        return torch.load(str(legacy), map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {directory}")
+
+
+class OpenProvenceModel:
+    """Reranker + pruning head on hand-written gfx950 kernels, with the reference's public API."""
+
+    config_class = OpenProvenceConfig
+
+    # ------------------------------------------------------------------------------------------
+    # construction
+    # ------------------------------------------------------------------------------------------
+    def __init__(
+        self,
+        config: OpenProvenceConfig,
+        *,
+        device: str | torch.device | None = None,
+        tokenizer: Any | None = None,
+        state_dict: Mapping[str, torch.Tensor] | None = None,
+        precision: str | None = None,
+        torch_dtype: Any | None = None,
+        chunk_rows: int | None = None,
+    ) -> None:
+        self.config = config
+        self.max_length = int(config.max_length)
+        self.num_labels = int(config.num_labels)
+        self.num_pruning_labels = int(config.num_pruning_labels)
+        if self.num_pruning_labels != 2:
+            raise ValueError("the pruning head has exactly 2 labels (keep / drop)")
+        self.default_splitter_language = DEFAULT_SPLITTER_LANGUAGE
+        try:
+            self._runtime_device = require_gpu(self._normalize_device(device))
+        except ValueError as exc:
+            raise ValueError(f"Invalid device specification for {type(self).__name__}: {device!r}") from exc
+        self.dims: EncoderDims = config.encoder_dims()
+        head_hidden = int(config.pruning_config.get("hidden_size", self.dims.hidden_size))
+        if head_hidden != self.dims.hidden_size:
+            raise ValueError("pruning_config.hidden_size must equal the backbone hidden_size")
+        self.precision = precision or _precision_from_dtype(torch_dtype)
+        if chunk_rows is None and os.getenv("OPEN_PROVENCE_CHUNK_ROWS"):
+            chunk_rows = int(os.environ["OPEN_PROVENCE_CHUNK_ROWS"])
+        self.encoder = HipEncoder(self.dims, device=self._runtime_device, precision=self.precision, chunk_rows=chunk_rows)
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+        self.tokenizer = tokenizer if tokenizer is not None else self._init_tokenizer(config)
+        self._manual_special_tokens_required = False
+        self._manual_cls_token_id: int | None = None
+        self._manual_sep_token_id: int | None = None
+        self._update_tokenizer_runtime()
+        self._update_runtime_defaults()
+        self.default_threshold = self._resolve_default_threshold(config)
+
+    @staticmethod
+    def _normalize_device(device: str | torch.device | None) -> torch.device | None:
+        if device is None or isinstance(device, torch.device):
+            return device
+        text = str(device).strip().lower()
+        if not text or text == "auto":
+            return None
+        if text.startswith("cuda"):
+            return torch.device(text)
+        if text == "cpu" or text.startswith("mps"):
+            raise ValueError(f"{device!r}: the MI355X path has no CPU/MPS implementation")
+        raise ValueError(f"Unsupported device specification: {device!r}")
+
+    def _init_tokenizer(self, config: OpenProvenceConfig) -> Any:
+        reference = config.tokenizer_name_or_path or config._name_or_path or config.base_model_name_or_path
+        if not reference:
+            raise ValueError("Unable to determine tokenizer reference for OpenProvence model.")
+        try:
+            from transformers import AutoTokenizer  # text front-end only; never on the arithmetic path
+
+            return AutoTokenizer.from_pretrained(reference)
+        except Exception as exc:
+            raise RuntimeError(f"Failed to initialize tokenizer from '{reference}'.") from exc
+
+    def _update_tokenizer_runtime(self, max_length_override: int | None = None) -> None:
+        """Lift the tokenizer's model_max_length so sentence pre-tokenisation never truncates (ref :1391-1399)."""
+
+        if self.tokenizer is None:
+            return
+        upper = max(getattr(self.tokenizer, "model_max_length", 0) or 0, 1_000_000)
+        if max_length_override is not None and max_length_override > 0:
+            upper = max(upper, int(max_length_override))
+        elif self.max_length and self.max_length > 0:
+            upper = max(upper, int(self.max_length))
+        try:
+            self.tokenizer.model_max_length = upper
+        except Exception:  # pragma: no cover - exotic tokenizer objects
+            pass
+
+    def _update_runtime_defaults(self) -> None:
+        self._manual_special_tokens_required = pl.requires_manual_special_tokens(self.tokenizer)
+        if self._manual_special_tokens_required:
+            cls_c, sep_c = pl.special_token_candidates(self.tokenizer)
+            self._manual_cls_token_id = cls_c[0] if cls_c else None
+            self._manual_sep_token_id = sep_c[0] if sep_c else None
+        else:
+            self._manual_cls_token_id = None
+            self._manual_sep_token_id = None
+
+    def _resolve_default_threshold(self, config: OpenProvenceConfig) -> float:
+        value = getattr(config, "default_threadshold", None)
+        if value is None:
+            return DEFAULT_PROCESS_THRESHOLD
+        try:
+            return float(value)
+        except (TypeError, ValueError) as exc:
+            raise TypeError("OpenProvenceConfig.default_threadshold must be numeric when provided.") from exc
+
+    def _resolve_process_threshold(self, threshold: float | None) -> float:
+        resolved = threshold
+        if resolved is None:
+            resolved = getattr(self, "default_threshold", DEFAULT_PROCESS_THRESHOLD)
+            if resolved is None:
+                resolved = DEFAULT_PROCESS_THRESHOLD
+        try:
+            return float(resolved)
+        except (TypeError, ValueError) as exc:
+            raise TypeError("Resolved threshold must be numeric.") from exc
+
+    # nn.Module-flavoured no-ops so that calling code written for the reference keeps working
+    def eval(self) -> "OpenProvenceModel":
+        return self
+
+    def to(self, *args: Any, **kwargs: Any) -> "OpenProvenceModel":
+        target = kwargs.get("device", args[0] if args else None)
+        if target is not None and not isinstance(target, torch.dtype):
+            resolved = require_gpu(self._normalize_device(target))
+            if resolved != self._runtime_device:
+                raise NotImplementedError("moving a loaded model between GPUs is not supported; reload on the target device")
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self._runtime_device
+
+    @staticmethod
+    def _convert_legacy_state_dict(state_dict: Mapping[str, torch.Tensor]) -> Mapping[str, torch.Tensor]:
+        """Checkpoints saved without the ``ranking_model.`` prefix are re-prefixed (ref :1452-1464)."""
+
+        if any(key.startswith("ranking_model.") for key in state_dict):
+            return state_dict
+        return {(k if k.startswith("pruning_head.") else f"ranking_model.{k}"): v for k, v in state_dict.items()}
+
+    def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = True) -> None:
+        self.encoder.load_state_dict(self._convert_legacy_state_dict(state_dict))
+
+    @classmethod
+    def from_pretrained(
+        cls,
+        pretrained_model_name_or_path: str | Path,
+        *,
+        device: str | torch.device | None = None,
+        trust_remote_code: bool = True,
+        max_length: int | None = None,
+        torch_dtype: torch.dtype | str | None = None,
+        tokenizer: Any | None = None,
+        **kwargs: Any,
+    ) -> "OpenProvenceModel":
+        """Load ``config.json`` + ``model.safetensors`` (+ tokenizer files) from a local checkpoint directory
+        in the reference's format (ref: encoder.py:1040-1094).  There is no network in this build: hub ids
+        must already be materialised on disk."""
+
+        directory = Path(pretrained_model_name_or_path)
+        if not directory.is_dir():
+            raise FileNotFoundError(
+                f"{pretrained_model_name_or_path!r} is not a local checkpoint directory (hub download is unavailable)"
+            )
+        config = OpenProvenceConfig.from_json_file(directory / "config.json")
+        config._name_or_path = str(directory)
+        if "dtype" in kwargs and torch_dtype is None:
+            torch_dtype = kwargs.pop("dtype")
+        kwargs.pop("attn_implementation", None)  # HF knob; the HIP attention kernel is the only implementation
+        if max_length is not None:
+            config.max_length = int(max_length)
+        state = _load_checkpoint_tensors(directory)
+        model = cls(
+            config,
+            device=device,
+            tokenizer=tokenizer,
+            state_dict=state,
+            torch_dtype=torch_dtype,
+            precision=kwargs.pop("precision", None),
+            chunk_rows=kwargs.pop("chunk_rows", None),
+        )
+        if max_length is not None:
+            model.max_length = int(max_length)
+        model._update_tokenizer_runtime(max_length_override=max_length)
+        model._update_runtime_defaults()
+        return model
+
+    # ------------------------------------------------------------------------------------------
+    # forward boundary
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _extract_model_output(outputs: Any, key: str) -> torch.Tensor:
+        candidate = None
+        if isinstance(outputs, Mapping):
+            candidate = outputs.get(key)
+            if candidate is None and key == "ranking_logits":
+                candidate = outputs.get("logits")
+        if candidate is None:
+            candidate = getattr(outputs, key, None)
+            if candidate is None and key == "ranking_logits":
+                candidate = getattr(outputs, "logits", None)
+        if candidate is None:
+            raise KeyError(f"{key} not found in model outputs")
+        return candidate
+
+    def forward(
+        self,
+        input_ids: torch.Tensor | None = None,
+        attention_mask: torch.Tensor | None = None,
+        labels: torch.Tensor | None = None,
+        return_dict: bool | None = None,
+        **kwargs: Any,
+    ) -> OpenProvenceOutput | tuple[torch.Tensor, ...]:
+        """``input_ids[B, L]`` (+ right-padded ``attention_mask``) -> ``ranking_logits[B, nl]`` and
+        ``pruning_logits[B, L, 2]`` (fp32, on the GPU; zeros at padding positions).  ``token_type_ids`` and
+        other HF kwargs are accepted and ignored, as ModernBERT ignores them."""
+
+        if input_ids is None:
+            raise ValueError("input_ids must be provided")
+        if labels is not None:
+            raise NotImplementedError("training losses are outside the MI355X inference path")
+        ids_np, cu_np, max_len = pack_padded(input_ids, attention_mask)
+        width = int(input_ids.shape[1])
+        dev = self._runtime_device
+        ids = torch.from_numpy(ids_np).to(dev)
+        cu = torch.from_numpy(cu_np).to(dev)
+        prune, rank = self.encoder.forward_packed(ids, cu, cu_np, max_len)
+        pruning_logits = unpack_to_padded(prune, cu_np, width)
+        if return_dict is not None and not return_dict:
+            return (rank, pruning_logits)
+        return OpenProvenceOutput(
+            loss=None, logits=rank, ranking_logits=rank, pruning_logits=pruning_logits, hidden_states=None, attentions=None
+        )
+
+    __call__ = forward
+
+    def _forward_is_native(self) -> bool:
+        """True unless ``forward`` was overridden / monkeypatched (the reference's tests do that, and the
+        boundary must keep accepting any Mapping-returning replacement: tests/test_modeling_open_provence.py:940-949)."""
+
+        if "forward" in self.__dict__:
+            return False
+        return type(self).forward in (
+            OpenProvenceModel.forward,
+            OpenProvenceForSequenceClassification.forward,
+        )
+
+    def _predict_rows(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
+        """Rows of token ids -> (ranking_logits[B, nl] fp32 CPU, per-row keep probabilities fp32).
+
+        Native path: one packed H2D copy, one forward, softmax over the two pruning logits on the
+        device, one D2H copy.  Overridden ``forward``: the reference's padded protocol
+        (standalone.py:2832-2924)."""
+
+        if self._forward_is_native():
+            ids_np, cu_np, max_len = pack_rows(rows)
+            dev = self._runtime_device
+            prune, rank = self.encoder.forward_packed(
+                torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev), cu_np, max_len
+            )
+            keep = torch.softmax(prune, dim=-1)[:, 1].contiguous().cpu().numpy()
+            rank_cpu = rank.cpu()
+            return rank_cpu, [keep[cu_np[i] : cu_np[i + 1]] for i in range(len(rows))]
+
+        pad_raw = getattr(self.tokenizer, "pad_token_id", None)
+        pad_id = int(pad_raw) if pad_raw is not None else 0
+        width = max((len(r) for r in rows), default=0)
+        ids = torch.full((len(rows), width), pad_id, dtype=torch.long)
+        mask = torch.zeros((len(rows), width), dtype=torch.long)
+        types = torch.zeros((len(rows), width), dtype=torch.long) if type_rows and any(type_rows) else None
+        for i, row in enumerate(rows):
+            n = len(row)
+            if n == 0:
+                continue
+            ids[i, :n] = torch.tensor(row, dtype=torch.long)
+            mask[i, :n] = 1
+            if types is not None:
+                t = list(type_rows[i] or [0] * n)[:n]
+                t = t + [t[-1] if t else 0] * (n - len(t))
+                types[i, :n] = torch.tensor(t, dtype=torch.long)
+        inputs: dict[str, torch.Tensor] = {"input_ids": ids, "attention_mask": mask}
+        if types is not None:
+            inputs["token_type_ids"] = types
+        outputs = self.forward(return_dict=True, **inputs)
+        rank_cpu = self._extract_model_output(outputs, "ranking_logits").detach().cpu().to(torch.float32)
+        prune_cpu = self._extract_model_output(outputs, "pruning_logits").detach().cpu().to(torch.float32)
+        keeps: list[np.ndarray] = []
+        for i in range(len(rows)):
+            probs = torch.softmax(prune_cpu[i], dim=-1).numpy()
+            if probs.ndim == 2 and probs.shape[1] == 2:
+                probs = probs[:, 1]
+            elif probs.ndim != 1:
+                probs = probs.reshape(-1)
+            keeps.append(probs)
+        return rank_cpu, keeps
+
+    def _sync(self) -> None:
+        dev = getattr(self, "_runtime_device", None)
+        if isinstance(dev, torch.device) and dev.type == "cuda" and torch.cuda.is_available():
+            torch.cuda.synchronize(dev)
+
+    @staticmethod
+    def _ranking_score(logits: torch.Tensor) -> float:
+        if logits.ndim == 0 or logits.numel() == 1:
+            return torch.sigmoid(logits.flatten())[0].item()
+        return torch.sigmoid(logits[..., 0]).item()
+
+    # ------------------------------------------------------------------------------------------
+    # single-block API (ref: get_raw_predictions_batch :1752-1841, predict_with_thresholds :1843-1881)
+    # ------------------------------------------------------------------------------------------
+    def _encode_texts(self, texts: list[str], truncate: bool) -> list[list[int]]:
+        encoded = self.tokenizer(
+            texts, padding=False, truncation=truncate, max_length=self.max_length if truncate else None
+        )
+        return [[int(t) for t in ids] for ids in encoded["input_ids"]]
+
+    def _context_ranges_from_contexts(self, query: str, contexts: Sequence[str]) -> list[tuple[int, int]]:
+        if not contexts:
+            return []
+        prefix = query + (self.tokenizer.sep_token or "")
+        cumulative = [prefix + "".join(contexts[: i + 1]) for i in range(len(contexts))]
+        boundaries = [len(ids) for ids in self._encode_texts(cumulative, truncate=True)]
+        prev = len(self._encode_texts([prefix], truncate=False)[0])
+        ranges = []
+        for boundary in boundaries:
+            ranges.append((prev, boundary))
+            prev = boundary
+        return ranges
+
+    def get_raw_predictions_batch(
+        self, query: str | Sequence[str], contexts_batch: Sequence[Sequence[str]], batch_size: int | None = None
+    ) -> list[RawPrediction]:
+        if not contexts_batch:
+            return []
+        sep = self.tokenizer.sep_token or ""
+        if batch_size is None or batch_size <= 0:
+            batch_size = len(contexts_batch)
+        if isinstance(query, Sequence) and not isinstance(query, str):
+            queries = [str(q) for q in query]
+            if len(queries) != len(contexts_batch):
+                raise ValueError("When providing multiple queries, their count must match contexts_batch.")
+        else:
+            queries = [str(query)] * len(contexts_batch)
+        results: list[RawPrediction] = []
+        for start in range(0, len(contexts_batch), batch_size):
+            chunk = contexts_batch[start : start + batch_size]
+            chunk_queries = queries[start : start + batch_size]
+            rows = self._encode_texts([q + sep + "".join(c) for q, c in zip(chunk_queries, chunk)], truncate=True)
+            rank, keeps = self._predict_rows(rows, None)
+            for i, ctxs in enumerate(chunk):
+                if len(ctxs) == 0:
+                    continue
+                results.append(
+                    RawPrediction(
+                        query=chunk_queries[i],
+                        contexts=list(ctxs),
+                        ranking_score=self._ranking_score(rank[i]),
+                        pruning_probs=keeps[i],
+                        context_ranges=self._context_ranges_from_contexts(chunk_queries[i], ctxs),
+                    )
+                )
+        return results
+
+    def get_raw_predictions(self, query: str, contexts: Iterable[str]) -> RawPrediction:
+        return self.get_raw_predictions_batch(query, [list(contexts)])[0]
+
+    def predict_with_thresholds(
+        self, query: str, contexts: Iterable[str], thresholds: Iterable[float], *, use_majority: bool = False
+    ) -> dict[str, Any]:
+        raw = self.get_raw_predictions(query, contexts)
+        predictions: dict[float, list[int]] = {}
+        for threshold in thresholds:
+            flags: list[int] = []
+            for start, end in raw.context_ranges:
+                segment = raw.pruning_probs[start:end]
+                if segment.size == 0:
+                    flags.append(1)
+                elif use_majority:
+                    flags.append(1 if np.count_nonzero(segment > threshold) >= (segment.size / 2) else 0)
+                else:
+                    flags.append(1 if float(segment.mean()) > threshold else 0)
+            predictions[threshold] = flags
+        return {
+            "query": raw.query,
+            "contexts": raw.contexts,
+            "ranking_score": raw.ranking_score,
+            "predictions": predictions,
+            "context_ranges": raw.context_ranges,
+            "pruning_probs": raw.pruning_probs,
+        }
+
+    # ------------------------------------------------------------------------------------------
+    # process(): host stages (thin wrappers over pipeline.py so they can be overridden / tested)
+    # ------------------------------------------------------------------------------------------
+    def _normalize_inputs(self, question, context):
+        return pl.normalize_inputs(question, context)
+
+    def _resolve_titles(self, queries, contexts, title, *, first_line_as_title: bool):
+        return pl.resolve_titles(queries, contexts, title, first_line_as_title=first_line_as_title)
+
+    def _resolve_prefix_sentences(self, title_spec, context_idx: int):
+        return pl.resolve_prefix_sentences(title_spec, context_idx)
+
+    def _resolve_sentence_splitter(self, splitter, language):
+        return resolve_sentence_splitter(splitter, language, getattr(self, "default_splitter_language", None))
+
+    def _truncate_fragment(self, fragment: FragmentRecord, max_tokens: int) -> FragmentRecord:
+        return pl.truncate_fragment(self.tokenizer, fragment, max_tokens)
+
+    def _assemble_blocks_from_fragments(self, query_token_length: int, sep_token_length: int, fragments):
+        return pl.assemble_blocks(self.tokenizer, fragments, query_token_length, sep_token_length, self.max_length)
+
+    def _prepare_block_inputs(self, query_tokens, fragments):
+        return pl.prepare_block_inputs(
+            self.tokenizer,
+            query_tokens,
+            fragments,
+            manual_specials=getattr(self, "_manual_special_tokens_required", False),
+            manual_cls=getattr(self, "_manual_cls_token_id", None),
+            manual_sep=getattr(self, "_manual_sep_token_id", None),
+        )
+
+    def _extract_first_line_titles(self, contexts):
+        return pl.extract_first_line_titles(contexts)
+
+    def _prepare_titles(self, title, queries, contexts):
+        return pl.prepare_titles(title, queries, contexts)
+
+    @staticmethod
+    def _as_state(info: Any) -> ContextState | None:
+        """Accept the reference's dict-shaped ``contexts_info`` entries as well as ContextState."""
+
+        if info is None or isinstance(info, ContextState):
+            return info
+        return ContextState(
+            sentences=list(info.get("sentences", [])),
+            fragments=list(info.get("fragments", [])),
+            blocks=list(info.get("blocks", [])),
+            prefix_length=int(info.get("prefix_length", 0)),
+            prefix_sentences=list(info.get("prefix_sentences", []) or []),
+            prefix_token_counts=list(info.get("prefix_token_counts", []) or []),
+            title_is_first_sentence=bool(info.get("title_is_first_sentence", False)),
+            original_text=info.get("original_text", ""),
+            raw_blocks=list(info.get("raw_blocks", [])),
+        )
+
+    def _postprocess_contexts(
+        self,
+        queries,
+        contexts,
+        contexts_info,
+        *,
+        threshold: float,
+        always_select_title: bool,
+        use_best_reranker_score: bool,
+        sentence_probability_groups_requested: bool,
+        collect_sentence_texts: bool,
+        first_line_as_title: bool,
+        zero_score_when_empty: bool,
+    ):
+        """Reference-shaped entry point (ref: _postprocess_contexts :2962-3202): returns the 8-tuple
+        (pruned, scores, compression, kept, removed, titles, sentence_probabilities, seconds)."""
+
+        t0 = perf_counter()
+        states = {key: self._as_state(value) for key, value in contexts_info.items()}
+        res = pl.postprocess_contexts(
+            queries,
+            contexts,
+            states,
+            threshold=threshold,
+            always_select_title=always_select_title,
+            use_best_reranker_score=use_best_reranker_score,
+            want_sentence_probabilities=sentence_probability_groups_requested,
+            want_sentence_texts=collect_sentence_texts,
+            first_line_as_title=first_line_as_title,
+            zero_score_when_empty=zero_score_when_empty,
+        )
+        return (
+            res.pruned_contexts,
+            res.reranking_scores,
+            res.compression_rates,
+            res.kept_sentences,
+            res.removed_sentences,
+            res.titles,
+            res.sentence_probabilities,
+            perf_counter() - t0,
+        )
+
+    def _apply_reordering(
+        self,
+        pruned_contexts,
+        reranking_scores,
+        compression_rates,
+        kept_sentences,
+        removed_sentences,
+        title_values,
+        sentence_probability_groups,
+        *,
+        top_k: int | None,
+    ):
+        """Reference-shaped entry point (ref: _apply_reordering :3204-3312)."""
+
+        res = pl.apply_reordering(
+            pl.PostprocessResult(
+                pruned_contexts,
+                reranking_scores,
+                compression_rates,
+                kept_sentences,
+                removed_sentences,
+                title_values,
+                sentence_probability_groups,
+            ),
+            top_k,
+        )
+        return (
+            res.pruned_contexts,
+            res.reranking_scores,
+            res.compression_rates,
+            res.kept_sentences,
+            res.removed_sentences,
+            res.titles,
+            res.sentence_probabilities,
+        )
+
+    def _estimate_device_memory_bytes(self) -> int | None:
+        override = os.getenv("OPEN_PROVENCE_DEVICE_MEMORY_GB")
+        if override:
+            try:
+                parsed = float(override)
+            except ValueError:
+                parsed = None
+            if parsed and parsed > 0:
+                return int(parsed * (1024**3))
+        try:
+            return int(torch.cuda.get_device_properties(self._runtime_device).total_memory)
+        except Exception:
+            return None
+
+    def _resolve_preprocess_workers(self, override: int | None) -> int:
+        if override is not None:
+            return max(0, int(override))
+        env_value = os.getenv("OPEN_PROVENCE_PREPROCESS_WORKERS")
+        if env_value:
+            try:
+                parsed = int(env_value)
+            except ValueError:
+                parsed = 0
+            if parsed > 0:
+                return parsed
+        return pl.default_preprocess_workers()
+
+    def _auto_tune_preprocess_loader(self, **kwargs: Any) -> tuple[int, int, int | None]:
+        return pl.auto_tune_preprocess_loader(device_memory_bytes=self._estimate_device_memory_bytes(), **kwargs)
+
+    def _build_jobs(
+        self, queries, contexts, titles, splitter: SentenceSplitter, *, strip_sentences: bool, timing: dict[str, float]
+    ) -> tuple[list[dict[str, Any]], list[list[int]]]:
+        """One job per (query, context): sentences (prefix + split or pre-split), their token lists and the
+        prefix token counts (ref: _build_preprocess_jobs :2436-2519, _precompute_sentences_and_tokens :2198)."""
+
+        jobs: list[dict[str, Any]] = []
+        query_token_ids: list[list[int]] = []
+        for q_idx, query in enumerate(queries):
+            query_token_ids.append([int(t) for t in self.tokenizer.encode(query, add_special_tokens=False)])
+            for c_idx, entry in enumerate(contexts[q_idx]):
+                if isinstance(entry, list):
+                    manual = [str(s) for s in entry if str(s).strip()]
+                    text = "".join(manual)
+                else:
+                    manual = None
+                    text = entry
+                prefix, title_is_first = self._resolve_prefix_sentences(titles[q_idx], c_idx)
+                payload = {"context_text": text, "prefix_sentences": prefix, "manual_sentences": manual}
+                t0 = perf_counter()
+                raw = pl.collect_candidate_sentences(payload, splitter)
+                t1 = perf_counter()
+                sentences = pl.normalize_sentences(raw, text, strip_sentences)
+                t2 = perf_counter()
+                token_lists = pl.tokenize_sentences(self.tokenizer, sentences)
+                t3 = perf_counter()
+                timing["sentence_collect_seconds"] += t1 - t0
+                timing["sentence_normalize_seconds"] += t2 - t1
+                timing["tokenize_seconds"] += t3 - t2
+                jobs.append(
+                    {
+                        "query_idx": q_idx,
+                        "context_idx": c_idx,
+                        "context_text": text,
+                        "prefix_sentences": prefix,
+                        "title_is_first_sentence": title_is_first,
+                        "prefix_token_counts": [len(t) for t in token_lists[: len(prefix)]],
+                        "sentences": sentences,
+                        "token_lists": token_lists,
+                    }
+                )
+        return jobs, query_token_ids
+
+    def _run_inference_batches(
+        self,
+        inference_jobs: list[dict[str, Any]],
+        batch_size: int,
+        queries: list[str],
+        query_token_ids: list[list[int]],
+        states: dict[tuple[int, int], ContextState],
+    ) -> float:
+        """Blocks -> ``[CLS] q [SEP] ctx [SEP]`` rows -> forward -> per-block raw predictions (ref :2761-2960).
+        Returns synchronised inference seconds."""
+
+        elapsed = 0.0
+        for start in range(0, len(inference_jobs), batch_size):
+            chunk = inference_jobs[start : start + batch_size]
+            if not chunk:
+                continue
+            rows: list[list[int]] = []
+            type_rows: list[list[int]] = []
+            ranges_per_job: list[list[tuple[int, int]]] = []
+            for job in chunk:
+                block = states[(job["query_idx"], job["context_idx"])].blocks[job["block_idx"]]
+                ids, _mask, type_ids, ranges = self._prepare_block_inputs(query_token_ids[job["query_idx"]], block)
+                rows.append(ids)
+                type_rows.append(type_ids)
+                ranges_per_job.append(ranges)
+            self._sync()
+            t0 = perf_counter()
+            rank, keeps = self._predict_rows(rows, type_rows)
+            self._sync()
+            elapsed += perf_counter() - t0
+            for i, job in enumerate(chunk):
+                states[(job["query_idx"], job["context_idx"])].raw_blocks.append(
+                    (
+                        job["block_idx"],
+                        RawPrediction(
+                            query=queries[job["query_idx"]],
+                            contexts=list(job["texts"]),
+                            ranking_score=self._ranking_score(rank[i]),
+                            pruning_probs=keeps[i],
+                            context_ranges=ranges_per_job[i],
+                        ),
+                    )
+                )
+        return elapsed
+
+    # ------------------------------------------------------------------------------------------
+    # process()
+    # ------------------------------------------------------------------------------------------
+    def process(
+        self,
+        question: str | Sequence[str],
+        context: str | Sequence[str] | Sequence[Sequence[str]],
+        title: None | str | Sequence[str] | Sequence[Sequence[str]] = "first_sentence",
+        first_line_as_title: bool = False,
+        *,
+        batch_size: int = 32,
+        threshold: float | None = None,
+        always_select_title: bool = False,
+        reorder: bool = False,
+        top_k: int | None = None,
+        sentence_splitter: SentenceSplitter | Mapping[str, SentenceSplitter] | None = None,
+        language: str | None = None,
+        use_best_reranker_score: bool = True,
+        zero_score_when_empty: bool = True,
+        show_progress: bool = True,
+        debug_messages: bool | Callable[[str], None] = False,
+        enable_warnings: bool = True,
+        strip_sentences: bool = False,
+        respect_sentence_boundaries: bool = False,
+        return_sentence_metrics: bool = False,
+        return_sentence_texts: bool = False,
+        show_inference_progress: bool | None = None,
+        preprocess_workers: int | None = None,
+        preprocess_batch_size: int | None = None,
+        torch_dataloader_kwargs: Mapping[str, Any] | None = None,
+    ) -> dict[str, Any]:
+        """Prune contexts sentence by sentence and score them against the question(s).
+
+        Same parameters, input-shape dispatch and result keys as the reference's ``process``
+        (standalone.py:3314-3808): ``pruned_context``, ``reranking_score``, ``compression_rate``, ``title``,
+        ``timing``, ``performance_trace`` and, on request, ``kept_sentences`` / ``removed_sentences`` /
+        ``sentence_probabilities``.  ``preprocess_workers`` / ``torch_dataloader_kwargs`` are accepted for
+        compatibility; preprocessing runs in-process (the reference's worker processes only re-copied cached
+        token ids) but the preprocess-batch heuristics that cap the forward batch are kept."""
+
+        batch_size = max(1, batch_size)
+        threshold = self._resolve_process_threshold(threshold)
+        start_total = perf_counter()
+        splitter = self._resolve_sentence_splitter(sentence_splitter, language)
+
+        if isinstance(debug_messages, bool):
+            debug_callback = LOGGER.info if debug_messages else None
+        elif callable(debug_messages):
+            debug_callback = debug_messages
+        else:
+            raise TypeError("debug_messages must be a bool or a callable that accepts a string")
+
+        timing = {
+            "sentence_collect_seconds": 0.0,
+            "sentence_normalize_seconds": 0.0,
+            "tokenize_seconds": 0.0,
+            "fragment_split_seconds": 0.0,
+            "fragment_decode_seconds": 0.0,
+        }
+        assembly_time = 0.0
+        inference_time = 0.0
+
+        with contextlib.ExitStack() as stack:
+            if not enable_warnings:
+                stack.enter_context(warnings.catch_warnings())
+                warnings.simplefilter("ignore")
+
+            queries, contexts, structure = self._normalize_inputs(question, context)
+            contexts, titles = self._resolve_titles(queries, contexts, title, first_line_as_title=first_line_as_title)
+            if respect_sentence_boundaries:
+                max_fragment_tokens = max(16, self.max_length - 2)
+            else:
+                max_fragment_tokens = max(16, self.max_length // 2)
+            sep_token_ids = self.tokenizer.encode(self.tokenizer.sep_token or "", add_special_tokens=False)
+
+            jobs, query_token_ids = self._build_jobs(
+                queries, contexts, titles, splitter, strip_sentences=strip_sentences, timing=timing
+            )
+
+            # effective preprocess batch (= cap of blocks per inference pass), as the reference computes it
+            workers = self._resolve_preprocess_workers(preprocess_workers)
+            preprocess_batch = max(1, int(preprocess_batch_size or batch_size))
+            workers_explicit = preprocess_workers is not None
+            batch_explicit = preprocess_batch_size is not None
+            prefetch_explicit = False
+            prefetch: int | None = None
+            if not workers_explicit:
+                env_workers = os.getenv("OPEN_PROVENCE_PREPROCESS_WORKERS")
+                if env_workers:
+                    try:
+                        workers_explicit = int(env_workers) > 0
+                    except ValueError:
+                        workers_explicit = False
+            if torch_dataloader_kwargs:
+                custom = dict(torch_dataloader_kwargs)
+                if "num_workers" in custom:
+                    workers_explicit = True
+                    workers = int(custom["num_workers"])
+                if "batch_size" in custom:
+                    batch_explicit = True
+                    preprocess_batch = int(custom["batch_size"])
+                if "prefetch_factor" in custom:
+                    prefetch_explicit = True
+                    raw_prefetch = custom["prefetch_factor"]
+                    if isinstance(raw_prefetch, (int, float)) or (isinstance(raw_prefetch, str) and raw_prefetch.isdigit()):
+                        prefetch = int(raw_prefetch)
+            workers, preprocess_batch, _prefetch = self._auto_tune_preprocess_loader(
+                total_jobs=len(jobs),
+                inference_batch_size=batch_size,
+                current_workers=workers,
+                current_preprocess_batch=preprocess_batch,
+                current_prefetch=prefetch,
+                workers_explicit=workers_explicit,
+                batch_explicit=batch_explicit,
+                prefetch_explicit=prefetch_explicit,
+            )
+            if debug_callback is not None:
+                debug_callback(
+                    f"[OpenProvenceModel] preprocess_workers={workers} preprocess_batch={preprocess_batch} "
+                    f"default_workers={pl.default_preprocess_workers()}"
+                )
+
+            states: dict[tuple[int, int], ContextState] = {}
+            total_blocks = 0
+            for batch_start in range(0, len(jobs), preprocess_batch):
+                batch_jobs = jobs[batch_start : batch_start + preprocess_batch]
+                inference_jobs: list[dict[str, Any]] = []
+                t_asm = perf_counter()
+                for job in batch_jobs:
+                    t0 = perf_counter()
+                    fragments = pl.fragmentize(
+                        self.tokenizer,
+                        job["token_lists"],
+                        job["context_text"],
+                        max_fragment_tokens,
+                        strip_sentences=strip_sentences,
+                        respect_sentence_boundaries=respect_sentence_boundaries,
+                    )
+                    timing["fragment_decode_seconds"] += perf_counter() - t0
+                    q_idx, c_idx = job["query_idx"], job["context_idx"]
+                    blocks = self._assemble_blocks_from_fragments(len(query_token_ids[q_idx]), len(sep_token_ids), fragments)
+                    states[(q_idx, c_idx)] = ContextState(
+                        sentences=job["sentences"],
+                        fragments=fragments,
+                        blocks=blocks,
+                        prefix_length=len(job["prefix_sentences"]),
+                        prefix_sentences=job["prefix_sentences"],
+                        prefix_token_counts=job["prefix_token_counts"],
+                        title_is_first_sentence=job["title_is_first_sentence"],
+                        original_text=job["context_text"],
+                    )
+                    for b_idx, block in enumerate(blocks):
+                        inference_jobs.append(
+                            {"query_idx": q_idx, "context_idx": c_idx, "block_idx": b_idx, "texts": [f.text for f in block]}
+                        )
+                assembly_time += perf_counter() - t_asm
+                if inference_jobs:
+                    inference_time += self._run_inference_batches(inference_jobs, batch_size, queries, query_token_ids, states)
+                    total_blocks += len(inference_jobs)
+
+            if show_progress and total_blocks and is_progress_bar_enabled():
+                message = f"[OpenProvenceModel] Model inference time: {inference_time:.2f}s ({total_blocks} blocks)"
+                if debug_callback is None:
+                    print(message, flush=True)
+                else:
+                    debug_callback(message)
+
+            (
+                pruned_l,
+                scores_l,
+                rates_l,
+                kept_l,
+                removed_l,
+                titles_l,
+                probs_l,
+                post_time,
+            ) = self._postprocess_contexts(
+                queries,
+                contexts,
+                states,
+                threshold=threshold,
+                always_select_title=always_select_title,
+                use_best_reranker_score=use_best_reranker_score,
+                sentence_probability_groups_requested=return_sentence_metrics,
+                collect_sentence_texts=return_sentence_texts,
+                first_line_as_title=first_line_as_title,
+                zero_score_when_empty=zero_score_when_empty,
+            )
+            result = pl.PostprocessResult(pruned_l, scores_l, rates_l, kept_l, removed_l, titles_l, probs_l)
+
+        preprocess_time = sum(timing.values())
+        trace = ProcessPerformanceTrace(
+            preprocess_seconds=preprocess_time,
+            assembly_seconds=assembly_time,
+            inference_seconds=inference_time,
+            postprocess_seconds=post_time,
+            total_seconds=perf_counter() - start_total,
+            **timing,
+        )
+        if debug_callback is not None:
+            debug_callback(
+                "[OpenProvenceModel] Timing: "
+                f"preprocess={trace.preprocess_seconds:.2f}s assembly={trace.assembly_seconds:.2f}s "
+                f"inference={trace.inference_seconds:.2f}s postprocess={trace.postprocess_seconds:.2f}s "
+                f"total={trace.total_seconds:.2f}s"
+            )
+
+        if reorder:
+            result = pl.PostprocessResult(
+                *self._apply_reordering(
+                    result.pruned_contexts,
+                    result.reranking_scores,
+                    result.compression_rates,
+                    result.kept_sentences,
+                    result.removed_sentences,
+                    result.titles,
+                    result.sentence_probabilities,
+                    top_k=top_k,
+                )
+            )
+
+        pruned: Any = result.pruned_contexts
+        scores: Any = result.reranking_scores
+        rates: Any = result.compression_rates
+        kept: Any = result.kept_sentences
+        removed: Any = result.removed_sentences
+        title_out: Any = result.titles
+        probs: Any = result.sentence_probabilities
+
+        if structure == "str" and result.pruned_contexts:
+            pruned = result.pruned_contexts[0][0] if result.pruned_contexts[0] else ""
+            scores = result.reranking_scores[0][0] if result.reranking_scores[0] else None
+            rates = result.compression_rates[0][0] if result.compression_rates[0] else 0.0
+            if kept is not None:
+                kept = result.kept_sentences[0][0] if result.kept_sentences[0] else []
+            if removed is not None:
+                removed = result.removed_sentences[0][0] if result.removed_sentences[0] else []
+            title_out = result.titles[0][0] if result.titles[0] else None
+            if probs is not None and probs and probs[0]:
+                probs = probs[0][0]
+        elif structure == "list" and result.pruned_contexts:
+            pruned, scores, rates = result.pruned_contexts[0], result.reranking_scores[0], result.compression_rates[0]
+            if kept is not None:
+                kept = result.kept_sentences[0]
+            if removed is not None:
+                removed = result.removed_sentences[0]
+            title_out = result.titles[0]
+            if probs is not None:
+                probs = probs[0] if probs else []
+        elif structure == "aligned" and result.pruned_contexts:
+            pruned = [e[0] if e else "" for e in result.pruned_contexts]
+            scores = [s[0] if s else None for s in result.reranking_scores]
+            rates = [r[0] if r else 0.0 for r in result.compression_rates]
+            if kept is not None:
+                kept = [v[0] if v else [] for v in result.kept_sentences]
+            if removed is not None:
+                removed = [v[0] if v else [] for v in result.removed_sentences]
+            title_out = [v[0] if v else None for v in result.titles]
+            if probs is not None:
+                probs = [v[0] if v else [] for v in probs]
+
+        payload: dict[str, Any] = {
+            "pruned_context": pruned,
+            "reranking_score": scores,
+            "compression_rate": rates,
+            "title": title_out,
+            "timing": trace.as_dict(),
+            "performance_trace": trace,
+        }
+        if kept is not None:
+            payload["kept_sentences"] = kept
+        if removed is not None:
+            payload["removed_sentences"] = removed
+        if probs is not None:
+            payload["sentence_probabilities"] = probs
+        return payload
+
+
+class OpenProvenceForSequenceClassification(OpenProvenceModel):
+    """AutoModel-style alias: ``.logits`` are the ranking logits (ref: standalone.py:3814-3831)."""
+
+
+class OpenProvenceForTokenClassification(OpenProvenceModel):
+    """``.logits`` are the per-token pruning logits; ``ranking_logits`` rides along (ref: standalone.py:3834-3901)."""
+
+    def __init__(self, config: OpenProvenceConfig, **kwargs: Any) -> None:
+        super().__init__(config, **kwargs)
+        self.num_labels = config.num_pruning_labels
+
+    def forward(self, input_ids=None, attention_mask=None, labels=None, return_dict=None, **kwargs: Any):
+        base = OpenProvenceModel.forward(self, input_ids=input_ids, attention_mask=attention_mask, labels=labels, return_dict=True)
+        if return_dict is not None and not return_dict:
+            return (base["pruning_logits"],)
+        return OpenProvenceOutput(
+            loss=None,
+            logits=base["pruning_logits"],
+            pruning_logits=base["pruning_logits"],
+            ranking_logits=base["ranking_logits"],
+            hidden_states=None,
+            attentions=None,
+        )
+
+    __call__ = forward
+
+
+# module-level helpers under the reference's names (its tests import these: tests/test_modeling_open_provence.py:11-29)
+_FragmentRecord = FragmentRecord
+_split_token_lists = pl.split_token_lists
+_collect_candidate_sentences = pl.collect_candidate_sentences
+_normalize_sentences = pl.normalize_sentences
+
+
+def _tokenize_sentences_with_context(tokenizer, sentences, prefix_count, context_text, *, strip_sentences):
+    return pl.tokenize_sentences(tokenizer, sentences)
+
+
+def _fragmentize_example(
+    example: dict[str, Any],
+    tokenizer: Any,
+    max_fragment_tokens: int,
+    splitter: SentenceSplitter,
+    strip_sentences: bool,
+    *,
+    respect_sentence_boundaries: bool = False,
+) -> dict[str, Any]:
+    """Sentences + fragments of one context, in the reference's dict shape (ref: _fragmentize_example :1146-1243)."""
+
+    context_text = str(example.get("context_text", ""))
+    if example.get("cached_sentences") is not None:
+        sentences = [str(s) for s in example["cached_sentences"]]
+    else:
+        sentences = pl.normalize_sentences(pl.collect_candidate_sentences(example, splitter), context_text, strip_sentences)
+    if example.get("cached_token_lists") is not None:
+        token_lists = [[int(t) for t in ids] for ids in example["cached_token_lists"]]
+    else:
+        token_lists = pl.tokenize_sentences(tokenizer, sentences)
+    if not pl.split_token_lists(token_lists, max_fragment_tokens, keep_sentence_boundaries=respect_sentence_boundaries):
+        sentences = [pl.fallback_sentence(context_text, strip_sentences)]
+    records = pl.fragmentize(
+        tokenizer,
+        token_lists,
+        context_text,
+        max_fragment_tokens,
+        strip_sentences=strip_sentences,
+        respect_sentence_boundaries=respect_sentence_boundaries,
+    )
+    return {
+        "sentences": sentences,
+        "fragment_texts": [r.text for r in records],
+        "fragment_sentence_index": [r.sentence_index for r in records],
+        "fragment_fragment_index": [r.fragment_index for r in records],
+        "fragment_global_index": [r.global_index for r in records],
+        "fragment_token_ids": [list(r.token_ids) for r in records],
+    }
+
+
+OpenProvenceEncoderConfig = OpenProvenceConfig
+OpenProvenceEncoderForSequenceClassification = OpenProvenceForSequenceClassification
+OpenProvenceEncoderForTokenClassification = OpenProvenceForTokenClassification
+
+__all__ = [
+    "OpenProvenceModel",
+    "OpenProvenceRawPrediction",
+    "OpenProvenceConfig",
+    "OpenProvenceForSequenceClassification",
+    "OpenProvenceForTokenClassification",
+]

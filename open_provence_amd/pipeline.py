@@ -1,0 +1,732 @@
+"""Host pipeline of ``process()``: everything either side of the forward that is integer/string work.
+
+Restates the behaviour of the reference's host code (``open_provence/modeling_open_provence_standalone.py``;
+"ref:" citations below give the lines whose behaviour each function reproduces) as free functions over
+plain Python data so that they can be unit-tested against the reference's own known-answer tests and
+the G3 golden fixtures without a GPU.  No arithmetic of the encoder lives here.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+from collections import defaultdict
+from dataclasses import dataclass, field
+from typing import Any, Callable, Mapping, Sequence
+
+import numpy as np
+
+SentenceSplitter = Callable[[str], list[str]]
+
+DEFAULT_ENGLISH_SENTENCE_MAX_CHARS = 1200  # ref: standalone.py:100
+
+
+# ---------------------------------------------------------------------------------------------
+# data carried between stages
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class FragmentRecord:
+    """A run of tokens of one sentence that travels as a unit (ref: _FragmentRecord :990-999)."""
+
+    text: str
+    sentence_index: int
+    fragment_index: int
+    global_index: int
+    token_length: int
+    token_ids: list[int]
+
+
+@dataclass
+class RawPrediction:
+    """Per-block model output (ref: OpenProvenceRawPrediction :451-459)."""
+
+    query: str
+    contexts: list[str]
+    ranking_score: float | None
+    pruning_probs: np.ndarray
+    context_ranges: list[tuple[int, int]]
+
+
+@dataclass
+class ContextState:
+    """Everything known about one (query, context) pair while it moves through the pipeline."""
+
+    sentences: list[str]
+    fragments: list[FragmentRecord]
+    blocks: list[list[FragmentRecord]]
+    prefix_length: int
+    prefix_sentences: list[str]
+    prefix_token_counts: list[int]
+    title_is_first_sentence: bool
+    original_text: str
+    raw_blocks: list[tuple[int, RawPrediction]] = field(default_factory=list)
+
+
+# ---------------------------------------------------------------------------------------------
+# input normalisation (ref: _normalize_inputs :2261-2323)
+# ---------------------------------------------------------------------------------------------
+def _is_sequence(value: Any) -> bool:
+    return isinstance(value, Sequence) and not isinstance(value, (str, bytes, bytearray))
+
+
+def _normalize_collection(values: Sequence[Any]) -> list[Any]:
+    return [[str(e) for e in item] if _is_sequence(item) else str(item) for item in values]
+
+
+def normalize_inputs(question: str | Sequence[str], context: Any) -> tuple[list[str], list[list[Any]], str]:
+    """Return (queries, contexts[q][d], structure) with structure in {str, list, aligned, nested}."""
+
+    queries = [question] if isinstance(question, str) else [str(q) for q in question]
+
+    if isinstance(context, str):
+        structure = "str"
+        contexts: list[list[Any]] = [[context]]
+    elif not _is_sequence(context):
+        raise ValueError("Unsupported context format")
+    elif len(queries) == 1:
+        structure = "list"
+        contexts = [_normalize_collection(context)]
+    else:
+        entries = list(context)
+        if all(not _is_sequence(entry) for entry in entries):
+            if len(entries) != len(queries):
+                raise ValueError("Number of contexts must match number of queries")
+            structure = "aligned"
+            contexts = [[str(entry)] for entry in entries]
+        else:
+            structure = "nested"
+            contexts = []
+            for entry in entries:
+                if not _is_sequence(entry):
+                    raise ValueError("Number of context lists must match number of queries")
+                contexts.append(_normalize_collection(entry))
+
+    if structure == "list" and len(queries) != 1:
+        raise ValueError("Single list of contexts requires a single query")
+    if structure == "nested" and len(contexts) != len(queries):
+        raise ValueError("Number of context lists must match number of queries")
+    if structure == "str" and len(queries) != 1:
+        raise ValueError("Single context string requires a single query")
+    if structure in {"str", "list"}:
+        contexts = [contexts[0]]
+    return queries, contexts, structure
+
+
+# ---------------------------------------------------------------------------------------------
+# titles (ref: _prepare_titles :2325-2360, _extract_first_line_titles :2362-2410,
+#         _resolve_titles :2412-2434, _resolve_prefix_sentences :1971-2005)
+# ---------------------------------------------------------------------------------------------
+def prepare_titles(title: Any, queries: list[str], contexts: list[list[Any]]) -> list[Any]:
+    n_queries = len(queries)
+    if title is None:
+        return [None] * n_queries
+    if isinstance(title, str):
+        if title == "first_sentence":
+            return ["first_sentence"] * n_queries
+        return [[title for _ in ctxs] for ctxs in contexts]
+    if isinstance(title, Sequence):
+        normalized: list[Any] = []
+        for entry in title:
+            if isinstance(entry, Sequence) and not isinstance(entry, str):
+                normalized.append([str(v) for v in entry])
+            else:
+                normalized.append(str(entry))
+        if n_queries == 1 and all(isinstance(item, str) for item in normalized):
+            return [[str(item) for item in normalized]]
+        if len(normalized) == n_queries and all(isinstance(item, list) for item in normalized):
+            return [list(map(str, item)) for item in normalized]
+        if len(normalized) == n_queries and all(isinstance(item, str) for item in normalized):
+            return [[value for _ in contexts[idx]] for idx, value in enumerate(normalized)]
+    raise ValueError("Unsupported title format")
+
+
+def extract_first_line_titles(contexts: list[list[Any]]) -> tuple[list[list[Any]], list[list[str]]]:
+    """Peel the first non-blank line (or pre-split sentence) off every context as its title."""
+
+    new_contexts: list[list[Any]] = []
+    titles: list[list[str]] = []
+    for group in contexts:
+        group_titles: list[str] = []
+        new_group: list[Any] = []
+        for entry in group:
+            if isinstance(entry, list):
+                pieces = [str(v) for v in entry]
+                keep_from = next((i for i, seg in enumerate(pieces) if seg.strip()), None)
+                if keep_from is None:
+                    group_titles.append("")
+                    new_group.append(pieces)
+                else:
+                    group_titles.append(pieces[keep_from].rstrip("\r\n"))
+                    new_group.append(pieces[keep_from + 1 :])
+            else:
+                text = str(entry)
+                candidate, remainder = "", ""
+                if text:
+                    lines = text.splitlines(keepends=True)
+                    keep_from = next((i for i, line in enumerate(lines) if line.strip()), None)
+                    if keep_from is None:
+                        remainder = "".join(lines)
+                    else:
+                        candidate = lines[keep_from].rstrip("\r\n")
+                        remainder = "".join(lines[keep_from + 1 :])
+                group_titles.append(candidate)
+                new_group.append(remainder)
+        titles.append(group_titles)
+        new_contexts.append(new_group)
+    return new_contexts, titles
+
+
+def resolve_titles(
+    queries: list[str], contexts: list[list[Any]], title: Any, *, first_line_as_title: bool
+) -> tuple[list[list[Any]], list[Any]]:
+    if first_line_as_title:
+        if title not in (None, "first_sentence"):
+            raise ValueError("first_line_as_title=True cannot be combined with an explicit title override.")
+        contexts, payload = extract_first_line_titles(contexts)
+    else:
+        payload = title
+    return contexts, prepare_titles(payload, queries, contexts)
+
+
+def resolve_prefix_sentences(title_spec: Any, context_idx: int) -> tuple[list[str], bool]:
+    """(prefix sentences, title_is_first_sentence).  Explicit titles become prefix sentences whose last
+    element ends with exactly one newline; the legacy "first_sentence" marker adds no tokens."""
+
+    prefix: list[str] = []
+    first_sentence_is_title = False
+    if title_spec == "first_sentence":
+        first_sentence_is_title = True
+    elif isinstance(title_spec, list):
+        raw = title_spec[context_idx] if context_idx < len(title_spec) else None
+        if title_spec and isinstance(title_spec[0], list):
+            if raw:
+                prefix.extend(t.strip() for t in raw if isinstance(t, str) and t.strip())
+        elif isinstance(raw, str) and raw.strip():
+            prefix.append(raw.strip())
+    elif isinstance(title_spec, str) and title_spec.strip():
+        prefix.append(title_spec.strip())
+    if prefix:
+        prefix[-1] = prefix[-1].rstrip("\n") + "\n"
+    return prefix, first_sentence_is_title
+
+
+# ---------------------------------------------------------------------------------------------
+# sentences (ref: _collect_candidate_sentences :615-630, _normalize_sentences :640-661,
+#            _split_multiline_sentence :582-612, _fallback_sentence :633-637)
+# ---------------------------------------------------------------------------------------------
+def fallback_sentence(context_text: str, strip_sentences: bool) -> str:
+    if not strip_sentences:
+        return context_text
+    return context_text.strip() or context_text
+
+
+def split_multiline_sentence(text: str, strip_sentences: bool) -> list[str]:
+    whole = [text.strip() if strip_sentences else text]
+    if "\n" not in text:
+        return whole
+    segments = text.splitlines(keepends=not strip_sentences)
+    meaningful = [seg for seg in segments if seg.strip()]
+    if len(meaningful) <= 1:
+        return whole
+    if sum(1 for ch in text if ch in ".?!") >= len(meaningful):
+        return whole  # already punctuated line by line
+    if any(len(seg.strip()) > DEFAULT_ENGLISH_SENTENCE_MAX_CHARS for seg in meaningful):
+        return whole
+    pieces = [seg.strip() for seg in meaningful] if strip_sentences else list(meaningful)
+    pieces = [p for p in pieces if p]
+    return pieces or whole
+
+
+def collect_candidate_sentences(example: Mapping[str, Any], splitter: SentenceSplitter) -> list[str]:
+    sentences = [str(s) for s in (example.get("prefix_sentences") or []) if s is not None]
+    manual = example.get("manual_sentences")
+    if manual is not None:
+        sentences.extend(str(s) for s in manual if s is not None)
+    else:
+        sentences.extend(str(s) for s in splitter(str(example.get("context_text", ""))) if s is not None)
+    return sentences
+
+
+def normalize_sentences(raw_sentences: Sequence[str], context_text: str, strip_sentences: bool) -> list[str]:
+    out: list[str] = []
+    for entry in raw_sentences:
+        text = str(entry)
+        if not text:
+            continue
+        out.extend(seg for seg in split_multiline_sentence(text, strip_sentences) if seg)
+    return out or [fallback_sentence(context_text, strip_sentences)]
+
+
+def tokenize_sentences(tokenizer: Any, sentences: Sequence[str]) -> list[list[int]]:
+    if not sentences:
+        return []
+    encoded = tokenizer(list(sentences), add_special_tokens=False, return_attention_mask=False)
+    if not isinstance(encoded, Mapping):
+        try:
+            encoded = dict(encoded)
+        except Exception:
+            return []
+    return [[int(t) for t in ids] for ids in encoded.get("input_ids", [])]
+
+
+# ---------------------------------------------------------------------------------------------
+# fragments and blocks (ref: _split_token_lists :686-713, _decode_and_filter_fragments :846-894,
+#   _build_fragment_payload :795-843, _truncate_fragment :2082-2102,
+#   _assemble_blocks_from_fragments :2222-2259)
+# ---------------------------------------------------------------------------------------------
+def split_token_lists(
+    token_lists: Sequence[Sequence[int]], max_fragment_tokens: int, *, keep_sentence_boundaries: bool = False
+) -> list[tuple[list[int], int, int, int]]:
+    """(tokens, sentence_index, fragment_index, global_index) in reading order; empty sentences vanish."""
+
+    step = max(1, int(max_fragment_tokens))
+    out: list[tuple[list[int], int, int, int]] = []
+    for sentence_index, ids in enumerate(token_lists):
+        tokens = list(ids)
+        if not tokens:
+            continue
+        if keep_sentence_boundaries and len(tokens) <= max_fragment_tokens:
+            out.append((tokens, sentence_index, 0, len(out)))
+            continue
+        for fragment_index, start in enumerate(range(0, len(tokens), step)):
+            out.append((tokens[start : start + step], sentence_index, fragment_index, len(out)))
+    return out
+
+
+def fragmentize(
+    tokenizer: Any,
+    token_lists: Sequence[Sequence[int]],
+    context_text: str,
+    max_fragment_tokens: int,
+    *,
+    strip_sentences: bool,
+    respect_sentence_boundaries: bool,
+) -> list[FragmentRecord]:
+    """Token lists -> fragment records with decoded text; fragments whose text decodes to nothing are
+    dropped, and if that empties the context the first fragment is resurrected."""
+
+    pieces = split_token_lists(
+        [[int(t) for t in ids] for ids in token_lists],
+        max_fragment_tokens,
+        keep_sentence_boundaries=respect_sentence_boundaries,
+    )
+    if not pieces:
+        fallback = tokenizer.encode(fallback_sentence(context_text, strip_sentences), add_special_tokens=False)
+        pieces = [(list(fallback), 0, 0, 0)]
+
+    texts = tokenizer.batch_decode(
+        [tokens for tokens, _, _, _ in pieces], skip_special_tokens=True, clean_up_tokenization_spaces=False
+    )
+    records: list[FragmentRecord] = []
+    for text, (tokens, s_idx, f_idx, g_idx) in zip(texts, pieces):
+        shown = text.strip() if strip_sentences else text
+        if not (shown if strip_sentences else text):
+            continue
+        records.append(FragmentRecord(shown, s_idx, f_idx, g_idx, len(tokens), list(tokens)))
+    if not records:
+        tokens, s_idx, f_idx, g_idx = pieces[0]
+        text = tokenizer.decode(tokens, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+        records.append(
+            FragmentRecord(text.strip() if strip_sentences else text, s_idx, f_idx, g_idx, len(tokens), list(tokens))
+        )
+    return records
+
+
+def truncate_fragment(tokenizer: Any, fragment: FragmentRecord, max_tokens: int) -> FragmentRecord:
+    max_tokens = max(1, max_tokens)
+    if fragment.token_length <= max_tokens:
+        return fragment
+    kept = list(fragment.token_ids[:max_tokens])
+    text = tokenizer.decode(kept, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+    return FragmentRecord(text, fragment.sentence_index, fragment.fragment_index, fragment.global_index, len(kept), kept)
+
+
+def assemble_blocks(
+    tokenizer: Any, fragments: list[FragmentRecord], query_len: int, sep_len: int, max_length: int
+) -> list[list[FragmentRecord]]:
+    """Greedy, order-preserving packing: len(query)+len(sep)+sum(fragments) <= max_length-2 per block; a
+    fragment that cannot fit even alone opens a new block and is truncated to the remaining room."""
+
+    if not fragments:
+        return []
+    budget = max_length - 2
+    base = query_len + sep_len
+    solo_capacity = max(1, budget - base)
+    blocks: list[list[FragmentRecord]] = []
+    current: list[FragmentRecord] = []
+    used = base
+    for fragment in fragments:
+        if used + fragment.token_length <= budget:
+            current.append(fragment)
+            used += fragment.token_length
+            continue
+        if current:
+            blocks.append(current)
+        clipped = truncate_fragment(tokenizer, fragment, solo_capacity)
+        current = [clipped]
+        used = base + clipped.token_length
+    if current:
+        blocks.append(current)
+    return blocks
+
+
+# ---------------------------------------------------------------------------------------------
+# block -> model input (ref: _prepare_block_inputs :2104-2196, _requires_manual_special_tokens :1501-1538)
+# ---------------------------------------------------------------------------------------------
+def _first_int(*candidates: Any) -> int | None:
+    for c in candidates:
+        if isinstance(c, int):
+            return c
+    return None
+
+
+def special_token_candidates(tokenizer: Any) -> tuple[list[int], list[int]]:
+    special_map = getattr(tokenizer, "special_tokens_map", {}) or {}
+    cls_c = [
+        getattr(tokenizer, "cls_token_id", None),
+        special_map.get("cls_token_id"),
+        getattr(tokenizer, "bos_token_id", None),
+        special_map.get("bos_token_id"),
+    ]
+    sep_c = [
+        getattr(tokenizer, "sep_token_id", None),
+        special_map.get("sep_token_id"),
+        getattr(tokenizer, "eos_token_id", None),
+        special_map.get("eos_token_id"),
+    ]
+    return [v for v in cls_c if isinstance(v, int)], [v for v in sep_c if isinstance(v, int)]
+
+
+def requires_manual_special_tokens(tokenizer: Any) -> bool:
+    """True for tokenizers (gte-ModernBERT) whose build_inputs_with_special_tokens drops CLS/SEP."""
+
+    try:
+        q = tokenizer.encode("open provence query", add_special_tokens=False)
+        c = tokenizer.encode("open provence document", add_special_tokens=False)
+    except Exception:
+        return False
+    if not q or not c:
+        return False
+    built = [int(t) for t in tokenizer.build_inputs_with_special_tokens(q, c)]
+    cls_c, sep_c = special_token_candidates(tokenizer)
+    missing_cls = bool(cls_c) and not any(t in cls_c for t in built)
+    missing_sep = bool(sep_c) and not any(t in sep_c for t in built)
+    return missing_cls or missing_sep
+
+
+def _find_subsequence(haystack: Sequence[int], needle: Sequence[int]) -> int:
+    n = len(needle)
+    if n == 0:
+        return -1
+    needle = list(needle)
+    first = needle[0]
+    for idx in range(0, len(haystack) - n + 1):
+        if haystack[idx] == first and list(haystack[idx : idx + n]) == needle:
+            return idx
+    return -1
+
+
+def prepare_block_inputs(
+    tokenizer: Any,
+    query_tokens: Sequence[int],
+    fragments: Sequence[FragmentRecord],
+    *,
+    manual_specials: bool = False,
+    manual_cls: int | None = None,
+    manual_sep: int | None = None,
+) -> tuple[list[int], list[int], list[int], list[tuple[int, int]]]:
+    """(input_ids, attention_mask, token_type_ids, token range of every fragment inside input_ids)."""
+
+    query = [int(t) for t in query_tokens]
+    ctx: list[int] = []
+    for frag in fragments:
+        ctx.extend(int(t) for t in frag.token_ids)
+    built = [int(t) for t in tokenizer.build_inputs_with_special_tokens(query, ctx)]
+
+    if manual_specials:
+        ids: list[int] = []
+        if manual_cls is not None:
+            ids.append(manual_cls)
+        ids.extend(query)
+        if manual_sep is not None:
+            ids.append(manual_sep)
+        ids.extend(ctx)
+        if manual_sep is not None and ctx:
+            ids.append(manual_sep)
+    else:
+        ids = built if built else query + ctx
+
+    try:
+        type_ids = tokenizer.create_token_type_ids_from_sequences(query, ctx)
+        type_ids = [int(t) for t in type_ids] if type_ids is not None else None
+    except Exception:
+        type_ids = None
+
+    ranges: list[tuple[int, int]] = []
+    if ctx:
+        start = _find_subsequence(ids, ctx)
+        if start < 0:
+            start = len(tokenizer.build_inputs_with_special_tokens(query, []))
+        cursor = start
+        for frag in fragments:
+            ranges.append((cursor, cursor + len(frag.token_ids)))
+            cursor += len(frag.token_ids)
+
+    if type_ids is not None and len(type_ids) < len(ids):
+        pad = type_ids[-1] if type_ids else 0
+        type_ids = type_ids + [pad] * (len(ids) - len(type_ids))
+    if type_ids is None:
+        ctx_start = ranges[0][0] if ctx else len(ids)
+        type_ids = [0] * ctx_start + [1] * (len(ids) - ctx_start)
+    return ids, [1] * len(ids), type_ids, ranges
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocess-batch heuristics (ref: _default_preprocess_workers :82-96,
+#   _auto_tune_preprocess_loader :2567-2623).  The reference runs one inference pass per DataLoader
+#   batch, so these numbers cap the effective forward batch.
+# ---------------------------------------------------------------------------------------------
+def default_preprocess_workers() -> int:
+    try:
+        import psutil
+
+        total = psutil.cpu_count(logical=False) or psutil.cpu_count(logical=True)
+    except Exception:
+        total = os.cpu_count()
+    return 0 if total is None else max(0, int(total) - 1)
+
+
+def auto_tune_preprocess_loader(
+    *,
+    total_jobs: int,
+    inference_batch_size: int,
+    current_workers: int,
+    current_preprocess_batch: int,
+    current_prefetch: int | None,
+    workers_explicit: bool,
+    batch_explicit: bool,
+    prefetch_explicit: bool,
+    device_memory_bytes: int | None,
+) -> tuple[int, int, int | None]:
+    jobs = max(0, int(total_jobs))
+    workers = max(0, int(current_workers))
+    batch = max(1, int(current_preprocess_batch))
+    prefetch = current_prefetch if prefetch_explicit else None
+
+    if not workers_explicit:
+        cpu_limit = max(0, default_preprocess_workers())
+        workers = min(workers or cpu_limit, cpu_limit)
+        if jobs < 2_000:
+            workers = 0
+        elif workers == 0 and cpu_limit > 0:
+            workers = min(cpu_limit, 4)
+        if jobs:
+            workers = min(workers, jobs)
+
+    if not batch_explicit:
+        cap: int | None = None
+        if device_memory_bytes:
+            gib = device_memory_bytes / float(1024**3)
+            cap = 64 if gib < 12 else (128 if gib < 20 else 192)
+        target = cap or min(96, max(32, inference_batch_size))
+        batch = min(batch, target, max(1, inference_batch_size))
+        if jobs:
+            batch = min(batch, jobs)
+
+    workers = max(workers, 0)
+    if workers == 0 and not prefetch_explicit:
+        prefetch = None
+    elif workers > 0 and not prefetch_explicit:
+        prefetch = max(2, min(8, math.ceil(batch / workers)))
+    return workers, batch, prefetch
+
+
+# ---------------------------------------------------------------------------------------------
+# post-processing (ref: _postprocess_contexts :2962-3202)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PostprocessResult:
+    pruned_contexts: list[list[str]]
+    reranking_scores: list[list[float | None]]
+    compression_rates: list[list[float]]
+    kept_sentences: list[list[list[str]]] | None
+    removed_sentences: list[list[list[str]]] | None
+    titles: list[list[Any]]
+    sentence_probabilities: list[list[list[float]]] | None
+
+
+def score_fragments(state: ContextState, use_best_reranker_score: bool) -> tuple[dict[int, list[float]], float | None]:
+    """Mean keep-probability of every fragment in every block, and the context's rerank score.
+
+    The fragment's token range is shifted LEFT by the token count of the prefix (title) sentences that
+    precede its sentence index -- the reference's behaviour (ref :3075-3082)."""
+
+    per_fragment: dict[int, list[float]] = defaultdict(list)
+    ranking: float | None = None
+    ordered = sorted(state.raw_blocks, key=lambda item: item[0])
+    for (_, raw), block in zip(ordered, state.blocks):
+        probs = raw.pruning_probs
+        n = len(probs)
+        for fragment, (start, end) in zip(block, raw.context_ranges):
+            offset = sum(state.prefix_token_counts[: fragment.sentence_index])
+            start = max(0, start - offset)
+            end = max(start, end - offset)
+            end = min(end, n)
+            start = min(start, n)
+            per_fragment[fragment.global_index].append(1.0 if end <= start else float(probs[start:end].mean()))
+        if raw.ranking_score is not None:
+            if ranking is None:
+                ranking = raw.ranking_score
+            elif use_best_reranker_score:
+                ranking = max(ranking, raw.ranking_score)
+    return per_fragment, ranking
+
+
+def postprocess_contexts(
+    queries: list[str],
+    contexts: list[list[Any]],
+    states: Mapping[tuple[int, int], ContextState],
+    *,
+    threshold: float,
+    always_select_title: bool,
+    use_best_reranker_score: bool,
+    want_sentence_probabilities: bool,
+    want_sentence_texts: bool,
+    first_line_as_title: bool,
+    zero_score_when_empty: bool,
+) -> PostprocessResult:
+    out = PostprocessResult([], [], [], [] if want_sentence_texts else None, [] if want_sentence_texts else None, [],
+                            [] if want_sentence_probabilities else None)
+    for q_idx in range(len(queries)):
+        q_pruned: list[str] = []
+        q_scores: list[float | None] = []
+        q_comp: list[float] = []
+        q_kept: list[list[str]] = []
+        q_removed: list[list[str]] = []
+        q_titles: list[Any] = []
+        q_probs: list[list[float]] = []
+        for c_idx, entry in enumerate(contexts[q_idx]):
+            state = states.get((q_idx, c_idx))
+            prefix = tuple(str(p) for p in state.prefix_sentences) if state else ()
+            fallback_title: Any = None
+            if first_line_as_title and prefix:
+                fallback_title = prefix[0] if len(prefix) == 1 else list(prefix)
+
+            if state is None or not state.fragments:
+                q_pruned.append(entry)
+                q_scores.append(None)
+                q_comp.append(0.0)
+                q_kept.append([entry] if entry else [])
+                q_removed.append([])
+                q_titles.append(fallback_title)
+                q_probs.append([])
+                continue
+            if not state.blocks or not state.raw_blocks:
+                q_pruned.append(entry)
+                q_scores.append(None)
+                q_comp.append(0.0)
+                q_kept.append(state.sentences)
+                q_removed.append([])
+                q_titles.append(fallback_title)
+                q_probs.append([1.0] * len(state.sentences))
+                continue
+
+            per_fragment, ranking = score_fragments(state, use_best_reranker_score)
+            per_sentence: dict[int, list[float]] = defaultdict(list)
+            for fragment in state.fragments:
+                if fragment.global_index in per_fragment:
+                    per_sentence[fragment.sentence_index].extend(per_fragment[fragment.global_index])
+
+            sentences = state.sentences
+            n_prefix = state.prefix_length
+            title_index: int | None = None
+            if always_select_title:
+                if n_prefix > 0:
+                    title_index = 0
+                elif state.title_is_first_sentence and len(sentences) > n_prefix:
+                    title_index = n_prefix
+
+            averages: list[float] = []
+            for s_idx in range(len(sentences)):
+                values = per_sentence.get(s_idx)
+                avg = float(np.mean(values)) if values else 0.0
+                averages.append(max(0.0, min(avg, 1.0)))
+            any_above = any(a > threshold for a in averages)
+            keep = [a > threshold for a in averages]
+            if title_index is not None and any_above:
+                keep[title_index] = True
+
+            kept = [s for s, k in zip(sentences, keep) if k]
+            removed = [s for s, k in zip(sentences, keep) if not k]
+            pruned_text = "".join(s for i, (s, k) in enumerate(zip(sentences, keep)) if k and i >= n_prefix)
+            original = state.original_text
+            compression = (len(original) - len(pruned_text)) / max(len(original), 1) * 100.0
+            if zero_score_when_empty and not pruned_text.strip():
+                ranking = 0.0
+
+            if state.prefix_sentences:
+                title_value: Any = (
+                    state.prefix_sentences[0] if len(state.prefix_sentences) == 1 else list(state.prefix_sentences)
+                )
+            else:
+                title_value = None
+
+            q_pruned.append(pruned_text)
+            q_scores.append(ranking)
+            q_comp.append(compression)
+            q_kept.append(kept)
+            q_removed.append(removed)
+            q_titles.append(title_value)
+            q_probs.append(averages)
+
+        out.pruned_contexts.append(q_pruned)
+        out.reranking_scores.append(q_scores)
+        out.compression_rates.append(q_comp)
+        if out.kept_sentences is not None:
+            out.kept_sentences.append(q_kept)
+        if out.removed_sentences is not None:
+            out.removed_sentences.append(q_removed)
+        out.titles.append(q_titles)
+        if out.sentence_probabilities is not None:
+            out.sentence_probabilities.append(q_probs)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# reordering (ref: _apply_reordering :3204-3312)
+# ---------------------------------------------------------------------------------------------
+def apply_reordering(result: PostprocessResult, top_k: int | None) -> PostprocessResult:
+    """Per query: stable sort by score descending (None = -inf), then keep the first top_k."""
+
+    if not result.pruned_contexts:
+        return result
+    limit = None if top_k is None else max(0, int(top_k))
+
+    def pick(rows: list[Any] | None, order: list[int]) -> list[Any] | None:
+        return None if rows is None else [rows[i] for i in order]
+
+    new = PostprocessResult([], [], [], [] if result.kept_sentences is not None else None,
+                            [] if result.removed_sentences is not None else None, [],
+                            [] if result.sentence_probabilities is not None else None)
+    for q_idx, scores in enumerate(result.reranking_scores):
+        if scores:
+            order = sorted(
+                range(len(scores)),
+                key=lambda i: float("-inf") if scores[i] is None else float(scores[i]),
+                reverse=True,
+            )
+            if limit is not None:
+                order = order[:limit]
+        else:
+            order = list(range(len(result.pruned_contexts[q_idx])))
+        new.pruned_contexts.append(pick(result.pruned_contexts[q_idx], order))
+        new.reranking_scores.append(pick(scores, order) if scores else scores)
+        new.compression_rates.append(pick(result.compression_rates[q_idx], order))
+        if new.kept_sentences is not None:
+            new.kept_sentences.append(pick(result.kept_sentences[q_idx], order))
+        if new.removed_sentences is not None:
+            new.removed_sentences.append(pick(result.removed_sentences[q_idx], order))
+        new.titles.append(pick(result.titles[q_idx], order))
+        if new.sentence_probabilities is not None:
+            new.sentence_probabilities.append(pick(result.sentence_probabilities[q_idx], order))
+    return new

@@ -145,3 +145,65 @@ def rows_from_fixture(arrays: dict[str, np.ndarray]) -> list[list[int]]:
     ids = arrays["input_ids"]
     mask = arrays["attention_mask"]
     return [ids[i, : int(mask[i].sum())].tolist() for i in range(ids.shape[0])]
+
+
+def host_only_model(tokenizer=None, max_length: int = 96, forward=None, cls=None):
+    """An ``OpenProvenceModel`` built WITHOUT touching a GPU (the reference's tests use the same
+    ``__new__`` + hand-set attributes idiom: tests/test_modeling_open_provence.py:214,349,...) whose
+    ``forward`` is a caller-supplied stub -- used to pin host semantics on the CPU box."""
+
+    from open_provence_amd import modeling
+
+    klass = cls or modeling.OpenProvenceModel
+    model = klass.__new__(klass)
+    model.tokenizer = tokenizer or CharTokenizer()
+    model.max_length = max_length
+    model._runtime_device = torch.device("cpu")
+    model.default_threshold = 0.1
+    model.default_splitter_language = "auto"
+    model._manual_special_tokens_required = False
+    model._manual_cls_token_id = None
+    model._manual_sep_token_id = None
+    model._update_runtime_defaults()
+    if forward is not None:
+        model.forward = forward
+    return model
+
+
+def golden_stub_forward(input_ids=None, attention_mask=None, **_kw):
+    """The deterministic forward replacement used to generate g3_process_stub*.json
+    (tests/golden/make_golden.py: stub_forward)."""
+
+    b, length = input_ids.shape
+    pos = torch.arange(length, dtype=torch.float32)[None, :].expand(b, length)
+    tok = input_ids.to(torch.float32)
+    keep = torch.sin(0.37 * pos + 0.011 * tok) * 3.0
+    prune = torch.stack([torch.zeros_like(keep), keep], dim=-1)
+    rank = (input_ids.sum(dim=1, keepdim=True).to(torch.float32) % 17.0) / 4.0 - 2.0
+    return {"ranking_logits": rank, "pruning_logits": prune}
+
+
+def assert_process_result_matches(result, expected, *, prob_tol: float, score_tol: float):
+    """Structural equality for text/indices, tolerance for the floating-point fields."""
+
+    import math
+
+    def walk(got, exp, path, tol):
+        if isinstance(exp, float) or isinstance(got, float):
+            if exp is None or got is None:
+                assert got == exp, path
+            else:
+                assert math.isclose(float(got), float(exp), rel_tol=0.0, abs_tol=tol), (path, got, exp)
+        elif isinstance(exp, (list, tuple)):
+            assert isinstance(got, (list, tuple)) and len(got) == len(exp), (path, got, exp)
+            for i, (g, e) in enumerate(zip(got, exp)):
+                walk(g, e, f"{path}[{i}]", tol)
+        else:
+            assert got == exp, (path, got, exp)
+
+    for key in ("pruned_context", "title", "kept_sentences", "removed_sentences"):
+        assert key in result, key
+        walk(result[key], expected[key], key, 0.0)
+    walk(result["compression_rate"], expected["compression_rate"], "compression_rate", 1e-9)
+    walk(result["sentence_probabilities"], expected["sentence_probabilities"], "sentence_probabilities", prob_tol)
+    walk(result["reranking_score"], expected["reranking_score"], "reranking_score", score_tol)

@@ -1,0 +1,230 @@
+"""GPU tests of the drop-in class: process() end to end on the HIP path against the real reference's
+outputs (g3_process_model), the padded forward boundary, checkpoint loading, and size-independent
+properties at the BASELINE.json batch size."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (
+    GOLDEN_DIR,
+    CharTokenizer,
+    assert_process_result_matches,
+    dims_from_meta,
+    load_golden,
+    period_splitter,
+    rows_from_fixture,
+    state_from_fixture,
+)
+
+pytestmark = pytest.mark.gpu
+
+
+def _g3_model(precision="bf16x3", cls=None):
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.modeling import OpenProvenceModel
+    from open_provence_amd.synthetic import synth_state_dict
+
+    with open(GOLDEN_DIR / "g3_process_model.json", "r", encoding="utf-8") as handle:
+        meta = json.load(handle)
+    cfg = OpenProvenceConfig(
+        base_model_config=meta["base_model_config"],
+        tokenizer_name_or_path="char-tokenizer",
+        pruning_config={"hidden_size": meta["base_model_config"]["hidden_size"]},
+        max_length=meta["max_length"],
+        num_labels=1,
+    )
+    state = synth_state_dict(dims_from_meta(meta), meta["weight_seed"])
+    klass = cls or OpenProvenceModel
+    model = klass(cfg, device="cuda:0", tokenizer=CharTokenizer(), state_dict=state, precision=precision)
+    return model, meta
+
+
+def test_process_end_to_end_matches_reference():
+    """Identical kept/removed sentence sets and pruned text; probabilities / scores within 1e-3."""
+
+    model, meta = _g3_model()
+    for case in meta["cases"]:
+        result = model.process(
+            question=case["question"],
+            context=case["context"],
+            sentence_splitter=period_splitter,
+            show_progress=False,
+            return_sentence_metrics=True,
+            return_sentence_texts=True,
+            batch_size=4,
+            **case["kwargs"],
+        )
+        assert_process_result_matches(result, case["expected"], prob_tol=1e-3, score_tol=1e-3)
+        assert result["timing"]["inference_seconds"] > 0.0
+
+
+def test_padded_forward_boundary():
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.modeling import OpenProvenceForTokenClassification, OpenProvenceModel
+
+    arrays, meta = load_golden("g0c_hd64_synth")
+    cfg = OpenProvenceConfig(
+        base_model_config=meta["base_model_config"], tokenizer_name_or_path="x",
+        pruning_config={"hidden_size": meta["base_model_config"]["hidden_size"]}, max_length=128,
+    )
+    state = state_from_fixture(arrays, meta)
+    model = OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
+    ids = torch.from_numpy(arrays["input_ids"])
+    mask = torch.from_numpy(arrays["attention_mask"])
+    out = model(input_ids=ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids))
+    assert out.logits is out.ranking_logits and out["pruning_logits"].shape == (ids.shape[0], ids.shape[1], 2)
+    prune = out.pruning_logits.cpu().numpy()
+    m = mask.bool().numpy()
+    assert np.abs(prune - arrays["pruning_logits"])[m].max() < 1e-3
+    assert np.all(prune[~m] == 0.0)
+    assert np.abs(out.ranking_logits.cpu().numpy() - arrays["ranking_logits"]).max() < 1e-3
+    rank_t, prune_t = model(input_ids=ids.cuda(), attention_mask=mask.cuda(), return_dict=False)
+    assert torch.equal(rank_t, out.ranking_logits) and torch.equal(prune_t, out.pruning_logits)
+    with pytest.raises(ValueError):
+        model(input_ids=None)
+    with pytest.raises(NotImplementedError):  # left padding is not what process() produces
+        model(input_ids=ids, attention_mask=torch.flip(mask, dims=[1]))
+
+    tok_model = OpenProvenceForTokenClassification(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
+    tout = tok_model(input_ids=ids, attention_mask=mask)
+    assert tout.logits.shape[-1] == 2 and torch.equal(tout.logits, out.pruning_logits)
+    assert torch.equal(tout.ranking_logits, out.ranking_logits)
+
+
+def test_from_pretrained_roundtrip_including_legacy_keys_and_bf16_weights(tmp_path):
+    from safetensors.torch import save_file
+
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.modeling import OpenProvenceModel
+
+    arrays, meta = load_golden("g0c_hd64_synth")
+    state = state_from_fixture(arrays, meta)
+    cfg = OpenProvenceConfig(
+        base_model_config=meta["base_model_config"], tokenizer_name_or_path="x",
+        pruning_config={"hidden_size": 128}, max_length=128, default_threadshold=0.2,
+    )
+    rows = rows_from_fixture(arrays)
+    ref_model = OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
+    ref_prune, ref_rank, _ = ref_model.encoder.forward_rows(rows)
+
+    # modern layout
+    d1 = tmp_path / "ckpt"
+    d1.mkdir()
+    cfg.save_json(d1 / "config.json")
+    save_file({k: v.contiguous() for k, v in state.items()}, str(d1 / "model.safetensors"))
+    m1 = OpenProvenceModel.from_pretrained(d1, device="cuda", tokenizer=CharTokenizer(), max_length=64)
+    assert m1.max_length == 64 and m1.default_threshold == pytest.approx(0.2)
+    p1, r1, _ = m1.encoder.forward_rows(rows)
+    assert torch.equal(p1, ref_prune) and torch.equal(r1, ref_rank)
+
+    # legacy layout: no "ranking_model." prefix (standalone.py:1452-1464)
+    d2 = tmp_path / "legacy"
+    d2.mkdir()
+    cfg.save_json(d2 / "config.json")
+    legacy = {(k[len("ranking_model."):] if k.startswith("ranking_model.") else k): v.contiguous() for k, v in state.items()}
+    save_file(legacy, str(d2 / "model.safetensors"))
+    m2 = OpenProvenceModel.from_pretrained(d2, device="cuda", tokenizer=CharTokenizer())
+    p2, _, _ = m2.encoder.forward_rows(rows)
+    assert torch.equal(p2, ref_prune)
+
+    # bf16 checkpoint tensors are widened on load (not bit-identical to fp32 weights, but close)
+    d3 = tmp_path / "bf16"
+    d3.mkdir()
+    cfg.save_json(d3 / "config.json")
+    save_file({k: v.to(torch.bfloat16).contiguous() for k, v in state.items()}, str(d3 / "model.safetensors"))
+    m3 = OpenProvenceModel.from_pretrained(d3, device="cuda", tokenizer=CharTokenizer())
+    p3, _, _ = m3.encoder.forward_rows(rows)
+    assert torch.isfinite(p3).all() and (p3 - ref_prune).abs().max() < 0.3
+
+    with pytest.raises(FileNotFoundError):
+        OpenProvenceModel.from_pretrained(tmp_path / "missing", device="cuda")
+
+
+def test_missing_weight_is_reported():
+    from open_provence_amd import _lib
+    from open_provence_amd.engine import HipEncoder
+
+    arrays, meta = load_golden("g0c_hd64_synth")
+    state = state_from_fixture(arrays, meta)
+    state.pop("ranking_model.model.layers.2.mlp.Wo.weight")
+    enc = HipEncoder(dims_from_meta(meta), device="cuda")
+    with pytest.raises(_lib.HipLibraryError, match="layers.2.mlp.Wo.weight"):
+        enc.load_state_dict(state)
+    with pytest.raises(_lib.HipLibraryError, match="shape"):
+        enc.load_weight("ranking_model.model.final_norm.weight", torch.zeros(7))
+
+
+def test_single_block_api():
+    model, _ = _g3_model()
+    contexts = ["First part. ", "Second part is here. ", "Third."]
+    raw = model.get_raw_predictions("a query?", contexts)
+    assert raw.context_ranges == [(10, 22), (22, 43), (43, 49)]
+    assert raw.pruning_probs.dtype == np.float32 and len(raw.pruning_probs) == 50
+    assert 0.0 < raw.ranking_score < 1.0
+    res = model.predict_with_thresholds("a query?", contexts, [0.1, 0.9])
+    assert set(res["predictions"]) == {0.1, 0.9} and all(len(v) == 3 for v in res["predictions"].values())
+    batch = model.get_raw_predictions_batch(["q1?", "q2?"], [contexts, contexts[:1]], batch_size=1)
+    assert len(batch) == 2 and len(batch[1].context_ranges) == 1
+    with pytest.raises(ValueError):
+        model.get_raw_predictions_batch(["q1?"], [contexts, contexts])
+
+
+def test_edge_cases_empty_single_token_and_long_sequence():
+    from open_provence_amd.engine import HipEncoder
+    from oracle.modernbert_oracle import oracle_forward
+
+    arrays, meta = load_golden("g0c_hd64_synth")
+    dims = dims_from_meta(meta)
+    state = state_from_fixture(arrays, meta)
+    enc = HipEncoder(dims, device="cuda")
+    enc.load_state_dict(state)
+    prune, rank, _ = enc.forward_rows([])
+    assert prune.shape == (0, 2) and rank.shape == (0, 1)
+    rng = np.random.default_rng(5)
+    rows = [[1], [1, 7, 2], rng.integers(3, 250, size=2050).tolist(), [], [9, 9]]
+    prune, rank, cu = enc.forward_rows(rows)
+    assert prune.shape == (2056, 2) and torch.isfinite(prune).all() and torch.isfinite(rank).all()
+    assert rank[3].abs().max() == 0  # empty row: defined as zeros
+    for i in (0, 1, 2, 4):
+        ids = torch.tensor([rows[i]], dtype=torch.long)
+        ref = oracle_forward(state, dims, ids, torch.ones_like(ids))
+        got = prune[cu[i] : cu[i + 1]].cpu()
+        assert (got - ref.pruning_logits[0]).abs().max() < 1e-3, i
+        assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3, i
+
+
+def test_batch_composition_invariance_at_baseline_size():
+    """C2 size (256 pairs x 512 tokens, xsmall dims): every pair's outputs are bit-identical whatever the
+    batch order, the companions in the batch or the chunking -- pairs are independent."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict
+
+    dims = named_dims("xsmall", vocab_size=8192)
+    state = synth_state_dict(dims, 3)
+    rows = synth_pair_batch(dims, 256, 512)
+    enc = HipEncoder(dims, device="cuda")
+    enc.load_state_dict(state)
+    prune, rank, cu = enc.forward_rows(rows)
+    assert torch.isfinite(prune).all() and torch.isfinite(rank).all()
+    perm = np.random.default_rng(0).permutation(256)
+    prune_p, rank_p, cu_p = enc.forward_rows([rows[i] for i in perm])
+    assert torch.equal(rank_p, rank[torch.from_numpy(perm).cuda()])
+    for j in (0, 17, 255):
+        i = int(perm[j])
+        assert torch.equal(prune_p[cu_p[j] : cu_p[j + 1]], prune[cu[i] : cu[i + 1]])
+    small = HipEncoder(dims, device="cuda", chunk_rows=4096)
+    small.load_state_dict(state)
+    prune_s, rank_s, _ = small.forward_rows(rows[:40])
+    assert torch.equal(rank_s, rank[:40]) and torch.equal(prune_s, prune[: cu[40]])
+    # spot-check three pairs against the CPU oracle at full length
+    from oracle.modernbert_oracle import oracle_forward
+
+    for i in (0, 100, 255):
+        ids = torch.tensor([rows[i]], dtype=torch.long)
+        ref = oracle_forward(state, dims, ids, torch.ones_like(ids))
+        assert (prune[cu[i] : cu[i + 1]].cpu() - ref.pruning_logits[0]).abs().max() < 1e-3
+        assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3

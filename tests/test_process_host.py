@@ -1,0 +1,95 @@
+"""Host pipeline of process() against golden outputs of the REAL reference (tests/golden/g3_process_stub*.json).
+
+The forward is replaced by the same deterministic stub on both sides, so every difference would be a
+difference in host semantics: input-shape dispatch, titles, sentence collection, fragmenting, block
+assembly, special tokens, ranges (incl. the title-offset quirk), sentence means, thresholding,
+compression, zero-score rule, reordering/top-k and output un-nesting."""
+
+import json
+
+import pytest
+
+from helpers import (
+    GOLDEN_DIR,
+    CharTokenizer,
+    assert_process_result_matches,
+    golden_stub_forward,
+    host_only_model,
+    period_splitter,
+)
+
+
+def _cases(name):
+    with open(GOLDEN_DIR / f"{name}.json", "r", encoding="utf-8") as handle:
+        meta = json.load(handle)
+    return meta, [pytest.param(meta, case, id=case["case"]) for case in meta["cases"]]
+
+
+_META_STD, _CASES_STD = _cases("g3_process_stub")
+_META_MAN, _CASES_MAN = _cases("g3_process_stub_manual_specials")
+
+
+def _run(meta, case):
+    model = host_only_model(
+        CharTokenizer(emit_specials=meta["emit_specials"]), max_length=meta["max_length"], forward=golden_stub_forward
+    )
+    return model.process(
+        question=case["question"],
+        context=case["context"],
+        sentence_splitter=period_splitter,
+        show_progress=False,
+        return_sentence_metrics=True,
+        return_sentence_texts=True,
+        batch_size=4,
+        **case["kwargs"],
+    )
+
+
+@pytest.mark.parametrize("meta,case", _CASES_STD)
+def test_process_matches_reference_with_stub_forward(meta, case):
+    result = _run(meta, case)
+    assert_process_result_matches(result, case["expected"], prob_tol=1e-6, score_tol=1e-6)
+    assert set(result["timing"]) == {
+        "preprocess_seconds", "assembly_seconds", "inference_seconds", "postprocess_seconds", "total_seconds",
+        "sentence_collect_seconds", "sentence_normalize_seconds", "tokenize_seconds", "fragment_split_seconds",
+        "fragment_decode_seconds",
+    }
+    assert result["performance_trace"].as_dict() == result["timing"]
+
+
+@pytest.mark.parametrize("meta,case", _CASES_MAN)
+def test_process_manual_special_tokens_path(meta, case):
+    model = host_only_model(CharTokenizer(emit_specials=False), max_length=meta["max_length"], forward=golden_stub_forward)
+    assert model._manual_special_tokens_required is True
+    result = _run(meta, case)
+    assert_process_result_matches(result, case["expected"], prob_tol=1e-6, score_tol=1e-6)
+
+
+def test_optional_keys_follow_flags():
+    model = host_only_model(forward=golden_stub_forward)
+    plain = model.process("q?", "One. Two.", sentence_splitter=period_splitter, show_progress=False)
+    assert "kept_sentences" not in plain and "sentence_probabilities" not in plain
+    full = model.process(
+        "q?", "One. Two.", sentence_splitter=period_splitter, show_progress=False,
+        return_sentence_texts=True, return_sentence_metrics=True,
+    )
+    assert {"kept_sentences", "removed_sentences", "sentence_probabilities"} <= set(full)
+
+
+def test_batch_size_and_preprocess_batch_do_not_change_results():
+    model = host_only_model(forward=golden_stub_forward)
+    case = _META_STD["cases"][4]  # long document, several blocks
+    kwargs = dict(sentence_splitter=period_splitter, show_progress=False, return_sentence_metrics=True, threshold=0.5)
+    a = model.process(case["question"], case["context"], batch_size=1, **kwargs)
+    b = model.process(case["question"], case["context"], batch_size=64, preprocess_batch_size=1, **kwargs)
+    assert a["pruned_context"] == b["pruned_context"]
+    assert a["sentence_probabilities"] == b["sentence_probabilities"]
+    assert a["reranking_score"] == b["reranking_score"]
+
+
+def test_mismatched_lengths_raise():
+    model = host_only_model(forward=golden_stub_forward)
+    with pytest.raises(ValueError):
+        model.process(["a", "b"], ["only one"], sentence_splitter=period_splitter, show_progress=False)
+    with pytest.raises(ValueError):
+        model.process("q", "ctx", title="T", first_line_as_title=True, sentence_splitter=period_splitter, show_progress=False)
