@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""Headline benchmark: query-context pairs/sec of the cross-encoder forward on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path (``op_forward_packed``: ids -> per-token keep/drop logits + CLS rerank
+logits) over one batch of synthetic (query, context) pairs already resident in HBM.  Workload =
+BASELINE.json configs[1]: open-provence-reranker-xsmall-v1 dims, 256 pairs x 512 tokens per GPU, one query
+shared by all contexts, random-init weights (no network: no checkpoint, no dataset).  N > 1 is weak
+scaling: every rank processes its own 256 pairs (no data-path collective) and the per-pair outputs are
+gathered on rank 0 over RCCL inside the timed step.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from open_provence_amd.config import EncoderDims  # noqa: E402
+from open_provence_amd.engine import HipEncoder  # noqa: E402
+from open_provence_amd.packing import pack_rows  # noqa: E402
+from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict  # noqa: E402
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_flops_per_pair(dims: EncoderDims, seq_len: int) -> float:
+    """per token per layer 2*(4H^2 + 3HI) linear + 4*H*S_eff attention (keys inside the
+    mask only; edge-exact local window), + 4H per token (pruning head) + 2H^2 + 2H*nl per pair (rank head)."""
+
+    H, I, L = dims.hidden_size, dims.intermediate_size, seq_len
+    w = dims.half_window
+    idx = np.arange(L)
+    local_keys = float((np.minimum(idx + w, L - 1) - np.maximum(idx - w, 0) + 1).mean())
+    per_token = 0.0
+    for is_global in dims.layer_is_global:
+        per_token += 2.0 * (4 * H * H + 3 * H * I) + 4.0 * H * (L if is_global else local_keys)
+    per_token += 4.0 * H
+    return per_token * L + 2.0 * H * H + 2.0 * H * dims.num_labels
+
+
+def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
+    """The CPU oracle (torch fp32, SDPA attention = what the reference executes on a CPU device) timed on this
+    box's host cores on a bounded sample: batch 32 (the reference's default batch_size) x seq_len."""
+
+    from oracle.modernbert_oracle import oracle_forward
+    from open_provence_amd.synthetic import pad_rows
+
+    threads = torch.get_num_threads()
+    rows = synth_pair_batch(dims, 32, seq_len, seed=4321)
+    ids, mask = pad_rows(rows)
+    with torch.no_grad():
+        oracle_forward(state, dims, ids[:4], mask[:4], attn="sdpa")  # warm-up
+        t0 = time.perf_counter()
+        iters = 0
+        while True:
+            oracle_forward(state, dims, ids, mask, attn="sdpa")
+            iters += 1
+            elapsed = time.perf_counter() - t0
+            if iters >= 3 or elapsed > 20.0:
+                break
+    return {
+        "value": 32 * iters / elapsed,
+        "unit": "pairs/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle/modernbert_oracle.py (torch-CPU fp32, SDPA), {iters} x batch 32 x seq_len {seq_len}, {threads} threads",
+    }
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=20)
+    parser.add_argument("--warmup", type=int, default=5)
+    parser.add_argument("--pairs", type=int, default=256, help="pairs per GPU")
+    parser.add_argument("--seq-len", type=int, default=512)
+    parser.add_argument("--model", default="xsmall", choices=["xsmall", "base", "large", "en-gte"])
+    parser.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    parser.add_argument("--chunk-rows", type=int, default=0)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the hot path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore[no-redef]
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    dims = named_dims(args.model)
+    state = synth_state_dict(dims, seed=7)
+    encoder = HipEncoder(dims, device=device, precision=args.precision, chunk_rows=args.chunk_rows or None)
+    encoder.load_state_dict(state)
+
+    # 1 query x (pairs * world) contexts; this rank owns a contiguous slice (weak scaling: fixed per-GPU work)
+    rows_all = synth_pair_batch(dims, args.pairs * world, args.seq_len, seed=1234)
+    rows = rows_all[rank * args.pairs : (rank + 1) * args.pairs]
+    ids_np, cu_np, max_len = pack_rows(rows)
+    ids = torch.from_numpy(ids_np).to(device)
+    cu = torch.from_numpy(cu_np).to(device)
+    total_tokens = int(cu_np[-1])
+
+    gather_rank = gather_prune = None
+    if world > 1 and rank == 0:
+        gather_rank = [torch.empty((args.pairs, dims.num_labels), dtype=torch.float32, device=device) for _ in range(world)]
+        gather_prune = [torch.empty((total_tokens, 2), dtype=torch.float32, device=device) for _ in range(world)]
+
+    def step():
+        prune, rank_logits = encoder.forward_packed(ids, cu, cu_np, max_len)
+        if world > 1:
+            dist.gather(rank_logits, gather_list=gather_rank, dst=0)
+            dist.gather(prune, gather_list=gather_prune, dst=0)
+        return prune, rank_logits
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(out[0]).all().item() and torch.isfinite(out[1]).all().item())
+
+    # per-kernel HIP-event timing on the launch stream (separate, un-timed passes)
+    encoder.profile_enable(True)
+    encoder.profile_reset()
+    prof_steps = 3
+    for _ in range(prof_steps):
+        encoder.forward_packed(ids, cu, cu_np, max_len)
+    profile = encoder.profile_read()
+    encoder.profile_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    pairs_per_s = args.pairs * world * args.steps / elapsed
+    flops_pair = algorithmic_flops_per_pair(dims, args.seq_len)
+    whole_tflops = pairs_per_s / world * flops_pair / 1e12  # per GPU
+
+    dominant = max(profile.items(), key=lambda kv: kv[1]["total_ms"])[0]
+    H, I = dims.hidden_size, dims.intermediate_size
+    n_layers = dims.num_layers
+    n_global = sum(dims.layer_is_global)
+    w = dims.half_window
+    idx = np.arange(args.seq_len)
+    local_keys = float((np.minimum(idx + w, args.seq_len - 1) - np.maximum(idx - w, 0) + 1).mean())
+    flops_per_forward = {  # algorithmic FLOPs of each kernel kind over one forward of this rank's batch
+        "gemm_qk_rope": 2.0 * total_tokens * H * 2 * H * n_layers,
+        "gemm_v_t": 2.0 * total_tokens * H * H * n_layers,
+        "gemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
+        "gemm_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,
+        "gemm_mlp_out": 2.0 * total_tokens * I * H * n_layers,
+        "attn_global": 4.0 * total_tokens * H * args.seq_len * n_global,
+        "attn_local": 4.0 * total_tokens * H * local_keys * (n_layers - n_global),
+    }
+    roofline = None
+    if dominant in flops_per_forward:
+        entry = profile[dominant]
+        launches_per_forward = entry["launches"] / prof_steps
+        flops_per_launch = flops_per_forward[dominant] / launches_per_forward
+        achieved = flops_per_launch / (entry["avg_ms"] * 1e-3) / 1e12
+        traffic = None
+        pmc_file = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc_file.exists():
+            try:
+                traffic = json.loads(pmc_file.read_text()).get(f"{dominant}:{args.precision}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "mfma",
+            "kernel": dominant,
+            "achieved": achieved,
+            "peak": BF16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
+            "traffic": traffic,
+            "avg_launch_ms": entry["avg_ms"],
+            "algorithmic_flops_per_launch": flops_per_launch,
+            "whole_forward_tflops": whole_tflops,
+            "whole_forward_frac": whole_tflops / BF16_MFMA_PEAK_TFLOPS,
+        }
+
+    line = {
+        "metric": "query-context pairs/sec @ seq_len %d, %s-v1" % (args.seq_len, args.model),
+        "value": pairs_per_s,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"open-provence-reranker-{args.model}-v1 dims (H={H}, I={I}, {n_layers} layers, {dims.num_heads} heads, "
+            f"V={dims.vocab_size}), {args.pairs} pairs/GPU x seq_len {args.seq_len}, 1 query x N contexts, random-init weights",
+            "pairs_per_gpu": args.pairs,
+            "seq_len": args.seq_len,
+            "global_pairs": args.pairs * world,
+            "precision": args.precision + (" (bf16 hi/lo split operands, 3 MFMA passes, fp32 accumulate)" if args.precision == "bf16x3" else " (single-pass bf16 operands, fp32 accumulate)"),
+            "parallelism": f"dp{world} (pairs sharded, RCCL gather of per-pair outputs)" if world > 1 else "single GPU",
+            "algorithmic_gflop_per_pair": flops_pair / 1e9,
+            "outputs_finite": finite,
+        },
+        "roofline": roofline,
+        "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in profile.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(dims, state, args.seq_len)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
