@@ -161,7 +161,8 @@ def test_single_block_api():
     model, _ = _g3_model()
     contexts = ["First part. ", "Second part is here. ", "Third."]
     raw = model.get_raw_predictions("a query?", contexts)
-    assert raw.context_ranges == [(10, 22), (22, 43), (43, 49)]
+    # the reference counts the specials of the encoded prefix ([CLS] + 9 chars + [SEP] = 11): standalone.py:1955-1969
+    assert raw.context_ranges == [(11, 23), (23, 44), (44, 50)]
     assert raw.pruning_probs.dtype == np.float32 and len(raw.pruning_probs) == 50
     assert 0.0 < raw.ranking_score < 1.0
     res = model.predict_with_thresholds("a query?", contexts, [0.1, 0.9])
