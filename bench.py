@@ -186,6 +186,9 @@ def main() -> None:
         "gemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
         "gemm_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,
         "gemm_mlp_out": 2.0 * total_tokens * I * H * n_layers,
+        "rowgemm_ln_qkv_rope": 2.0 * total_tokens * H * 3 * H * n_layers,
+        "rowgemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
+        "rowgemm_ln_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,
         "attn_global": 4.0 * total_tokens * H * args.seq_len * n_global,
         "attn_local": 4.0 * total_tokens * H * local_keys * (n_layers - n_global),
     }

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,11 +36,17 @@ enum ProfileKind {
   PK_FINAL_LN_PRUNE,
   PK_RANK_HEAD,
   PK_CAPTURE,
+  PK_ROW_QKV,
+  PK_ROW_ATTN_OUT,
+  PK_ROW_WI_GEGLU,
+  PK_KSTREAM_MLP_OUT,
   PK_COUNT
 };
 const char* kProfileNames[PK_COUNT] = {"rowmap",        "embed_ln",      "layer_norm",    "gemm_qk_rope", "gemm_v_t",
                                        "attn_global",   "attn_local",    "gemm_attn_out", "gemm_wi_geglu",
-                                       "gemm_mlp_out",  "final_ln_prune", "rank_head",    "capture"};
+                                       "gemm_mlp_out",  "final_ln_prune", "rank_head",    "capture",
+                                       "rowgemm_ln_qkv_rope", "rowgemm_attn_out", "rowgemm_ln_wi_geglu",
+                                       "kstream_mlp_out"};
 
 struct LayerWeights {
   float* attn_norm = nullptr;  // absent on layer 0
@@ -48,6 +55,9 @@ struct LayerWeights {
   u16 *wo_hi = nullptr, *wo_lo = nullptr;
   u16 *wi_hi = nullptr, *wi_lo = nullptr;
   u16 *wo2_hi = nullptr, *wo2_lo = nullptr;
+  // row-stationary layouts (hidden <= 256): chunk-major, fragment-ordered, hi/lo planes interleaved per k-step
+  u16 *wqkv_pk = nullptr, *wo_pk = nullptr, *wi_pk = nullptr;
+  u16* wo2_pk = nullptr;  // k-streamed layout for the MLP output projection
 };
 
 struct ProfileEvent {
@@ -61,6 +71,8 @@ struct op_handle {
   op_config cfg;
   int H = 0, I = 0, N = 0, nh = 0, V = 0, nl = 0, max_pos = 0;
   bool split = true;
+  bool row_path = false;  // hidden <= 256: row-stationary GEMMs with fused LayerNorm
+  int row_waves = 8;      // waves per block of the row-stationary kernels (4 or 8)
   int chunk_rows = 0;
   float* emb = nullptr;
   float* emb_norm = nullptr;
@@ -243,10 +255,56 @@ int launch_gemm(Launcher& L, int kind, const GemmParams& p, bool split) {
   return L.end();
 }
 
+
+template <int EPI, int PRO>
+int launch_rowgemm(Launcher& L, int kind, const RowGemmParams& p, int hidden, int r_pad, bool split) {
+  OP_TRY(L.begin(kind));
+  const int waves = L.h->row_waves;
+  const dim3 grid((unsigned)(r_pad / (waves * 32)));
+  const dim3 block((unsigned)(waves * 64));
+  const int ks = hidden / 32;
+#define OPK_ROW_LAUNCH(KS_, W_)                                                                       \
+  do {                                                                                                \
+    if (split)                                                                                        \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, W_>), grid, block, 0, L.stream, p);     \
+    else                                                                                              \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, W_>), grid, block, 0, L.stream, p);    \
+  } while (0)
+  if (ks == 4 && waves == 4) OPK_ROW_LAUNCH(4, 4);
+  else if (ks == 4) OPK_ROW_LAUNCH(4, 8);
+  else if (ks == 8 && waves == 4) OPK_ROW_LAUNCH(8, 4);
+  else if (ks == 8) OPK_ROW_LAUNCH(8, 8);
+  else return fail(L.h, OP_ERR_UNSUPPORTED, "row-stationary GEMM supports hidden 128 or 256, got %d", hidden);
+#undef OPK_ROW_LAUNCH
+  return L.end();
+}
+
+int launch_kstream(Launcher& L, int kind, const KStreamParams& p, int hidden, int r_pad, bool split) {
+  OP_TRY(L.begin(kind));
+  const int waves = L.h->row_waves;
+  const dim3 grid((unsigned)(r_pad / (waves * 32)));
+  const dim3 block((unsigned)(waves * 64));
+  const int nf = hidden / 16;
+#define OPK_KS_LAUNCH(NF_, W_)                                                                     \
+  do {                                                                                             \
+    if (split)                                                                                     \
+      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, true, W_>), grid, block, 0, L.stream, p);       \
+    else                                                                                           \
+      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, false, W_>), grid, block, 0, L.stream, p);      \
+  } while (0)
+  if (nf == 8 && waves == 4) OPK_KS_LAUNCH(8, 4);
+  else if (nf == 8) OPK_KS_LAUNCH(8, 8);
+  else if (nf == 16 && waves == 4) OPK_KS_LAUNCH(16, 4);
+  else if (nf == 16) OPK_KS_LAUNCH(16, 8);
+  else return fail(L.h, OP_ERR_UNSUPPORTED, "k-streamed GEMM supports hidden 128 or 256, got %d", hidden);
+#undef OPK_KS_LAUNCH
+  return L.end();
+}
+
 int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t* ids_dev, const int32_t* cu_dev, int s0,
                   int ns, int rows, int max_len, int total_tokens, float* prune_out, float* rank_out) {
   const int H = h->H, I = h->I;
-  const int r_pad = align_up(rows + 64, GEMM_BM);
+  const int r_pad = align_up(rows + 64, 256);  // multiple of the largest row block (8 waves x 32 rows)
   const int m_tiles = r_pad / GEMM_BM;
   const unsigned row_blocks = (unsigned)((r_pad + 3) / 4);
   const bool split = h->split;
@@ -299,38 +357,70 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     const LayerWeights& lw = h->layers[li];
     const bool is_global = h->cfg.layer_is_global[li] != 0;
     OP_TRY(capture(li));
-    if (li != 0) OP_TRY(layer_norm(lw.attn_norm));
-
+    const bool row_path = h->row_path;
+    RowGemmParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.eps = h->cfg.norm_eps;
+    rp.hidden = H;
+    rp.r_pad = r_pad;
+    rp.row_pos = ws.row_pos;
+    rp.rope_cos = h->rope_cos[is_global ? 1 : 0];
+    rp.rope_sin = h->rope_sin[is_global ? 1 : 0];
+    rp.max_pos = h->max_pos;
+    {
+      const char* dbg = getenv("OPEN_PROVENCE_DEBUG_FLAGS");
+      rp.debug_flags = dbg ? atoi(dbg) : 0;
+    }
+    if (row_path) {
+      // q, k, v^T = RoPE / transpose of LN(x) Wqkv^T, LayerNorm fused into the prologue
+      rp.x_in = ws.x;
+      rp.ln_w = lw.attn_norm;
+      rp.wp = lw.wqkv_pk;
+      rp.n_chunks = 3 * H / ROW_CHUNK;
+      rp.n_swapped = 2 * H / ROW_CHUNK;
+      rp.o0_hi = ws.q_hi; rp.o0_lo = ws.q_lo;
+      rp.o1_hi = ws.k_hi; rp.o1_lo = ws.k_lo;
+      rp.o2_hi = ws.vt_hi; rp.o2_lo = ws.vt_lo;
+      rp.ld_out = H;
+      if (li == 0)
+        OP_TRY((launch_rowgemm<RE_QKV, RP_SPLIT>(L, PK_ROW_QKV, rp, H, r_pad, split)));
+      else
+        OP_TRY((launch_rowgemm<RE_QKV, RP_LN>(L, PK_ROW_QKV, rp, H, r_pad, split)));
+    }
     GemmParams p;
     memset(&p, 0, sizeof(p));
-    p.a_hi = ws.ln_hi;
-    p.a_lo = ws.ln_lo;
-    p.K = H;
-    p.m_tiles = m_tiles;
-    p.hidden = H;
-    p.row_pos = ws.row_pos;
-    p.rope_cos = h->rope_cos[is_global ? 1 : 0];
-    p.rope_sin = h->rope_sin[is_global ? 1 : 0];
-    p.max_pos = h->max_pos;
+    if (!row_path) {
+    if (li != 0) OP_TRY(layer_norm(lw.attn_norm));
 
-    // q, k = RoPE(x Wq^T), RoPE(x Wk^T)
-    p.w_hi = lw.wqkv_hi;
-    p.w_lo = lw.wqkv_lo;
-    p.n_tiles = 2 * H / GEMM_BN;
-    p.o0_hi = ws.q_hi;
-    p.o0_lo = ws.q_lo;
-    p.o1_hi = ws.k_hi;
-    p.o1_lo = ws.k_lo;
-    p.ld_out = H;
-    OP_TRY(launch_gemm<EPI_QK_ROPE>(L, PK_GEMM_QK_ROPE, p, split));
-    // v^T
-    p.w_hi = lw.wqkv_hi + (size_t)2 * H * H;
-    p.w_lo = lw.wqkv_lo + (size_t)2 * H * H;
-    p.n_tiles = H / GEMM_BN;
-    p.o0_hi = ws.vt_hi;
-    p.o0_lo = ws.vt_lo;
-    p.ld_out = r_pad;
-    OP_TRY(launch_gemm<EPI_V_T>(L, PK_GEMM_V_T, p, split));
+      p.a_hi = ws.ln_hi;
+      p.a_lo = ws.ln_lo;
+      p.K = H;
+      p.m_tiles = m_tiles;
+      p.hidden = H;
+      p.row_pos = ws.row_pos;
+      p.rope_cos = h->rope_cos[is_global ? 1 : 0];
+      p.rope_sin = h->rope_sin[is_global ? 1 : 0];
+      p.max_pos = h->max_pos;
+
+      // q, k = RoPE(x Wq^T), RoPE(x Wk^T)
+      p.w_hi = lw.wqkv_hi;
+      p.w_lo = lw.wqkv_lo;
+      p.n_tiles = 2 * H / GEMM_BN;
+      p.o0_hi = ws.q_hi;
+      p.o0_lo = ws.q_lo;
+      p.o1_hi = ws.k_hi;
+      p.o1_lo = ws.k_lo;
+      p.ld_out = H;
+      OP_TRY(launch_gemm<EPI_QK_ROPE>(L, PK_GEMM_QK_ROPE, p, split));
+      // v^T
+      p.w_hi = lw.wqkv_hi + (size_t)2 * H * H;
+      p.w_lo = lw.wqkv_lo + (size_t)2 * H * H;
+      p.n_tiles = H / GEMM_BN;
+      p.o0_hi = ws.vt_hi;
+      p.o0_lo = ws.vt_lo;
+      p.ld_out = r_pad;
+      OP_TRY(launch_gemm<EPI_V_T>(L, PK_GEMM_V_T, p, split));
+    }
 
     AttnParams ap;
     ap.q_hi = ws.q_hi;
@@ -357,39 +447,68 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     }
     OP_TRY(L.end());
 
+    if (row_path) {
+      // x += attn Wo^T
+      rp.a_hi = ws.o_hi; rp.a_lo = ws.o_lo;
+      rp.wp = lw.wo_pk;
+      rp.n_chunks = H / ROW_CHUNK;
+      rp.x = ws.x;
+      rp.ld_out = H;
+      OP_TRY((launch_rowgemm<RE_RESIDUAL, RP_PLANES>(L, PK_ROW_ATTN_OUT, rp, H, r_pad, split)));
+      // h = gelu(a) * g, (a, g) = LN(x) Wi^T, LayerNorm fused
+      rp.x_in = ws.x;
+      rp.ln_w = lw.mlp_norm;
+      rp.wp = lw.wi_pk;
+      rp.n_chunks = 2 * I / ROW_CHUNK;
+      rp.o0_hi = ws.h_hi; rp.o0_lo = ws.h_lo;
+      rp.ld_out = I;
+      OP_TRY((launch_rowgemm<RE_GEGLU, RP_LN>(L, PK_ROW_WI_GEGLU, rp, H, r_pad, split)));
+      p.m_tiles = m_tiles;
+      p.hidden = H;
+    } else {
     // x += attn Wo^T
-    p.a_hi = ws.o_hi;
-    p.a_lo = ws.o_lo;
-    p.w_hi = lw.wo_hi;
-    p.w_lo = lw.wo_lo;
-    p.K = H;
-    p.n_tiles = H / GEMM_BN;
-    p.x = ws.x;
-    p.ld_out = H;
-    OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_ATTN_OUT, p, split));
+      p.a_hi = ws.o_hi;
+      p.a_lo = ws.o_lo;
+      p.w_hi = lw.wo_hi;
+      p.w_lo = lw.wo_lo;
+      p.K = H;
+      p.n_tiles = H / GEMM_BN;
+      p.x = ws.x;
+      p.ld_out = H;
+      OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_ATTN_OUT, p, split));
 
-    // x += (gelu(a) * g) Wo^T,  (a, g) = LN(x) Wi^T
-    OP_TRY(layer_norm(lw.mlp_norm));
-    p.a_hi = ws.ln_hi;
-    p.a_lo = ws.ln_lo;
-    p.w_hi = lw.wi_hi;
-    p.w_lo = lw.wi_lo;
-    p.K = H;
-    p.n_tiles = 2 * I / GEMM_BN;
-    p.o0_hi = ws.h_hi;
-    p.o0_lo = ws.h_lo;
-    p.ld_out = I;
-    OP_TRY(launch_gemm<EPI_GEGLU>(L, PK_GEMM_WI_GEGLU, p, split));
-
-    p.a_hi = ws.h_hi;
-    p.a_lo = ws.h_lo;
-    p.w_hi = lw.wo2_hi;
-    p.w_lo = lw.wo2_lo;
-    p.K = I;
-    p.n_tiles = H / GEMM_BN;
-    p.x = ws.x;
-    p.ld_out = H;
-    OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_MLP_OUT, p, split));
+      // x += (gelu(a) * g) Wo^T,  (a, g) = LN(x) Wi^T
+      OP_TRY(layer_norm(lw.mlp_norm));
+      p.a_hi = ws.ln_hi;
+      p.a_lo = ws.ln_lo;
+      p.w_hi = lw.wi_hi;
+      p.w_lo = lw.wi_lo;
+      p.K = H;
+      p.n_tiles = 2 * I / GEMM_BN;
+      p.o0_hi = ws.h_hi;
+      p.o0_lo = ws.h_lo;
+      p.ld_out = I;
+      OP_TRY(launch_gemm<EPI_GEGLU>(L, PK_GEMM_WI_GEGLU, p, split));
+    }
+    if (row_path) {
+      // x += h Wo^T, h read in its fragment-packed form (ws.h_hi / ws.h_lo are one contiguous buffer)
+      KStreamParams kp;
+      kp.a_fp = ws.h_hi;
+      kp.wp = lw.wo2_pk;
+      kp.n_ksteps = I / 32;
+      kp.x = ws.x;
+      OP_TRY(launch_kstream(L, PK_KSTREAM_MLP_OUT, kp, H, r_pad, split));
+    } else {
+      p.a_hi = ws.h_hi;
+      p.a_lo = ws.h_lo;
+      p.w_hi = lw.wo2_hi;
+      p.w_lo = lw.wo2_lo;
+      p.K = I;
+      p.n_tiles = H / GEMM_BN;
+      p.x = ws.x;
+      p.ld_out = H;
+      OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_MLP_OUT, p, split));
+    }
   }
 
   const int mean_pool = h->cfg.pooling == OP_POOL_MEAN ? 1 : 0;
@@ -471,6 +590,8 @@ int op_create(const op_config* cfg, op_handle** out) {
   h->split = cfg->precision == OP_PRECISION_BF16X3;
   h->chunk_rows = cfg->chunk_rows > 0 ? align_up(cfg->chunk_rows, ROW_ALIGN) : 32768;
   h->layers.resize(N);
+  if (const char* rw = getenv("OPEN_PROVENCE_ROW_WAVES")) h->row_waves = atoi(rw) == 4 ? 4 : 8;
+  h->row_path = (H <= 256) && (H % 32 == 0) && (I % 32 == 0) && getenv("OPEN_PROVENCE_FORCE_TILED") == nullptr;
 
 #define OP_CREATE_TRY(expr)  \
   do {                       \
@@ -521,6 +642,12 @@ int op_create(const op_config* cfg, op_handle** out) {
     OP_CREATE_TRY(dev_alloc(h, &lw.wi_lo, (size_t)2 * I * H));
     OP_CREATE_TRY(dev_alloc(h, &lw.wo2_hi, (size_t)H * I));
     OP_CREATE_TRY(dev_alloc(h, &lw.wo2_lo, (size_t)H * I));
+    if (h->row_path) {
+      OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_pk, 2 * 3 * HH));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wo_pk, 2 * HH));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
+    }
     h->missing.push_back(pre + "mlp_norm.weight");
     h->missing.push_back(pre + "attn.Wqkv.weight");
     h->missing.push_back(pre + "attn.Wo.weight");
@@ -562,6 +689,8 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   const int H = h->H, I = h->I;
 
   enum Kind { F32_COPY, F32_TRANSPOSE, PLANES, PLANES_GEGLU };
+  u16* dst_pk = nullptr;
+  int pk_mode = -1;
   Kind kind = F32_COPY;
   float* dst_f32 = nullptr;
   u16 *dst_hi = nullptr, *dst_lo = nullptr;
@@ -602,12 +731,16 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       dst_f32 = lw.mlp_norm; expect(H, 1);
     } else if (t == "attn.Wqkv.weight") {
       kind = PLANES; dst_hi = lw.wqkv_hi; dst_lo = lw.wqkv_lo; expect(3 * H, H);
+      dst_pk = lw.wqkv_pk; pk_mode = RE_QKV;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
+      dst_pk = lw.wo_pk; pk_mode = RE_RESIDUAL;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
+      dst_pk = lw.wi_pk; pk_mode = RE_GEGLU;
     } else if (t == "mlp.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo2_hi; dst_lo = lw.wo2_lo; expect(H, I);
+      dst_pk = lw.wo2_pk; pk_mode = 100;  // k-streamed
     } else {
       return fail(h, OP_ERR_INVALID, "op_load_weight: unknown tensor name '%s'", name_c);
     }
@@ -644,6 +777,12 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, I, dst_hi, dst_lo);
       break;
   }
+  if (dst_pk && h->row_path) {
+    if (pk_mode == 100)
+      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, dst_pk);
+    else
+      hipLaunchKernelGGL(pack_rowgemm_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_pk);
+  }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(0);
   (void)hipFree(raw);
@@ -672,7 +811,7 @@ int op_weights_ready(op_handle* h) {
 size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int max_seqlen) {
   if (!h || n_seqs < 0 || total_tokens < 0 || max_seqlen < 0) return 0;
   const int cap = chunk_row_capacity(h, n_seqs, total_tokens, max_seqlen);
-  const int cap_pad = align_up(cap + 64, GEMM_BM);
+  const int cap_pad = align_up(cap + 64, 256);
   Workspace ws;
   carve(h, nullptr, cap_pad, n_seqs, ws);
   return ws.bytes;
@@ -759,7 +898,7 @@ int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_de
   }
 
   const int cap = chunk_row_capacity(h, n_seqs, total_tokens, max_seqlen);
-  const int cap_pad = align_up(cap + 64, GEMM_BM);
+  const int cap_pad = align_up(cap + 64, 256);
   Workspace ws;
   carve(h, reinterpret_cast<char*>(workspace), cap_pad, n_seqs, ws);
 

@@ -23,6 +23,7 @@ namespace opk {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef uint16_t u16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte staging register (stays in VGPRs)
 
 constexpr int ROW_ALIGN = 16;   // sequence starts are multiples of this many rows
 constexpr int GEMM_BM = 128;    // rows (tokens) per GEMM tile
@@ -68,7 +69,9 @@ __device__ __forceinline__ bf16x8 as_frag(uint4 u) {
   f.u = u;
   return f.v;
 }
-__device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return as_frag(*reinterpret_cast<const uint4*>(p)); }
+// Load the fragment as an ext-vector type: an LDS load typed as HIP's uint4 class makes hipcc (ROCm 7.2) treat it
+// as possibly aliasing an in-flight global_load_lds DMA and drain the DMA (s_waitcnt vmcnt(0)) in front of it.
+__device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // D = X * Y + C on one wave.  X fragment: row (lane & 15), k-group (lane >> 4) holds 8 consecutive k.
 // Y fragment: column (lane & 15), same k-group.  D: column (lane & 15), rows 4*(lane >> 4) + r.
@@ -82,7 +85,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU (exact-erf form) = 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute, i.e. fp32-roundoff class) instead of the library erff: branch-free, one v_exp_f32
+// and one v_rcp_f32.  Written as x * (1 - e/2) for x >= 0 and x * e/2 for x < 0, e = erfc(|x|/sqrt 2): no
+// cancellation on the negative side.  Max |gelu - exact| = 2.1e-7 over [-6, 6] (checked offline in fp64).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = poly * t * __expf(-z * z);  // erfc(z)
+  return x * (x >= 0.f ? 1.0f - 0.5f * e : 0.5f * e);
+}
 
 // ----------------------------------------------------------------------------------------------
 // row map: sequence offsets (aligned) and per-row (seq, pos, token index)
@@ -682,6 +698,518 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       }
     }
     return;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Row-stationary GEMM for K = hidden <= 256 (the three projections whose input is the hidden state):
+//   C[m, n] = sum_k A[m, k] W[n, k],  A = 128 rows per block kept IN REGISTERS as MFMA fragments
+//   (each wave owns 32 rows = 2 fragments x K/32 k-steps x hi/lo), W streamed through LDS in chunks of
+//   32 output features, double-buffered, one barrier per chunk (96 MFMAs per wave between barriers).
+// Why: the activations are the big operand (read exactly once, never staged through LDS); the weights
+// are small, L2-resident and STATIC, so they are pre-packed at load time in exactly the order the MFMA
+// X/Y fragments want them ([chunk][k-step][plane][frag][k-group][row][8]) -- every LDS fragment read
+// is a lane-linear, conflict-free 1 KiB ds_read_b128, every global->LDS copy a linear memcpy.
+// Prologues fuse what used to be separate kernels: LayerNorm (+ hi/lo split) of the fp32 residual
+// stream is computed in registers directly in fragment layout (a row lives in 4 lanes).
+// ----------------------------------------------------------------------------------------------
+enum RowEpilogue { RE_QKV = 0, RE_RESIDUAL = 1, RE_GEGLU = 2 };
+enum RowPrologue { RP_LN = 0, RP_SPLIT = 1, RP_PLANES = 2 };
+constexpr int ROW_BM = 128;
+constexpr int ROW_CHUNK = 32;  // output features per streamed chunk
+
+struct RowGemmParams {
+  const float* x_in;  // RP_LN / RP_SPLIT: fp32 [r_pad][K]
+  const float* ln_w;  // RP_LN
+  float eps;
+  const u16* a_hi;  // RP_PLANES: planes [r_pad][K]
+  const u16* a_lo;
+  const u16* wp;  // packed weights, n_chunks x (K/32) x 2 planes x 2 frags x 512 elements
+  int n_chunks;
+  int n_swapped;  // RE_QKV: chunks [0, n_swapped) are q/k (RoPE), the rest v (transposed store)
+  float* x;       // RE_RESIDUAL: fp32 [r_pad][ld_out], updated in place
+  u16* o0_hi;     // RE_QKV: q   RE_GEGLU: h
+  u16* o0_lo;
+  u16* o1_hi;  // RE_QKV: k
+  u16* o1_lo;
+  u16* o2_hi;  // RE_QKV: v^T [H][r_pad]
+  u16* o2_lo;
+  int ld_out;  // RE_RESIDUAL: H   RE_GEGLU: I   RE_QKV: H
+  int hidden;
+  int r_pad;
+  const int32_t* row_pos;
+  const float* rope_cos;
+  const float* rope_sin;
+  int max_pos;
+  int debug_flags;  // experiments only (OPEN_PROVENCE_DEBUG_FLAGS): 1 skip epilogue, 2 skip DMA, 4 skip MFMA
+};
+
+// source row of packed row `pr` (0..31) of chunk `c`
+__device__ __forceinline__ int rowgemm_source_row(int mode, int c, int pr, int H, int I) {
+  const int nf = pr >> 4, i = pr & 15;
+  if (mode == RE_QKV) {
+    const int per_block = H / ROW_CHUNK;  // chunks in each of q, k, v
+    if (c < 2 * per_block) {              // q or k: fragment 0 = d in [16j, 16j+16), fragment 1 = d + 32
+      const int blk = c / per_block, cc = c % per_block;
+      const int head = cc >> 1, j = cc & 1;
+      return blk * H + head * HEAD_DIM + 16 * j + 32 * nf + i;
+    }
+    return 2 * H + (c - 2 * per_block) * ROW_CHUNK + pr;
+  }
+  if (mode == RE_GEGLU) {  // chunk pair (2t, 2t+1): lane slot i = 4g + r -> h-column 32t + 8g + 4u + r
+    const int col = 32 * (c >> 1) + 8 * (i >> 2) + 4 * (c & 1) + (i & 3);
+    return nf == 0 ? col : I + col;  // input column | matching gate column
+  }
+  return c * ROW_CHUNK + pr;
+}
+
+// dst[chunk][ks][plane][nf][g][i][e] <- src[source_row(chunk, nf*16+i)][ks*32 + g*8 + e]
+__global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, int K, int mode, int H, int I,
+                                    u16* __restrict__ dst) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_rows * K;
+  if (idx >= total) return;
+  const int KS = K / 32;
+  size_t t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int i = (int)(t & 15); t >>= 4;
+  const int g = (int)(t & 3); t >>= 2;
+  const int nf = (int)(t & 1); t >>= 1;
+  const int ks = (int)(t % KS);
+  const int c = (int)(t / KS);
+  const int srow = rowgemm_source_row(mode, c, nf * 16 + i, H, I);
+  const float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
+  const u16 h = f2bf(v);
+  const size_t base = (((size_t)c * KS + ks) * 2) * 1024 + (size_t)nf * 512 + (size_t)g * 128 + i * 8 + e;
+  dst[base] = h;
+  dst[base + 1024] = f2bf(v - bf2f(h));
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ void pack8(const float v[8], bf16x8& hi, bf16x8& lo) {
+  uint2 h0, l0, h1, l1;
+  split4<SPLIT>(v, h0, l0);
+  split4<SPLIT>(v + 4, h1, l1);
+  hi = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
+  lo = as_frag(make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+
+template <int KS, int EPI, int PRO, bool SPLIT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel(RowGemmParams p) {
+  constexpr int PLANES = SPLIT ? 2 : 1;
+  constexpr int K = KS * 32;
+  constexpr int CHUNK_SRC = KS * 2 * 1024;        // elements per packed chunk in global memory
+  constexpr int STAGE = KS * PLANES * 1024;       // elements per LDS stage
+  static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
+  __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+  const int m0 = blockIdx.x * (WAVES * 32) + wave * 32;
+
+  // ---- weight streaming: global -> LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction) --
+  // Stage layout = [ks][plane][frag][512] = a sequence of 1 KiB pieces; wave w copies pieces w, w+4, ...
+  // The copy is linear (the packing kernel already wrote fragment order), so the lane-linear LDS
+  // destination the DMA imposes is exactly the layout the fragment reads want.  No staging VGPRs, and
+  // the request is in flight while the MFMAs of the current chunk run.
+  constexpr int WAVE_PIECES = STAGE / (WAVES * 512);
+  auto stage_chunk = [&](int chunk, int stage) {
+    const u16* src = p.wp + (size_t)chunk * CHUNK_SRC;
+#pragma unroll
+    for (int u = 0; u < WAVE_PIECES; ++u) {
+      const int piece = wave + WAVES * u;              // wave-uniform
+      const int elem = piece * 512;                    // position inside the LDS stage
+      const int ks = elem / (PLANES * 1024);
+      const int rem = elem % (PLANES * 1024);
+      const int src_elem = ks * 2048 + rem;            // source keeps both planes per k-step
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + src_elem + lane * 8),
+          (__attribute__((address_space(3))) void*)(&sW[stage][elem]), 16, 0, 0);
+    }
+  };
+  stage_chunk(0, 0);
+
+  // ---- prologue: this wave's 32 rows as fragments ---------------------------------------------
+  bf16x8 a_hi[2][KS], a_lo[2][KS];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    const size_t row = (size_t)(m0 + mf * 16 + l15);
+    if (PRO == RP_PLANES) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a_hi[mf][ks] = as_frag(*reinterpret_cast<const uint4*>(p.a_hi + row * K + ks * 32 + g * 8));
+        if (SPLIT) a_lo[mf][ks] = as_frag(*reinterpret_cast<const uint4*>(p.a_lo + row * K + ks * 32 + g * 8));
+      }
+      // Pin the fragment loads in front of the chunk loop: an empty asm that "rewrites" each register makes
+      // the compiler wait for the load HERE; otherwise it sinks the loads next to their first MFMA inside the
+      // loop and then drains the weight DMA (vmcnt(0)) at the top of every iteration.
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("" : "+v"(a_hi[mf][ks]));
+        if (SPLIT) asm volatile("" : "+v"(a_lo[mf][ks]));
+      }
+    } else {
+      float v[KS][8];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 f0 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8);
+        const float4 f1 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8 + 4);
+        v[ks][0] = f0.x; v[ks][1] = f0.y; v[ks][2] = f0.z; v[ks][3] = f0.w;
+        v[ks][4] = f1.x; v[ks][5] = f1.y; v[ks][6] = f1.z; v[ks][7] = f1.w;
+      }
+      if (PRO == RP_LN) {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s += v[ks][e];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[ks][e] - mean;
+            q += d * d;
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)K + p.eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8 + 4);
+          const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[ks][e] = (v[ks][e] - mean) * rstd * ww[e];
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) pack8<SPLIT>(v[ks], a_hi[mf][ks], a_lo[mf][ks]);
+    }
+  }
+
+  // RE_QKV: this lane's two tokens need cos/sin rows [pos][16j + 4g .. +3], j = 0, 1 -- fetched ONCE here (8
+  // float4 registers) instead of two dependent global loads in front of every q/k chunk's stores.
+  f32x4 rope_c[2][2], rope_s[2][2];
+  if (EPI == RE_QKV) {
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      int pos = p.row_pos[m0 + mf * 16 + l15];
+      pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        rope_c[mf][j] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)pos * ROPE_HALF + j * 16 + g * 4);
+        rope_s[mf][j] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)pos * ROPE_HALF + j * 16 + g * 4);
+      }
+    }
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("" : "+v"(rope_c[mf][j]));
+        asm volatile("" : "+v"(rope_s[mf][j]));
+      }
+  }
+  __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
+
+  // ---- stream the weight chunks ---------------------------------------------------------------
+  // Unrolled by two so that the LDS stage index is a compile-time constant in each copy: the compiler can
+  // then tell the DMA into stage cur^1 from the fragment reads of stage cur and does NOT drain the DMA
+  // (s_waitcnt vmcnt(0)) before the first ds_read -- the wait sits only in front of the barrier.
+  uint2 hold_hi[2], hold_lo[2];  // RE_GEGLU: first half of a chunk pair
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
+  for (int c0 = 0; c0 < p.n_chunks; c0 += 2) {
+#pragma unroll
+   for (int cur = 0; cur < 2; ++cur) {
+    const int c = c0 + cur;
+    if (c >= p.n_chunks) break;
+    // every wave passed the barrier that ended iteration c-1, so nobody reads stage cur^1 any more.
+    // Unconditional (the last iteration harmlessly re-copies its own chunk into the idle stage): a DMA issued
+    // under a branch makes the compiler drain it at the join, in front of the first fragment read.
+    if (!(p.debug_flags & 2)) stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
+    const bool swapped = (EPI != RE_QKV) || (c < p.n_swapped);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (p.debug_flags & 4) {
+      acc[0][0][0] = (float)c;
+    } else if (swapped) {  // C rows = features, cols = tokens: lane owns 4 consecutive features of one token
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const bf16x8 wh = lds_frag(&sW[cur][(ks * PLANES) * 1024 + nf * 512 + lane * 8]);
+          if (SPLIT) {
+            const bf16x8 wl = lds_frag(&sW[cur][(ks * PLANES + 1) * 1024 + nf * 512 + lane * 8]);
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+              acc[nf][mf] = mfma16(wl, a_hi[mf][ks], acc[nf][mf]);
+              acc[nf][mf] = mfma16(wh, a_lo[mf][ks], acc[nf][mf]);
+            }
+          }
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = mfma16(wh, a_hi[mf][ks], acc[nf][mf]);
+        }
+      }
+    } else {  // v chunks: C rows = tokens, cols = features
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const bf16x8 wh = lds_frag(&sW[cur][(ks * PLANES) * 1024 + nf * 512 + lane * 8]);
+          if (SPLIT) {
+            const bf16x8 wl = lds_frag(&sW[cur][(ks * PLANES + 1) * 1024 + nf * 512 + lane * 8]);
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+              acc[nf][mf] = mfma16(a_hi[mf][ks], wl, acc[nf][mf]);
+              acc[nf][mf] = mfma16(a_lo[mf][ks], wh, acc[nf][mf]);
+            }
+          }
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = mfma16(a_hi[mf][ks], wh, acc[nf][mf]);
+        }
+      }
+    }
+
+    // ---- epilogue of this chunk --------------------------------------------------------------
+    if ((p.debug_flags & 1) && acc[0][0][0] != 12345.f) {
+    } else if (EPI == RE_RESIDUAL) {
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        const size_t row = (size_t)(m0 + mf * 16 + l15);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          float4* px = reinterpret_cast<float4*>(p.x + row * p.ld_out + c * ROW_CHUNK + nf * 16 + g * 4);
+          float4 r4 = *px;
+          r4.x += acc[nf][mf][0];
+          r4.y += acc[nf][mf][1];
+          r4.z += acc[nf][mf][2];
+          r4.w += acc[nf][mf][3];
+          *px = r4;
+        }
+      }
+    } else if (EPI == RE_GEGLU) {
+      // Output = "fragment-packed" h (see hfp_offset): chunk 2t gives this lane h-columns 32t + 8g + (0..3),
+      // chunk 2t+1 columns 32t + 8g + (4..7) (the Wi rows were permuted that way at load time), so after the
+      // pair the lane owns the 8 consecutive k-values of ITS OWN fragment slot for k-step t of the next GEMM
+      // and the wave stores one contiguous 1 KiB piece per (16-row block, plane).
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(acc[0][mf][r]) * acc[1][mf][r];
+        uint2 h2, l2;
+        split4<SPLIT>(v, h2, l2);
+        if (cur == 0) {
+          hold_hi[mf] = h2;
+          hold_lo[mf] = l2;
+        } else {
+          const size_t rb = (size_t)((m0 >> 4) + mf);
+          const size_t off = ((rb * (size_t)(p.ld_out >> 5) + (size_t)(c >> 1)) * 2) * 512 + lane * 8;
+          *reinterpret_cast<uint4*>(p.o0_hi + off) = make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y);
+          if (SPLIT) *reinterpret_cast<uint4*>(p.o0_hi + off + 512) = make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y);
+        }
+      }
+    } else {  // RE_QKV
+      if (swapped) {
+        const int per_block = p.hidden / ROW_CHUNK;
+        const bool is_q = c < per_block;
+        const int cc = is_q ? c : c - per_block;
+        const int col0 = (cc >> 1) * HEAD_DIM + (cc & 1) * 16 + g * 4;  // d = 16j + 4g + r, partner d + 32
+        u16* out_hi = is_q ? p.o0_hi : p.o1_hi;
+        u16* out_lo = is_q ? p.o0_lo : p.o1_lo;
+        const float qscale = is_q ? 0.125f : 1.0f;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+          const size_t row = (size_t)(m0 + mf * 16 + l15);
+          // hidden is a multiple of 64, so the number of chunks per q/k block is even and the half-head index
+          // j = cc & 1 equals the unroll index `cur`: a compile-time register choice, no dynamic indexing.
+          const f32x4 c4 = rope_c[mf][cur];
+          const f32x4 s4 = rope_s[mf][cur];
+          const float cs[4] = {c4[0], c4[1], c4[2], c4[3]};
+          const float sn[4] = {s4[0], s4[1], s4[2], s4[3]};
+          float lo_half[4], hi_half[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x1 = acc[0][mf][r], x2 = acc[1][mf][r];
+            lo_half[r] = (x1 * cs[r] - x2 * sn[r]) * qscale;
+            hi_half[r] = (x2 * cs[r] + x1 * sn[r]) * qscale;
+          }
+          uint2 h2, l2;
+          const size_t off = row * p.ld_out + col0;
+          split4<SPLIT>(lo_half, h2, l2);
+          *reinterpret_cast<uint2*>(out_hi + off) = h2;
+          if (SPLIT) *reinterpret_cast<uint2*>(out_lo + off) = l2;
+          split4<SPLIT>(hi_half, h2, l2);
+          *reinterpret_cast<uint2*>(out_hi + off + 32) = h2;
+          if (SPLIT) *reinterpret_cast<uint2*>(out_lo + off + 32) = l2;
+        }
+      } else {
+        const int cv = c - p.n_swapped;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const size_t f = (size_t)(cv * ROW_CHUNK + nf * 16 + l15);
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf) {
+            const float v[4] = {acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]};
+            uint2 h2, l2;
+            split4<SPLIT>(v, h2, l2);
+            const size_t off = f * p.r_pad + m0 + mf * 16 + g * 4;
+            *reinterpret_cast<uint2*>(p.o2_hi + off) = h2;
+            if (SPLIT) *reinterpret_cast<uint2*>(p.o2_lo + off) = l2;
+          }
+        }
+      }
+    }
+
+    __syncthreads();
+   }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Fragment-packed activations.  An activation matrix [rows x C] that is consumed as the MFMA operand
+// of the next GEMM is stored as 1 KiB pieces  [row/16][C/32][plane][lane = 16*(k%32/8) + row%16][8 k]:
+// exactly one wave-instruction of 16-byte lanes, in lane order.  Producer epilogues store whole pieces
+// (one fully coalesced 1 KiB store per wave), consumers load their fragment with one fully coalesced
+// 1 KiB load straight into registers -- no LDS staging, no row-strided 8-byte accesses.
+// ----------------------------------------------------------------------------------------------
+
+// dst[ks][plane][nf][g][i][e] <- W[nf*16 + i][ks*32 + g*8 + e]   (W is [N][K]; chunk = one k-step of all N)
+__global__ void pack_kstream_kernel(const float* __restrict__ src, int N, int K, u16* __restrict__ dst) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * K) return;
+  const int NF = N / 16;
+  size_t t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int i = (int)(t & 15); t >>= 4;
+  const int g = (int)(t & 3); t >>= 2;
+  const int nf = (int)(t % NF);
+  const int ks = (int)(t / NF);
+  const float v = src[(size_t)(nf * 16 + i) * K + ks * 32 + g * 8 + e];
+  const u16 h = f2bf(v);
+  const size_t base = ((size_t)ks * 2 * NF + nf) * 512 + (size_t)g * 128 + i * 8 + e;
+  dst[base] = h;
+  dst[base + (size_t)NF * 512] = f2bf(v - bf2f(h));
+}
+
+struct KStreamParams {
+  const u16* a_fp;  // fragment-packed activations [r_pad/16][n_ksteps][2 planes][512]
+  const u16* wp;    // packed weights [n_ksteps][2 planes][NF][512]
+  int n_ksteps;     // K / 32
+  float* x;         // fp32 [r_pad][N], x += A W^T
+};
+
+// x[128 or 256 rows, N = 16*NF] += A[rows, K] W[N, K]^T with K streamed: per k-step the block DMAs one
+// [N x 32] weight slab into LDS (double-buffered) while every wave pulls its own two A fragments straight
+// from the fragment-packed activation (prefetched one k-step ahead) and keeps all N outputs of its 32 rows
+// in accumulators (NF x 2 x 4 registers).
+template <int NF, bool SPLIT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void kstream_gemm_kernel(KStreamParams p) {
+  constexpr int PLANES = SPLIT ? 2 : 1;
+  constexpr int STAGE = NF * PLANES * 512;        // elements per LDS stage
+  constexpr int CHUNK_SRC = NF * 2 * 512;         // elements per k-step in the packed weights
+  constexpr int WAVE_PIECES = STAGE / (WAVES * 512);
+  static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
+  __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+  const int m0 = blockIdx.x * (WAVES * 32) + wave * 32;
+  const int nks = p.n_ksteps;
+
+  auto stage_chunk = [&](int ks, int stage) {
+    const u16* src = p.wp + (size_t)ks * CHUNK_SRC;
+#pragma unroll
+    for (int u = 0; u < WAVE_PIECES; ++u) {
+      const int piece = wave + WAVES * u;  // stage = [plane][nf] pieces; source = same order (2 planes)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+    }
+  };
+  // A fragments of k-step ks: piece (rb, ks, plane) of the fragment-packed activation, 16 bytes per lane
+  const u16* a_base0 = p.a_fp + ((size_t)(m0 >> 4) * nks * 2) * 512 + lane * 8;
+  const u16* a_base1 = a_base0 + (size_t)nks * 2 * 512;
+  bf16x8 an_hi[2], an_lo[2];
+  auto load_a = [&](int ks) {
+    an_hi[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks * 1024);
+    an_hi[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks * 1024);
+    if (SPLIT) {
+      an_lo[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks * 1024 + 512);
+      an_lo[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks * 1024 + 512);
+    }
+  };
+
+  f32x4 acc[NF][2];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_chunk(0, 0);
+  load_a(0);
+  __syncthreads();
+
+  for (int k0 = 0; k0 < nks; k0 += 2) {
+#pragma unroll
+    for (int cur = 0; cur < 2; ++cur) {
+      const int ks = k0 + cur;
+      if (ks >= nks) break;
+      const int kn = ks + 1 < nks ? ks + 1 : ks;
+      stage_chunk(kn, cur ^ 1);
+      bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        a_hi[mf] = an_hi[mf];
+        a_lo[mf] = an_lo[mf];
+      }
+      load_a(kn);                              // prefetch the next k-step's fragments ...
+      __builtin_amdgcn_sched_barrier(0);       // ... and keep the loads up here, ahead of the MFMAs
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const bf16x8 wh = lds_frag(&sW[cur][nf * 512 + lane * 8]);
+        if (SPLIT) {
+          const bf16x8 wl = lds_frag(&sW[cur][(NF + nf) * 512 + lane * 8]);
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf) {
+            acc[nf][mf] = mfma16(wl, a_hi[mf], acc[nf][mf]);
+            acc[nf][mf] = mfma16(wh, a_lo[mf], acc[nf][mf]);
+          }
+        }
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = mfma16(wh, a_hi[mf], acc[nf][mf]);
+      }
+      __syncthreads();
+    }
+  }
+
+  // x += acc : lane owns features 16nf + 4g + (0..3) of token m0 + 16mf + l15
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    float* xrow = p.x + (size_t)(m0 + mf * 16 + l15) * (NF * 16) + g * 4;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float4* px = reinterpret_cast<float4*>(xrow + nf * 16);
+      float4 r4 = *px;
+      r4.x += acc[nf][mf][0];
+      r4.y += acc[nf][mf][1];
+      r4.z += acc[nf][mf][2];
+      r4.w += acc[nf][mf][3];
+      *px = r4;
+    }
   }
 }
 
