@@ -72,7 +72,7 @@ struct op_handle {
   int H = 0, I = 0, N = 0, nh = 0, V = 0, nl = 0, max_pos = 0;
   bool split = true;
   bool row_path = false;  // hidden <= 256: row-stationary GEMMs with fused LayerNorm
-  int row_waves = 8;      // waves per block of the row-stationary kernels (4 or 8)
+  int row_waves = 4;      // waves per block of the row-stationary kernels (4 or 8)
   int chunk_rows = 0;
   float* emb = nullptr;
   float* emb_norm = nullptr;
@@ -588,9 +588,9 @@ int op_create(const op_config* cfg, op_handle** out) {
   h->nl = cfg->num_labels;
   h->max_pos = cfg->max_position_embeddings;
   h->split = cfg->precision == OP_PRECISION_BF16X3;
-  h->chunk_rows = cfg->chunk_rows > 0 ? align_up(cfg->chunk_rows, ROW_ALIGN) : 32768;
+  h->chunk_rows = cfg->chunk_rows > 0 ? align_up(cfg->chunk_rows, ROW_ALIGN) : 262144;  // grids must cover the chip several times over
   h->layers.resize(N);
-  if (const char* rw = getenv("OPEN_PROVENCE_ROW_WAVES")) h->row_waves = atoi(rw) == 4 ? 4 : 8;
+  if (const char* rw = getenv("OPEN_PROVENCE_ROW_WAVES")) h->row_waves = atoi(rw) == 8 ? 8 : 4;
   h->row_path = (H <= 256) && (H % 32 == 0) && (I % 32 == 0) && getenv("OPEN_PROVENCE_FORCE_TILED") == nullptr;
 
 #define OP_CREATE_TRY(expr)  \
