@@ -316,8 +316,12 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
                      r_pad, ws.row_seq, ws.row_pos, ws.row_tok);
   OP_TRY(L.end());
 
-  // rows >= `rows` are never produced by the attention kernel: keep its output planes finite there
-  {
+  // rows >= `rows` are never produced by the attention kernel: keep its output finite there
+  if (h->row_path) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
+    const size_t tail_off = (size_t)(rows / 16) * (H / 32) * 2 * 512;
+    const size_t tail_bytes = (size_t)((r_pad - rows) / 16) * (H / 32) * 2 * 512 * sizeof(u16);
+    OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
+  } else {
     const size_t tail_off = (size_t)rows * H;
     const size_t tail_bytes = (size_t)(r_pad - rows) * H * sizeof(u16);
     OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
@@ -422,23 +426,40 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       OP_TRY(launch_gemm<EPI_V_T>(L, PK_GEMM_V_T, p, split));
     }
 
-    AttnParams ap;
-    ap.q_hi = ws.q_hi;
-    ap.q_lo = ws.q_lo;
-    ap.k_hi = ws.k_hi;
-    ap.k_lo = ws.k_lo;
-    ap.vt_hi = ws.vt_hi;
-    ap.vt_lo = ws.vt_lo;
-    ap.o_hi = ws.o_hi;
-    ap.o_lo = ws.o_lo;
-    ap.cu = cu_dev;
-    ap.s0 = s0;
-    ap.roff = ws.roff;
-    ap.H = H;
-    ap.r_pad = r_pad;
-    ap.window = is_global ? -1 : h->cfg.local_attention / 2;
     OP_TRY(L.begin(is_global ? PK_ATTN_GLOBAL : PK_ATTN_LOCAL));
-    {
+    if (row_path) {
+      AttnFpParams ap;  // q_hi/q_lo (k, vt, o likewise) are adjacent: together they hold the fragment-packed tensor
+      ap.q_fp = ws.q_hi;
+      ap.k_fp = ws.k_hi;
+      ap.vt_fp = ws.vt_hi;
+      ap.o_fp = ws.o_hi;
+      ap.cu = cu_dev;
+      ap.s0 = s0;
+      ap.roff = ws.roff;
+      ap.H = H;
+      ap.r_pad = r_pad;
+      ap.window = is_global ? -1 : h->cfg.local_attention / 2;
+      const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
+      if (split)
+        hipLaunchKernelGGL((attn_fp_kernel<true>), grid, dim3(256), 0, st, ap);
+      else
+        hipLaunchKernelGGL((attn_fp_kernel<false>), grid, dim3(256), 0, st, ap);
+    } else {
+      AttnParams ap;
+      ap.q_hi = ws.q_hi;
+      ap.q_lo = ws.q_lo;
+      ap.k_hi = ws.k_hi;
+      ap.k_lo = ws.k_lo;
+      ap.vt_hi = ws.vt_hi;
+      ap.vt_lo = ws.vt_lo;
+      ap.o_hi = ws.o_hi;
+      ap.o_lo = ws.o_lo;
+      ap.cu = cu_dev;
+      ap.s0 = s0;
+      ap.roff = ws.roff;
+      ap.H = H;
+      ap.r_pad = r_pad;
+      ap.window = is_global ? -1 : h->cfg.local_attention / 2;
       const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
       if (split)
         hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(256), 0, st, ap);

@@ -27,7 +27,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef uint16_t u16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte staging register (stays in VGPRs)
 
-constexpr int ROW_ALIGN = 16;   // sequence starts are multiples of this many rows
+constexpr int ROW_ALIGN = 32;   // sequence starts are multiples of this many rows (= one wave's row group)
 constexpr int GEMM_BM = 128;    // rows (tokens) per GEMM tile
 constexpr int GEMM_BN = 128;    // output features per GEMM tile
 constexpr int GEMM_BK = 32;     // one 16x16x32 MFMA step
@@ -759,12 +759,14 @@ __device__ __forceinline__ int rowgemm_source_row(int mode, int c, int pr, int H
   const int nf = pr >> 4, i = pr & 15;
   if (mode == RE_QKV) {
     const int per_block = H / ROW_CHUNK;  // chunks in each of q, k, v
-    if (c < 2 * per_block) {              // q or k: fragment 0 = d in [16j, 16j+16), fragment 1 = d + 32
-      const int blk = c / per_block, cc = c % per_block;
-      const int head = cc >> 1, j = cc & 1;
-      return blk * H + head * HEAD_DIM + 16 * j + 32 * nf + i;
-    }
-    return 2 * H + (c - 2 * per_block) * ROW_CHUNK + pr;
+    const int blk = c / per_block, cc = c % per_block;
+    const int head = cc >> 1, j = cc & 1;
+    // q / k: the chunk pair (j = 0, 1) of a head leaves lane slot i = 4g + r with d = 8g + 4j + r (fragment 0)
+    // and its RoPE partner d + 32 (fragment 1): after the pair a lane owns 8 consecutive d of both k-steps.
+    if (blk < 2) return blk * H + head * HEAD_DIM + 32 * nf + 8 * (i >> 2) + 4 * j + (i & 3);
+    // v: fragment nf of chunk j becomes piece n = 2j + nf of the transposed layout, whose row i is
+    // d = 32j + 8(i>>2) + 4nf + (i&3) -- the order that makes the attention output lane-contiguous.
+    return 2 * H + head * HEAD_DIM + 32 * j + 8 * (i >> 2) + 4 * nf + (i & 3);
   }
   if (mode == RE_GEGLU) {  // chunk pair (2t, 2t+1): lane slot i = 4g + r -> h-column 32t + 8g + 4u + r
     const int col = 32 * (c >> 1) + 8 * (i >> 2) + 4 * (c & 1) + (i & 3);
@@ -805,44 +807,33 @@ __device__ __forceinline__ void pack8(const float v[8], bf16x8& hi, bf16x8& lo) 
 }
 
 // One weight chunk (32 output features x K) against this wave's 32 rows: 2 x 2 accumulators, K/32 k-steps of
-// 12 (split) or 4 MFMAs.  The weight fragments of k-step ks+1 are read from LDS BEFORE the MFMAs of k-step ks
-// are issued (register double buffer), so the ds_read latency sits under 12 MFMAs instead of in front of them.
+// 12 (split) or 4 MFMAs.  (hipcc hoists the fragment reads one k-step ahead of their MFMAs by itself; an explicit
+// register double buffer only cost 16 VGPRs.)
 template <int KS, bool SPLIT, bool SWAPPED>
 __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const bf16x8 (&a_hi)[2][KS],
                                                    const bf16x8 (&a_lo)[2][KS], f32x4 (&acc)[2][2]) {
   constexpr int PLANES = SPLIT ? 2 : 1;
-  bf16x8 wh[2][2], wl[2][2];
-#pragma unroll
-  for (int nf = 0; nf < 2; ++nf) {
-    wh[0][nf] = lds_frag(stage_lane + nf * 512);
-    if (SPLIT) wl[0][nf] = lds_frag(stage_lane + 1024 + nf * 512);
-  }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const int b = ks & 1;
-    if (ks + 1 < KS) {
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf) {
-        wh[b ^ 1][nf] = lds_frag(stage_lane + ((ks + 1) * PLANES) * 1024 + nf * 512);
-        if (SPLIT) wl[b ^ 1][nf] = lds_frag(stage_lane + ((ks + 1) * PLANES + 1) * 1024 + nf * 512);
-      }
-    }
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
+      const bf16x8 wh = lds_frag(stage_lane + (ks * PLANES) * 1024 + nf * 512);
+      bf16x8 wl = wh;
+      if (SPLIT) wl = lds_frag(stage_lane + (ks * PLANES + 1) * 1024 + nf * 512);
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
         if (SWAPPED) {  // C rows = features, cols = tokens
           if (SPLIT) {
-            acc[nf][mf] = mfma16(wl[b][nf], a_hi[mf][ks], acc[nf][mf]);
-            acc[nf][mf] = mfma16(wh[b][nf], a_lo[mf][ks], acc[nf][mf]);
+            acc[nf][mf] = mfma16(wl, a_hi[mf][ks], acc[nf][mf]);
+            acc[nf][mf] = mfma16(wh, a_lo[mf][ks], acc[nf][mf]);
           }
-          acc[nf][mf] = mfma16(wh[b][nf], a_hi[mf][ks], acc[nf][mf]);
+          acc[nf][mf] = mfma16(wh, a_hi[mf][ks], acc[nf][mf]);
         } else {  // C rows = tokens, cols = features
           if (SPLIT) {
-            acc[nf][mf] = mfma16(a_hi[mf][ks], wl[b][nf], acc[nf][mf]);
-            acc[nf][mf] = mfma16(a_lo[mf][ks], wh[b][nf], acc[nf][mf]);
+            acc[nf][mf] = mfma16(a_hi[mf][ks], wl, acc[nf][mf]);
+            acc[nf][mf] = mfma16(a_lo[mf][ks], wh, acc[nf][mf]);
           }
-          acc[nf][mf] = mfma16(a_hi[mf][ks], wh[b][nf], acc[nf][mf]);
+          acc[nf][mf] = mfma16(a_hi[mf][ks], wh, acc[nf][mf]);
         }
       }
     }
@@ -892,11 +883,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
     const size_t row = (size_t)(m0 + mf * 16 + l15);
-    if (PRO == RP_PLANES) {
+    if (PRO == RP_PLANES) {  // fragment-packed input: piece (row block, k-step, plane), 16 bytes per lane
+      const u16* base = p.a_hi + (((size_t)((m0 >> 4) + mf) * KS) * 2) * 512 + lane * 8;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        a_hi[mf][ks] = as_frag(*reinterpret_cast<const uint4*>(p.a_hi + row * K + ks * 32 + g * 8));
-        if (SPLIT) a_lo[mf][ks] = as_frag(*reinterpret_cast<const uint4*>(p.a_lo + row * K + ks * 32 + g * 8));
+        a_hi[mf][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)ks * 1024);
+        if (SPLIT) a_lo[mf][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)ks * 1024 + 512);
       }
       // Pin the fragment loads in front of the chunk loop: an empty asm that "rewrites" each register makes
       // the compiler wait for the load HERE; otherwise it sinks the loads next to their first MFMA inside the
@@ -949,32 +941,31 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     }
   }
 
-  // RE_QKV: this lane's two tokens need cos/sin rows [pos][16j + 4g .. +3], j = 0, 1 -- fetched ONCE here (8
-  // float4 registers) instead of two dependent global loads in front of every q/k chunk's stores.
-  f32x4 rope_c[2][2], rope_s[2][2];
+  // RE_QKV: RoPE rows of this lane's two tokens: cos/sin [pos][8g + 4j .. +3] for the half-head j of the chunk
+  // being computed are fetched at the top of each q/k iteration (before the DMA is issued, so the epilogue can
+  // wait for them with a counted vmcnt) and used after its 96 MFMAs.
+  const float* rope_c_row[2];
+  const float* rope_s_row[2];
+  f32x4 rope_c[2], rope_s[2];
   if (EPI == RE_QKV) {
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
       int pos = p.row_pos[m0 + mf * 16 + l15];
       pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        rope_c[mf][j] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)pos * ROPE_HALF + j * 16 + g * 4);
-        rope_s[mf][j] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)pos * ROPE_HALF + j * 16 + g * 4);
-      }
+      rope_c_row[mf] = p.rope_cos + (size_t)pos * ROPE_HALF + g * 8;
+      rope_s_row[mf] = p.rope_sin + (size_t)pos * ROPE_HALF + g * 8;
+      rope_c[mf] = rope_s[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        asm volatile("" : "+v"(rope_c[mf][j]));
-        asm volatile("" : "+v"(rope_s[mf][j]));
-      }
   }
   __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
 
   // ---- stream the weight chunks ---------------------------------------------------------------
   uint2 hold_hi[2], hold_lo[2];  // RE_GEGLU: first half of a chunk pair
+  uint2 qk_hold[2][4];           // RE_QKV: first half-head of a q/k chunk pair: [mf][d<32 hi, lo, d>=32 hi, lo]
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qk_hold[mf][t] = make_uint2(0u, 0u);
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
   // Epilogue of chunk `cc` (compile-time parity PP = cc & 1) from accumulators `av`.  It is issued one iteration
@@ -1021,58 +1012,62 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
           if (SPLIT) *reinterpret_cast<uint4*>(p.o0_hi + off + 512) = make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y);
         }
       }
-    } else {  // RE_QKV
+    } else {  // RE_QKV: fragment-packed q, k (pieces [row/16][H/32][plane]) and v^T (pieces [head][row/32][plane][4])
+      const int per_block = p.hidden / ROW_CHUNK;
       if (sw) {
-        const int per_block = p.hidden / ROW_CHUNK;
         const bool is_q = cc < per_block;
         const int cq = is_q ? cc : cc - per_block;
-        const int col0 = (cq >> 1) * HEAD_DIM + (cq & 1) * 16 + g * 4;  // d = 16j + 4g + r, partner d + 32
-        u16* out_hi = is_q ? p.o0_hi : p.o1_hi;
-        u16* out_lo = is_q ? p.o0_lo : p.o1_lo;
-        const float qscale = is_q ? 0.125f : 1.0f;
+        u16* out = is_q ? p.o0_hi : p.o1_hi;
+        const float qscale = is_q ? 0.125f : 1.0f;  // head_dim^-0.5, exact
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
-          const size_t row = (size_t)(m0 + mf * 16 + l15);
-          // hidden is a multiple of 64, so the number of chunks per q/k block is even and the half-head index
-          // j = cq & 1 equals the chunk parity PP: a compile-time register choice, no dynamic indexing.
-          const f32x4 c4 = rope_c[mf][PP];
-          const f32x4 s4 = rope_s[mf][PP];
-          const float cs[4] = {c4[0], c4[1], c4[2], c4[3]};
-          const float sn[4] = {s4[0], s4[1], s4[2], s4[3]};
+          // half-head index j = cq & 1 equals the chunk parity PP (even number of chunks per block)
+          const f32x4 c4 = rope_c[mf];
+          const f32x4 s4 = rope_s[mf];
           float lo_half[4], hi_half[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float x1 = av[0][mf][r], x2 = av[1][mf][r];
-            lo_half[r] = (x1 * cs[r] - x2 * sn[r]) * qscale;
-            hi_half[r] = (x2 * cs[r] + x1 * sn[r]) * qscale;
+            lo_half[r] = (x1 * c4[r] - x2 * s4[r]) * qscale;
+            hi_half[r] = (x2 * c4[r] + x1 * s4[r]) * qscale;
           }
-          uint2 h2, l2;
-          const size_t off = row * p.ld_out + col0;
-          split4<SPLIT>(lo_half, h2, l2);
-          *reinterpret_cast<uint2*>(out_hi + off) = h2;
-          if (SPLIT) *reinterpret_cast<uint2*>(out_lo + off) = l2;
-          split4<SPLIT>(hi_half, h2, l2);
-          *reinterpret_cast<uint2*>(out_hi + off + 32) = h2;
-          if (SPLIT) *reinterpret_cast<uint2*>(out_lo + off + 32) = l2;
+          uint2 h0, l0, h1, l1;
+          split4<SPLIT>(lo_half, h0, l0);
+          split4<SPLIT>(hi_half, h1, l1);
+          if (PP == 0) {
+            qk_hold[mf][0] = h0; qk_hold[mf][1] = l0; qk_hold[mf][2] = h1; qk_hold[mf][3] = l1;
+          } else {
+            const size_t rb = (size_t)((m0 >> 4) + mf);
+            const size_t kb = (size_t)(cq >> 1) * 2;  // k-step of d in [0, 32); d + 32 is the next one
+            const size_t off = ((rb * (size_t)(p.hidden >> 5) + kb) * 2) * 512 + lane * 8;
+            *reinterpret_cast<uint4*>(out + off) = make_uint4(qk_hold[mf][0].x, qk_hold[mf][0].y, h0.x, h0.y);
+            *reinterpret_cast<uint4*>(out + off + 1024) = make_uint4(qk_hold[mf][2].x, qk_hold[mf][2].y, h1.x, h1.y);
+            if (SPLIT) {
+              *reinterpret_cast<uint4*>(out + off + 512) = make_uint4(qk_hold[mf][1].x, qk_hold[mf][1].y, l0.x, l0.y);
+              *reinterpret_cast<uint4*>(out + off + 1536) = make_uint4(qk_hold[mf][3].x, qk_hold[mf][3].y, l1.x, l1.y);
+            }
+          }
         }
       } else {
+        // C rows = tokens 4g + r of block mf, column = feature slot l15: the two row blocks of this wave's
+        // 32-row group are the two halves of the 8 key slots of one v^T fragment lane.
         const int cv = cc - p.n_swapped;
+        const size_t head = (size_t)(cv >> 1);
+        const size_t tb = (size_t)(m0 >> 5);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
-          const size_t f = (size_t)(cv * ROW_CHUNK + nf * 16 + l15);
-#pragma unroll
-          for (int mf = 0; mf < 2; ++mf) {
-            const float v[4] = {av[nf][mf][0], av[nf][mf][1], av[nf][mf][2], av[nf][mf][3]};
-            uint2 h2, l2;
-            split4<SPLIT>(v, h2, l2);
-            const size_t off = f * p.r_pad + m0 + mf * 16 + g * 4;
-            *reinterpret_cast<uint2*>(p.o2_hi + off) = h2;
-            if (SPLIT) *reinterpret_cast<uint2*>(p.o2_lo + off) = l2;
-          }
+          const float v0[4] = {av[nf][0][0], av[nf][0][1], av[nf][0][2], av[nf][0][3]};
+          const float v1[4] = {av[nf][1][0], av[nf][1][1], av[nf][1][2], av[nf][1][3]};
+          uint2 h0, l0, h1, l1;
+          split4<SPLIT>(v0, h0, l0);
+          split4<SPLIT>(v1, h1, l1);
+          const size_t n = (size_t)((cv & 1) * 2 + nf);
+          const size_t off = (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + n) * 512 + lane * 8;
+          *reinterpret_cast<uint4*>(p.o2_hi + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+          if (SPLIT) *reinterpret_cast<uint4*>(p.o2_hi + off + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
       }
     }
-
   };
 
   f32x4 acc_prev[2][2];
@@ -1084,13 +1079,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   // Unrolled by two so that the LDS stage index is a compile-time constant in each copy: the compiler can
   // then tell the DMA into stage cur^1 from the fragment reads of stage cur and does NOT drain the DMA
   // (s_waitcnt vmcnt(0)) before the first ds_read -- the wait sits only in front of the barrier.
+  // The q/k/v variant needs its registers for the RoPE rows and the half-head hold, so it runs each chunk's
+  // epilogue right away; the other variants defer it by one iteration (see above).
+  constexpr bool LATE = (EPI != RE_QKV);
   auto iteration = [&](int c, auto cur_tag) {
     constexpr int cur = decltype(cur_tag)::value;
     // every wave passed the barrier that ended iteration c-1, so nobody reads stage cur^1 any more.
     // Unconditional (the last iteration harmlessly re-copies its own chunk into the idle stage): a DMA issued
     // under a branch makes the compiler drain it at the join, in front of the first fragment read.
+    if (EPI == RE_QKV) {  // RoPE rows for this chunk's half-head (j = cur); harmless extra loads on v chunks
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        rope_c[mf] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + cur * 4);
+        rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + cur * 4);
+      }
+    }
     if (!(p.debug_flags & 2)) stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
-    if (c > 0) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, acc_prev);
+    if (EPI == RE_QKV) __builtin_amdgcn_sched_barrier(0);  // keep those loads up here, ahead of the MFMAs
+    if (LATE && c > 0) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, acc_prev);
 
     const bool swapped = (EPI != RE_QKV) || (c < p.n_swapped);
     f32x4 acc[2][2];
@@ -1105,10 +1111,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     } else {
       rowgemm_chunk_mfma<KS, SPLIT, false>(&sW[cur][lane * 8], a_hi, a_lo, acc);
     }
+    if (LATE) {
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
+      for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) acc_prev[nf][mf] = acc[nf][mf];
+        for (int mf = 0; mf < 2; ++mf) acc_prev[nf][mf] = acc[nf][mf];
+    } else {
+      epilogue(c, cur_tag, acc);
+    }
     __syncthreads();
   };
   for (int c0 = 0; c0 < p.n_chunks; c0 += 2) {  // even chunk count (checked on the host)
@@ -1116,7 +1126,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     iteration(c0 + 1, std::integral_constant<int, 1>{});
   }
   // the host guarantees an even number of chunks, so the last chunk has parity 1
-  epilogue(p.n_chunks - 1, std::integral_constant<int, 1>{}, acc_prev);
+  if (LATE) epilogue(p.n_chunks - 1, std::integral_constant<int, 1>{}, acc_prev);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1381,20 +1391,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 
     // element (m, r) of this lane: key = kbase + 32*(m>>1) + 8*g + 4*(m&1) + r
-    float tile_max = -1e30f;
-    bool valid[4][4];
+    // masked scores become -3e30 (below the running-max initial value -1e30): exp(masked - max) underflows to
+    // exactly 0 even when a whole tile is masked for this query; branch-free (selects only).
+    const int win = p.window >= 0 ? p.window : (1 << 30);
+    float tile_max = -3e30f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kbase + 32 * (m >> 1) + 8 * g + 4 * (m & 1) + r;
-        bool ok = key < len;
-        if (p.window >= 0) {
-          const int d = key - qpos;
-          ok = ok && (d <= p.window) && (d >= -p.window);
-        }
-        valid[m][r] = ok;
-        if (ok) tile_max = fmaxf(tile_max, sacc[m][r]);
+        const int d = key - qpos;
+        const bool ok = (key < len) & (d <= win) & (d >= -win);
+        sacc[m][r] = ok ? sacc[m][r] : -3e30f;
+        tile_max = fmaxf(tile_max, sacc[m][r]);
       }
     }
     tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 16, 64));
@@ -1408,7 +1417,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = valid[m][r] ? __expf(sacc[m][r] - m_new) : 0.f;
+        const float e = __expf(sacc[m][r] - m_new);
         pv[m][r] = e;
         psum += e;
       }
@@ -1459,6 +1468,222 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
       const size_t off = qrow * H + hcol + n * 16 + g * 4;
       *reinterpret_cast<uint2*>(p.o_hi + off) = h2;
       if (SPLIT) *reinterpret_cast<uint2*>(p.o_lo + off) = l2;
+    }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------------
+// Attention on fragment-packed q / k / v^T (row-stationary path).  Same algorithm as attn_kernel above
+// (transposed scores, lane-local online softmax, O^T = V^T P^T) but every byte moves as 1 KiB pieces:
+//   * Q fragments: one coalesced 16-byte-per-lane load per (k-step, plane), straight into registers;
+//   * K / V^T tiles: 32 pieces per 64-key tile (16 KiB hi + 16 KiB lo) copied global -> LDS by DMA
+//     (global_load_lds), double-buffered, fragment reads lane-linear and conflict-free;
+//   * output: the v^T piece order was chosen at QKV time so that a lane ends up with 8 consecutive head
+//     dims -> two 16-byte stores per plane per lane, whole 1 KiB pieces of the fragment-packed o.
+// Sequences start at multiples of 32 rows, so key tiles coincide with whole pieces.
+// ----------------------------------------------------------------------------------------------
+struct AttnFpParams {
+  const u16* q_fp;   // [rows/16][H/32][2][512]
+  const u16* k_fp;
+  const u16* vt_fp;  // [heads][rows/32][2][4][512]
+  u16* o_fp;         // [rows/16][H/32][2][512]
+  const int32_t* cu;
+  int s0;
+  const int32_t* roff;
+  int H;
+  int r_pad;
+  int window;
+};
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
+  constexpr int PLANES = SPLIT ? 2 : 1;
+  constexpr int K_PIECES = 8 * PLANES;              // [m 0..3][ks 0..1][plane]
+  constexpr int V_PIECES = 8 * PLANES;              // [t 0..1][plane][n 0..3]
+  constexpr int STAGE = (K_PIECES + V_PIECES) * 512;
+  __shared__ __attribute__((aligned(16))) u16 sT[2][STAGE];
+
+  const int s = blockIdx.z;
+  const int head = blockIdx.y;
+  const int q0 = blockIdx.x * ATT_BQ;
+  const int len = p.cu[p.s0 + s + 1] - p.cu[p.s0 + s];
+  if (q0 >= len) return;
+  const int r0 = p.roff[s];
+  const int alloc = p.roff[s + 1] - r0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+  const int kbn = p.H >> 5;  // k-steps per row block
+
+  const int qbase = q0 + wave * 16;
+  const bool active = qbase < alloc;  // alloc is a multiple of 32
+  const int qpos = qbase + l15;
+  const size_t q_rb = (size_t)((r0 + (active ? qbase : q0)) >> 4);
+
+  bf16x8 qf_hi[2], qf_lo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const u16* src = p.q_fp + ((q_rb * kbn + head * 2 + ks) * 2) * 512 + lane * 8;
+    qf_hi[ks] = *reinterpret_cast<const bf16x8*>(src);
+    if (SPLIT) qf_lo[ks] = *reinterpret_cast<const bf16x8*>(src + 512);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {  // retire the loads before the tile loop (see rowgemm_kernel)
+    asm volatile("" : "+v"(qf_hi[ks]));
+    if (SPLIT) asm volatile("" : "+v"(qf_lo[ks]));
+  }
+
+  int kt_lo = 0, kt_hi = (len - 1) / ATT_BK;
+  if (p.window >= 0) {
+    const int lo_key = q0 - p.window;
+    kt_lo = lo_key > 0 ? lo_key / ATT_BK : 0;
+    const int hi_t = (q0 + ATT_BQ - 1 + p.window) / ATT_BK;
+    kt_hi = hi_t < kt_hi ? hi_t : kt_hi;
+  }
+
+  // DMA one key tile: wave w copies pieces w, w+4, ... of the stage [K: m, ks, plane | V: t, plane, n]
+  auto stage_tile = [&](int kt, int stage) {
+    const size_t k_rb0 = (size_t)((r0 + kt * ATT_BK) >> 4);
+    const size_t v_tb0 = (size_t)((r0 + kt * ATT_BK) >> 5);
+#pragma unroll
+    for (int u = 0; u < (K_PIECES + V_PIECES) / 4; ++u) {
+      const int piece = wave + 4 * u;  // wave-uniform
+      const u16* src;
+      if (piece < K_PIECES) {
+        const int m = piece / (2 * PLANES), rem = piece % (2 * PLANES);
+        const int ks = rem / PLANES, plane = rem % PLANES;
+        src = p.k_fp + (((k_rb0 + m) * kbn + head * 2 + ks) * 2 + plane) * 512;
+      } else {
+        const int pv = piece - K_PIECES;
+        const int t = pv / (4 * PLANES), rem = pv % (4 * PLANES);
+        const int plane = rem / 4, n = rem % 4;
+        src = p.vt_fp + ((((size_t)head * (p.r_pad >> 5) + v_tb0 + t) * 2 + plane) * 4 + n) * 512;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(&sT[stage][piece * 512]), 16, 0, 0);
+    }
+  };
+
+  float m_run = -1e30f;
+  float l_run = 0.f;
+  f32x4 oacc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) oacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto tile = [&](int kt, auto cur_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
+    stage_tile(kt + 1 <= kt_hi ? kt + 1 : kt, cur ^ 1);  // unconditional prefetch into the idle stage
+    const u16* st = &sT[cur][lane * 8];
+    const int kbase = kt * ATT_BK;
+
+    f32x4 sacc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) sacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const bf16x8 kh = lds_frag(st + ((m * 2 + ks) * PLANES) * 512);
+        if (SPLIT) {
+          const bf16x8 kl = lds_frag(st + ((m * 2 + ks) * PLANES + 1) * 512);
+          sacc[m] = mfma16(kl, qf_hi[ks], sacc[m]);
+          sacc[m] = mfma16(kh, qf_lo[ks], sacc[m]);
+        }
+        sacc[m] = mfma16(kh, qf_hi[ks], sacc[m]);
+      }
+    }
+
+    // element (m, r) of this lane: key = kbase + 16m + 4g + r (natural order inside a 16-row piece)
+    // masked scores become -3e30 (below the running-max initial value -1e30): exp(masked - max) underflows to
+    // exactly 0 even when a whole tile is masked for this query; branch-free (selects only).
+    const int win = p.window >= 0 ? p.window : (1 << 30);
+    float tile_max = -3e30f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kbase + 16 * m + 4 * g + r;
+        const int d = key - qpos;
+        const bool ok = (key < len) & (d <= win) & (d >= -win);
+        sacc[m][r] = ok ? sacc[m][r] : -3e30f;
+        tile_max = fmaxf(tile_max, sacc[m][r]);
+      }
+    }
+    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 16, 64));
+    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
+    const float m_new = fmaxf(m_run, tile_max);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    float pv[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(sacc[m][r] - m_new);
+        pv[m][r] = e;
+        psum += e;
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      oacc[n][0] *= alpha;
+      oacc[n][1] *= alpha;
+      oacc[n][2] *= alpha;
+      oacc[n][3] *= alpha;
+    }
+
+    // O^T += V^T P^T: k-step t covers keys 32t..32t+31; lane slot e < 4 -> key 32t + 4g + e (piece m = 2t),
+    // e >= 4 -> key 32t + 16 + 4g + (e-4) (piece m = 2t+1): the order the QKV epilogue stored v^T in.
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint2 h0, l0, h1, l1;
+      split4<SPLIT>(pv[2 * t], h0, l0);
+      split4<SPLIT>(pv[2 * t + 1], h1, l1);
+      const bf16x8 ph = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
+      const bf16x8 pl = as_frag(make_uint4(l0.x, l0.y, l1.x, l1.y));
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const bf16x8 vh = lds_frag(st + (K_PIECES + (t * PLANES) * 4 + n) * 512);
+        if (SPLIT) {
+          const bf16x8 vl = lds_frag(st + (K_PIECES + (t * PLANES + 1) * 4 + n) * 512);
+          oacc[n] = mfma16(vl, ph, oacc[n]);
+          oacc[n] = mfma16(vh, pl, oacc[n]);
+        }
+        oacc[n] = mfma16(vh, ph, oacc[n]);
+      }
+    }
+    __syncthreads();
+  };
+
+  stage_tile(kt_lo, 0);
+  __syncthreads();
+  for (int kt = kt_lo; kt <= kt_hi; kt += 2) {
+    tile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 <= kt_hi) tile(kt + 1, std::integral_constant<int, 1>{});
+  }
+
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (active) {
+    // oacc[n][r]: d = 32(n>>1) + 8g + 4(n&1) + r  ->  lane owns d = 8g..8g+7 of k-step (n>>1) of this head
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float v0[4] = {oacc[2 * half][0] * inv, oacc[2 * half][1] * inv, oacc[2 * half][2] * inv, oacc[2 * half][3] * inv};
+      const float v1[4] = {oacc[2 * half + 1][0] * inv, oacc[2 * half + 1][1] * inv, oacc[2 * half + 1][2] * inv,
+                           oacc[2 * half + 1][3] * inv};
+      uint2 h0, l0, h1, l1;
+      split4<SPLIT>(v0, h0, l0);
+      split4<SPLIT>(v1, h1, l1);
+      u16* dst = p.o_fp + ((q_rb * kbn + head * 2 + half) * 2) * 512 + lane * 8;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+      if (SPLIT) *reinterpret_cast<uint4*>(dst + 512) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
   }
 }
