@@ -186,6 +186,9 @@ def main() -> None:
         "gemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
         "gemm_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,
         "gemm_mlp_out": 2.0 * total_tokens * I * H * n_layers,
+        "fused_attnout_ln_wi_geglu": 2.0 * total_tokens * (H * H + H * 2 * I) * n_layers,
+        "fused_mlpout_ln_qkv_rope": 2.0 * total_tokens * (I * H + H * 3 * H) * (n_layers - 1),
+        "kstream_mlp_out": 2.0 * total_tokens * I * H,
         "rowgemm_ln_qkv_rope": 2.0 * total_tokens * H * 3 * H * n_layers,
         "rowgemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
         "rowgemm_ln_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,

@@ -40,13 +40,15 @@ enum ProfileKind {
   PK_ROW_ATTN_OUT,
   PK_ROW_WI_GEGLU,
   PK_KSTREAM_MLP_OUT,
+  PK_FUSED_ATTN_OUT_WI,
+  PK_FUSED_MLP_OUT_QKV,
   PK_COUNT
 };
 const char* kProfileNames[PK_COUNT] = {"rowmap",        "embed_ln",      "layer_norm",    "gemm_qk_rope", "gemm_v_t",
                                        "attn_global",   "attn_local",    "gemm_attn_out", "gemm_wi_geglu",
                                        "gemm_mlp_out",  "final_ln_prune", "rank_head",    "capture",
                                        "rowgemm_ln_qkv_rope", "rowgemm_attn_out", "rowgemm_ln_wi_geglu",
-                                       "kstream_mlp_out"};
+                                       "kstream_mlp_out", "fused_attnout_ln_wi_geglu", "fused_mlpout_ln_qkv_rope"};
 
 struct LayerWeights {
   float* attn_norm = nullptr;  // absent on layer 0
@@ -57,7 +59,8 @@ struct LayerWeights {
   u16 *wo2_hi = nullptr, *wo2_lo = nullptr;
   // row-stationary layouts (hidden <= 256): chunk-major, fragment-ordered, hi/lo planes interleaved per k-step
   u16 *wqkv_pk = nullptr, *wo_pk = nullptr, *wi_pk = nullptr;
-  u16* wo2_pk = nullptr;  // k-streamed layout for the MLP output projection
+  u16* wo2_pk = nullptr;  // k-streamed layouts (output features permuted): MLP output projection ...
+  u16* wo_ks = nullptr;   // ... and attention output projection (fused kernels)
 };
 
 struct ProfileEvent {
@@ -72,7 +75,6 @@ struct op_handle {
   int H = 0, I = 0, N = 0, nh = 0, V = 0, nl = 0, max_pos = 0;
   bool split = true;
   bool row_path = false;  // hidden <= 256: row-stationary GEMMs with fused LayerNorm
-  int row_waves = 4;      // waves per block of the row-stationary kernels (4 or 8)
   int chunk_rows = 0;
   float* emb = nullptr;
   float* emb_norm = nullptr;
@@ -259,21 +261,18 @@ int launch_gemm(Launcher& L, int kind, const GemmParams& p, bool split) {
 template <int EPI, int PRO>
 int launch_rowgemm(Launcher& L, int kind, const RowGemmParams& p, int hidden, int r_pad, bool split) {
   OP_TRY(L.begin(kind));
-  const int waves = L.h->row_waves;
-  const dim3 grid((unsigned)(r_pad / (waves * 32)));
-  const dim3 block((unsigned)(waves * 64));
+  const dim3 grid((unsigned)(r_pad / ROW_BM));
+  const dim3 block(256);
   const int ks = hidden / 32;
-#define OPK_ROW_LAUNCH(KS_, W_)                                                                       \
+#define OPK_ROW_LAUNCH(KS_)                                                                           \
   do {                                                                                                \
     if (split)                                                                                        \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, W_>), grid, block, 0, L.stream, p);     \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, 4>), grid, block, 0, L.stream, p);      \
     else                                                                                              \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, W_>), grid, block, 0, L.stream, p);    \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, 4>), grid, block, 0, L.stream, p);     \
   } while (0)
-  if (ks == 4 && waves == 4) OPK_ROW_LAUNCH(4, 4);
-  else if (ks == 4) OPK_ROW_LAUNCH(4, 8);
-  else if (ks == 8 && waves == 4) OPK_ROW_LAUNCH(8, 4);
-  else if (ks == 8) OPK_ROW_LAUNCH(8, 8);
+  if (ks == 4) OPK_ROW_LAUNCH(4);
+  else if (ks == 8) OPK_ROW_LAUNCH(8);
   else return fail(L.h, OP_ERR_UNSUPPORTED, "row-stationary GEMM supports hidden 128 or 256, got %d", hidden);
 #undef OPK_ROW_LAUNCH
   return L.end();
@@ -281,21 +280,18 @@ int launch_rowgemm(Launcher& L, int kind, const RowGemmParams& p, int hidden, in
 
 int launch_kstream(Launcher& L, int kind, const KStreamParams& p, int hidden, int r_pad, bool split) {
   OP_TRY(L.begin(kind));
-  const int waves = L.h->row_waves;
-  const dim3 grid((unsigned)(r_pad / (waves * 32)));
-  const dim3 block((unsigned)(waves * 64));
+  const dim3 grid((unsigned)(r_pad / ROW_BM));
+  const dim3 block(256);
   const int nf = hidden / 16;
-#define OPK_KS_LAUNCH(NF_, W_)                                                                     \
-  do {                                                                                             \
-    if (split)                                                                                     \
-      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, true, W_>), grid, block, 0, L.stream, p);       \
-    else                                                                                           \
-      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, false, W_>), grid, block, 0, L.stream, p);      \
+#define OPK_KS_LAUNCH(NF_)                                                                        \
+  do {                                                                                            \
+    if (split)                                                                                    \
+      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, true, 4>), grid, block, 0, L.stream, p);       \
+    else                                                                                          \
+      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, false, 4>), grid, block, 0, L.stream, p);      \
   } while (0)
-  if (nf == 8 && waves == 4) OPK_KS_LAUNCH(8, 4);
-  else if (nf == 8) OPK_KS_LAUNCH(8, 8);
-  else if (nf == 16 && waves == 4) OPK_KS_LAUNCH(16, 4);
-  else if (nf == 16) OPK_KS_LAUNCH(16, 8);
+  if (nf == 8) OPK_KS_LAUNCH(8);
+  else if (nf == 16) OPK_KS_LAUNCH(16);
   else return fail(L.h, OP_ERR_UNSUPPORTED, "k-streamed GEMM supports hidden 128 or 256, got %d", hidden);
 #undef OPK_KS_LAUNCH
   return L.end();
@@ -304,7 +300,10 @@ int launch_kstream(Launcher& L, int kind, const KStreamParams& p, int hidden, in
 int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t* ids_dev, const int32_t* cu_dev, int s0,
                   int ns, int rows, int max_len, int total_tokens, float* prune_out, float* rank_out) {
   const int H = h->H, I = h->I;
-  const int r_pad = align_up(rows + 64, 256);  // multiple of the largest row block (8 waves x 32 rows)
+  // Row path: exactly the computed rows, rounded to the 128-row block -- no slack rows: a 131072-row batch is 1024
+  // blocks = two full rounds of 2 blocks per CU; two extra (empty) blocks would cost a third round.  The tiled path
+  // keeps 64 slack rows for its attention kernel's tile over-read.
+  const int r_pad = h->row_path ? align_up(rows, ROW_BM) : align_up(rows + 64, 256);
   const int m_tiles = r_pad / GEMM_BM;
   const unsigned row_blocks = (unsigned)((r_pad + 3) / 4);
   const bool split = h->split;
@@ -357,77 +356,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
 
   const int q_tiles = (max_len + ATT_BQ - 1) / ATT_BQ;
 
-  for (int li = 0; li < h->N; ++li) {
-    const LayerWeights& lw = h->layers[li];
-    const bool is_global = h->cfg.layer_is_global[li] != 0;
-    OP_TRY(capture(li));
-    const bool row_path = h->row_path;
-    RowGemmParams rp;
-    memset(&rp, 0, sizeof(rp));
-    rp.eps = h->cfg.norm_eps;
-    rp.hidden = H;
-    rp.r_pad = r_pad;
-    rp.row_pos = ws.row_pos;
-    rp.rope_cos = h->rope_cos[is_global ? 1 : 0];
-    rp.rope_sin = h->rope_sin[is_global ? 1 : 0];
-    rp.max_pos = h->max_pos;
-    {
-      const char* dbg = getenv("OPEN_PROVENCE_DEBUG_FLAGS");
-      rp.debug_flags = dbg ? atoi(dbg) : 0;
-    }
-    if (row_path) {
-      // q, k, v^T = RoPE / transpose of LN(x) Wqkv^T, LayerNorm fused into the prologue
-      rp.x_in = ws.x;
-      rp.ln_w = lw.attn_norm;
-      rp.wp = lw.wqkv_pk;
-      rp.n_chunks = 3 * H / ROW_CHUNK;
-      rp.n_swapped = 2 * H / ROW_CHUNK;
-      rp.o0_hi = ws.q_hi; rp.o0_lo = ws.q_lo;
-      rp.o1_hi = ws.k_hi; rp.o1_lo = ws.k_lo;
-      rp.o2_hi = ws.vt_hi; rp.o2_lo = ws.vt_lo;
-      rp.ld_out = H;
-      if (li == 0)
-        OP_TRY((launch_rowgemm<RE_QKV, RP_SPLIT>(L, PK_ROW_QKV, rp, H, r_pad, split)));
-      else
-        OP_TRY((launch_rowgemm<RE_QKV, RP_LN>(L, PK_ROW_QKV, rp, H, r_pad, split)));
-    }
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    if (!row_path) {
-    if (li != 0) OP_TRY(layer_norm(lw.attn_norm));
+  const int dbg_flags = getenv("OPEN_PROVENCE_DEBUG_FLAGS") ? atoi(getenv("OPEN_PROVENCE_DEBUG_FLAGS")) : 0;
+  const bool fuse = getenv("OPEN_PROVENCE_NO_FUSE") == nullptr;
 
-      p.a_hi = ws.ln_hi;
-      p.a_lo = ws.ln_lo;
-      p.K = H;
-      p.m_tiles = m_tiles;
-      p.hidden = H;
-      p.row_pos = ws.row_pos;
-      p.rope_cos = h->rope_cos[is_global ? 1 : 0];
-      p.rope_sin = h->rope_sin[is_global ? 1 : 0];
-      p.max_pos = h->max_pos;
-
-      // q, k = RoPE(x Wq^T), RoPE(x Wk^T)
-      p.w_hi = lw.wqkv_hi;
-      p.w_lo = lw.wqkv_lo;
-      p.n_tiles = 2 * H / GEMM_BN;
-      p.o0_hi = ws.q_hi;
-      p.o0_lo = ws.q_lo;
-      p.o1_hi = ws.k_hi;
-      p.o1_lo = ws.k_lo;
-      p.ld_out = H;
-      OP_TRY(launch_gemm<EPI_QK_ROPE>(L, PK_GEMM_QK_ROPE, p, split));
-      // v^T
-      p.w_hi = lw.wqkv_hi + (size_t)2 * H * H;
-      p.w_lo = lw.wqkv_lo + (size_t)2 * H * H;
-      p.n_tiles = H / GEMM_BN;
-      p.o0_hi = ws.vt_hi;
-      p.o0_lo = ws.vt_lo;
-      p.ld_out = r_pad;
-      OP_TRY(launch_gemm<EPI_V_T>(L, PK_GEMM_V_T, p, split));
-    }
-
+  auto attention = [&](bool is_global) -> int {
     OP_TRY(L.begin(is_global ? PK_ATTN_GLOBAL : PK_ATTN_LOCAL));
-    if (row_path) {
+    const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
+    const int window = is_global ? -1 : h->cfg.local_attention / 2;
+    if (h->row_path) {
       AttnFpParams ap;  // q_hi/q_lo (k, vt, o likewise) are adjacent: together they hold the fragment-packed tensor
       ap.q_fp = ws.q_hi;
       ap.k_fp = ws.k_hi;
@@ -438,8 +374,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.roff = ws.roff;
       ap.H = H;
       ap.r_pad = r_pad;
-      ap.window = is_global ? -1 : h->cfg.local_attention / 2;
-      const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
+      ap.window = window;
       if (split)
         hipLaunchKernelGGL((attn_fp_kernel<true>), grid, dim3(256), 0, st, ap);
       else
@@ -459,77 +394,175 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.roff = ws.roff;
       ap.H = H;
       ap.r_pad = r_pad;
-      ap.window = is_global ? -1 : h->cfg.local_attention / 2;
-      const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
+      ap.window = window;
       if (split)
         hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(256), 0, st, ap);
       else
         hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(256), 0, st, ap);
     }
-    OP_TRY(L.end());
+    return L.end();
+  };
 
-    if (row_path) {
-      // x += attn Wo^T
-      rp.a_hi = ws.o_hi; rp.a_lo = ws.o_lo;
-      rp.wp = lw.wo_pk;
-      rp.n_chunks = H / ROW_CHUNK;
-      rp.x = ws.x;
-      rp.ld_out = H;
-      OP_TRY((launch_rowgemm<RE_RESIDUAL, RP_PLANES>(L, PK_ROW_ATTN_OUT, rp, H, r_pad, split)));
-      // h = gelu(a) * g, (a, g) = LN(x) Wi^T, LayerNorm fused
-      rp.x_in = ws.x;
+  // parameters of a q/k/v projection of layer `li` (row-stationary kernels)
+  auto qkv_params = [&](int li) {
+    const LayerWeights& lw = h->layers[li];
+    const bool is_global = h->cfg.layer_is_global[li] != 0;
+    RowGemmParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.eps = h->cfg.norm_eps;
+    rp.hidden = H;
+    rp.r_pad = r_pad;
+    rp.row_pos = ws.row_pos;
+    rp.rope_cos = h->rope_cos[is_global ? 1 : 0];
+    rp.rope_sin = h->rope_sin[is_global ? 1 : 0];
+    rp.max_pos = h->max_pos;
+    rp.debug_flags = dbg_flags;
+    rp.x_in = ws.x;
+    rp.ln_w = lw.attn_norm;
+    rp.wp = lw.wqkv_pk;
+    rp.n_chunks = 3 * H / ROW_CHUNK;
+    rp.n_swapped = 2 * H / ROW_CHUNK;
+    rp.o0_hi = ws.q_hi;
+    rp.o1_hi = ws.k_hi;
+    rp.o2_hi = ws.vt_hi;
+    rp.ld_out = H;
+    return rp;
+  };
+
+  for (int li = 0; li < h->N; ++li) {
+    const LayerWeights& lw = h->layers[li];
+    const bool is_global = h->cfg.layer_is_global[li] != 0;
+    OP_TRY(capture(li));
+
+    if (h->row_path) {
+      // ---- row-stationary path (hidden <= 256) --------------------------------------------------------
+      if (li == 0) {  // layer 0 has no attn_norm: split x0 directly
+        RowGemmParams rp = qkv_params(0);
+        OP_TRY((launch_rowgemm<RE_QKV, RP_SPLIT>(L, PK_ROW_QKV, rp, H, r_pad, split)));
+      } else if (!fuse) {
+        RowGemmParams rp = qkv_params(li);
+        OP_TRY((launch_rowgemm<RE_QKV, RP_LN>(L, PK_ROW_QKV, rp, H, r_pad, split)));
+      }  // else: q/k/v of this layer were produced by the fused kernel that closed layer li-1
+      OP_TRY(attention(is_global));
+
+      RowGemmParams rp;
+      memset(&rp, 0, sizeof(rp));
+      rp.eps = h->cfg.norm_eps;
+      rp.hidden = H;
+      rp.r_pad = r_pad;
+      rp.debug_flags = dbg_flags;
       rp.ln_w = lw.mlp_norm;
       rp.wp = lw.wi_pk;
       rp.n_chunks = 2 * I / ROW_CHUNK;
-      rp.o0_hi = ws.h_hi; rp.o0_lo = ws.h_lo;
+      rp.o0_hi = ws.h_hi;  // fragment-packed h (h_hi + h_lo are one buffer)
       rp.ld_out = I;
-      OP_TRY((launch_rowgemm<RE_GEGLU, RP_LN>(L, PK_ROW_WI_GEGLU, rp, H, r_pad, split)));
-      p.m_tiles = m_tiles;
-      p.hidden = H;
-    } else {
-    // x += attn Wo^T
-      p.a_hi = ws.o_hi;
-      p.a_lo = ws.o_lo;
-      p.w_hi = lw.wo_hi;
-      p.w_lo = lw.wo_lo;
-      p.K = H;
-      p.n_tiles = H / GEMM_BN;
-      p.x = ws.x;
-      p.ld_out = H;
-      OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_ATTN_OUT, p, split));
+      if (fuse) {
+        // x += o Wo^T ; h = GeGLU(LN(x) Wi^T)   -- one kernel, the hidden state stays in registers in between
+        rp.a1_fp = ws.o_hi;
+        rp.w1p = lw.wo_ks;
+        rp.k1_steps = H / 32;
+        rp.x_io = ws.x;
+        OP_TRY((launch_rowgemm<RE_GEGLU, RP_KSTREAM>(L, PK_FUSED_ATTN_OUT_WI, rp, H, r_pad, split)));
+      } else {
+        RowGemmParams ro;
+        memset(&ro, 0, sizeof(ro));
+        ro.hidden = H;
+        ro.r_pad = r_pad;
+        ro.debug_flags = dbg_flags;
+        ro.a_hi = ws.o_hi;
+        ro.wp = lw.wo_pk;
+        ro.n_chunks = H / ROW_CHUNK;
+        ro.x = ws.x;
+        ro.ld_out = H;
+        OP_TRY((launch_rowgemm<RE_RESIDUAL, RP_PLANES>(L, PK_ROW_ATTN_OUT, ro, H, r_pad, split)));
+        rp.x_in = ws.x;
+        OP_TRY((launch_rowgemm<RE_GEGLU, RP_LN>(L, PK_ROW_WI_GEGLU, rp, H, r_pad, split)));
+      }
 
-      // x += (gelu(a) * g) Wo^T,  (a, g) = LN(x) Wi^T
-      OP_TRY(layer_norm(lw.mlp_norm));
-      p.a_hi = ws.ln_hi;
-      p.a_lo = ws.ln_lo;
-      p.w_hi = lw.wi_hi;
-      p.w_lo = lw.wi_lo;
-      p.K = H;
-      p.n_tiles = 2 * I / GEMM_BN;
-      p.o0_hi = ws.h_hi;
-      p.o0_lo = ws.h_lo;
-      p.ld_out = I;
-      OP_TRY(launch_gemm<EPI_GEGLU>(L, PK_GEMM_WI_GEGLU, p, split));
+      if (fuse && li + 1 < h->N) {
+        // x += h Wo^T ; q, k, v^T of the NEXT layer = RoPE / transpose of LN(x) Wqkv^T
+        RowGemmParams rq = qkv_params(li + 1);
+        rq.a1_fp = ws.h_hi;
+        rq.w1p = lw.wo2_pk;
+        rq.k1_steps = I / 32;
+        rq.x_io = ws.x;
+        OP_TRY((launch_rowgemm<RE_QKV, RP_KSTREAM>(L, PK_FUSED_MLP_OUT_QKV, rq, H, r_pad, split)));
+      } else {
+        KStreamParams kp;
+        kp.a_fp = ws.h_hi;
+        kp.wp = lw.wo2_pk;
+        kp.n_ksteps = I / 32;
+        kp.x = ws.x;
+        OP_TRY(launch_kstream(L, PK_KSTREAM_MLP_OUT, kp, H, r_pad, split));
+      }
+      continue;
     }
-    if (row_path) {
-      // x += h Wo^T, h read in its fragment-packed form (ws.h_hi / ws.h_lo are one contiguous buffer)
-      KStreamParams kp;
-      kp.a_fp = ws.h_hi;
-      kp.wp = lw.wo2_pk;
-      kp.n_ksteps = I / 32;
-      kp.x = ws.x;
-      OP_TRY(launch_kstream(L, PK_KSTREAM_MLP_OUT, kp, H, r_pad, split));
-    } else {
-      p.a_hi = ws.h_hi;
-      p.a_lo = ws.h_lo;
-      p.w_hi = lw.wo2_hi;
-      p.w_lo = lw.wo2_lo;
-      p.K = I;
-      p.n_tiles = H / GEMM_BN;
-      p.x = ws.x;
-      p.ld_out = H;
-      OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_MLP_OUT, p, split));
-    }
+
+    // ---- tiled path (hidden > 256): separate LayerNorm kernels, 128 x 128 x 32 tiles, row-major planes ----
+    if (li != 0) OP_TRY(layer_norm(lw.attn_norm));
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.a_hi = ws.ln_hi;
+    p.a_lo = ws.ln_lo;
+    p.K = H;
+    p.m_tiles = m_tiles;
+    p.hidden = H;
+    p.row_pos = ws.row_pos;
+    p.rope_cos = h->rope_cos[is_global ? 1 : 0];
+    p.rope_sin = h->rope_sin[is_global ? 1 : 0];
+    p.max_pos = h->max_pos;
+    // q, k = RoPE(x Wq^T), RoPE(x Wk^T)
+    p.w_hi = lw.wqkv_hi;
+    p.w_lo = lw.wqkv_lo;
+    p.n_tiles = 2 * H / GEMM_BN;
+    p.o0_hi = ws.q_hi;
+    p.o0_lo = ws.q_lo;
+    p.o1_hi = ws.k_hi;
+    p.o1_lo = ws.k_lo;
+    p.ld_out = H;
+    OP_TRY(launch_gemm<EPI_QK_ROPE>(L, PK_GEMM_QK_ROPE, p, split));
+    // v^T
+    p.w_hi = lw.wqkv_hi + (size_t)2 * H * H;
+    p.w_lo = lw.wqkv_lo + (size_t)2 * H * H;
+    p.n_tiles = H / GEMM_BN;
+    p.o0_hi = ws.vt_hi;
+    p.o0_lo = ws.vt_lo;
+    p.ld_out = r_pad;
+    OP_TRY(launch_gemm<EPI_V_T>(L, PK_GEMM_V_T, p, split));
+
+    OP_TRY(attention(is_global));
+
+    // x += attn Wo^T
+    p.a_hi = ws.o_hi;
+    p.a_lo = ws.o_lo;
+    p.w_hi = lw.wo_hi;
+    p.w_lo = lw.wo_lo;
+    p.K = H;
+    p.n_tiles = H / GEMM_BN;
+    p.x = ws.x;
+    p.ld_out = H;
+    OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_ATTN_OUT, p, split));
+    // x += (gelu(a) * g) Wo^T,  (a, g) = LN(x) Wi^T
+    OP_TRY(layer_norm(lw.mlp_norm));
+    p.a_hi = ws.ln_hi;
+    p.a_lo = ws.ln_lo;
+    p.w_hi = lw.wi_hi;
+    p.w_lo = lw.wi_lo;
+    p.K = H;
+    p.n_tiles = 2 * I / GEMM_BN;
+    p.o0_hi = ws.h_hi;
+    p.o0_lo = ws.h_lo;
+    p.ld_out = I;
+    OP_TRY(launch_gemm<EPI_GEGLU>(L, PK_GEMM_WI_GEGLU, p, split));
+    p.a_hi = ws.h_hi;
+    p.a_lo = ws.h_lo;
+    p.w_hi = lw.wo2_hi;
+    p.w_lo = lw.wo2_lo;
+    p.K = I;
+    p.n_tiles = H / GEMM_BN;
+    p.x = ws.x;
+    p.ld_out = H;
+    OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_MLP_OUT, p, split));
   }
 
   const int mean_pool = h->cfg.pooling == OP_POOL_MEAN ? 1 : 0;
@@ -611,7 +644,6 @@ int op_create(const op_config* cfg, op_handle** out) {
   h->split = cfg->precision == OP_PRECISION_BF16X3;
   h->chunk_rows = cfg->chunk_rows > 0 ? align_up(cfg->chunk_rows, ROW_ALIGN) : 262144;  // grids must cover the chip several times over
   h->layers.resize(N);
-  if (const char* rw = getenv("OPEN_PROVENCE_ROW_WAVES")) h->row_waves = atoi(rw) == 8 ? 8 : 4;
   h->row_path = (H <= 256) && (H % 32 == 0) && (I % 32 == 0) && getenv("OPEN_PROVENCE_FORCE_TILED") == nullptr;
 
 #define OP_CREATE_TRY(expr)  \
@@ -668,6 +700,7 @@ int op_create(const op_config* cfg, op_handle** out) {
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_pk, 2 * HH));
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
     }
     h->missing.push_back(pre + "mlp_norm.weight");
     h->missing.push_back(pre + "attn.Wqkv.weight");
@@ -711,6 +744,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
 
   enum Kind { F32_COPY, F32_TRANSPOSE, PLANES, PLANES_GEGLU };
   u16* dst_pk = nullptr;
+  u16* dst_ks = nullptr;  // additional k-streamed packing (attention Wo)
   int pk_mode = -1;
   Kind kind = F32_COPY;
   float* dst_f32 = nullptr;
@@ -755,7 +789,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       dst_pk = lw.wqkv_pk; pk_mode = RE_QKV;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
-      dst_pk = lw.wo_pk; pk_mode = RE_RESIDUAL;
+      dst_pk = lw.wo_pk; pk_mode = RE_RESIDUAL; dst_ks = lw.wo_ks;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
       dst_pk = lw.wi_pk; pk_mode = RE_GEGLU;
@@ -800,9 +834,11 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   }
   if (dst_pk && h->row_path) {
     if (pk_mode == 100)
-      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, dst_pk);
+      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_pk);
     else
       hipLaunchKernelGGL(pack_rowgemm_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_pk);
+    if (dst_ks)
+      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_ks);
   }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(0);

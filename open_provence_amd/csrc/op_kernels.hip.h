@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 // stream is computed in registers directly in fragment layout (a row lives in 4 lanes).
 // ----------------------------------------------------------------------------------------------
 enum RowEpilogue { RE_QKV = 0, RE_RESIDUAL = 1, RE_GEGLU = 2 };
-enum RowPrologue { RP_LN = 0, RP_SPLIT = 1, RP_PLANES = 2 };
+enum RowPrologue { RP_LN = 0, RP_SPLIT = 1, RP_PLANES = 2, RP_KSTREAM = 3 };
 constexpr int ROW_BM = 128;
 constexpr int ROW_CHUNK = 32;  // output features per streamed chunk
 
@@ -751,6 +751,12 @@ struct RowGemmParams {
   const float* rope_cos;
   const float* rope_sin;
   int max_pos;
+  // RP_KSTREAM (fused block): x_new = x + A1 W1^T first, A1 fragment-packed [r_pad/16][k1_steps][2][512], W1 packed
+  // by pack_kstream_kernel with permuted output features; then LayerNorm(x_new) feeds the chunk loop.
+  const u16* a1_fp;
+  const u16* w1p;
+  int k1_steps;
+  float* x_io;
   int debug_flags;  // experiments only (OPEN_PROVENCE_DEBUG_FLAGS): 1 skip epilogue, 2 skip DMA, 4 skip MFMA
 };
 
@@ -815,25 +821,24 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const 
   constexpr int PLANES = SPLIT ? 2 : 1;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 wh[2], wl[2];
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
-      const bf16x8 wh = lds_frag(stage_lane + (ks * PLANES) * 1024 + nf * 512);
-      bf16x8 wl = wh;
-      if (SPLIT) wl = lds_frag(stage_lane + (ks * PLANES + 1) * 1024 + nf * 512);
+      wh[nf] = lds_frag(stage_lane + (ks * PLANES) * 1024 + nf * 512);
+      wl[nf] = SPLIT ? lds_frag(stage_lane + (ks * PLANES + 1) * 1024 + nf * 512) : wh[nf];
+    }
+    // The three product terms are issued term-major over the four accumulators: an accumulator is touched every
+    // fourth MFMA, so no MFMA waits for the result of the previous one (back-to-back MFMAs on one accumulator
+    // stall on the read-after-write).
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
-        if (SWAPPED) {  // C rows = features, cols = tokens
-          if (SPLIT) {
-            acc[nf][mf] = mfma16(wl, a_hi[mf][ks], acc[nf][mf]);
-            acc[nf][mf] = mfma16(wh, a_lo[mf][ks], acc[nf][mf]);
-          }
-          acc[nf][mf] = mfma16(wh, a_hi[mf][ks], acc[nf][mf]);
-        } else {  // C rows = tokens, cols = features
-          if (SPLIT) {
-            acc[nf][mf] = mfma16(a_hi[mf][ks], wl, acc[nf][mf]);
-            acc[nf][mf] = mfma16(a_lo[mf][ks], wh, acc[nf][mf]);
-          }
-          acc[nf][mf] = mfma16(a_hi[mf][ks], wh, acc[nf][mf]);
+    for (int term = SPLIT ? 0 : 2; term < 3; ++term) {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+          const bf16x8 w = term == 0 ? wl[nf] : wh[nf];
+          const bf16x8 a = term == 1 ? a_lo[mf][ks] : a_hi[mf][ks];
+          acc[nf][mf] = SWAPPED ? mfma16(w, a, acc[nf][mf]) : mfma16(a, w, acc[nf][mf]);
         }
       }
     }
@@ -876,12 +881,141 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
           (__attribute__((address_space(3))) void*)(&sW[stage][elem]), 16, 0, 0);
     }
   };
-  stage_chunk(0, 0);
+  bf16x8 a_hi[2][KS], a_lo[2][KS];
+  if (PRO == RP_KSTREAM) {
+    // ---- fused phase 1: x_new[32 rows, H] = x + A1[32 rows, K1] W1[H, K1]^T, K1 streamed ----------------
+    // Same structure as kstream_gemm_kernel (one [H x 32] weight slab per k-step by DMA, A1 fragments straight
+    // from the fragment-packed activation, prefetched one k-step ahead), all H outputs of the 32 rows in
+    // accumulators.  W1's output features were permuted at load time so that accumulator fragments (2s, 2s+1)
+    // are exactly lane slot g of k-step s of THIS kernel's chunk loop: residual add, LayerNorm and the hi/lo
+    // split happen in registers and the hidden state makes one fp32 round trip (read + write) per block.
+    constexpr int NF1 = 2 * KS;
+    constexpr int SLAB_SRC = NF1 * 2 * 512;
+    constexpr int SLAB_PIECES = (NF1 * PLANES) / WAVES;
+    static_assert((NF1 * PLANES) % WAVES == 0, "slab must split evenly over the waves");
+    auto stage_slab = [&](int ks1, int stage) {
+      const u16* src = p.w1p + (size_t)ks1 * SLAB_SRC;
+#pragma unroll
+      for (int u = 0; u < SLAB_PIECES; ++u) {
+        const int piece = wave + WAVES * u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+      }
+    };
+    const int nks1 = p.k1_steps;
+    const u16* a_base0 = p.a1_fp + ((size_t)(m0 >> 4) * nks1 * 2) * 512 + lane * 8;
+    const u16* a_base1 = a_base0 + (size_t)nks1 * 2 * 512;
+    bf16x8 an_hi[2], an_lo[2];
+    auto load_a1 = [&](int ks1) {
+      an_hi[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks1 * 1024);
+      an_hi[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks1 * 1024);
+      if (SPLIT) {
+        an_lo[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks1 * 1024 + 512);
+        an_lo[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks1 * 1024 + 512);
+      } else {
+        an_lo[0] = an_hi[0];
+        an_lo[1] = an_hi[1];
+      }
+    };
+    f32x4 acc1[NF1][2];
+#pragma unroll
+    for (int nf = 0; nf < NF1; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) acc1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_slab(0, 0);
+    load_a1(0);
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      asm volatile("" : "+v"(an_hi[mf]));
+      asm volatile("" : "+v"(an_lo[mf]));
+    }
+    __syncthreads();
+    auto slab_step = [&](int ks1, auto cur_tag) {
+      constexpr int cur = decltype(cur_tag)::value;
+      const int kn = ks1 + 1 < nks1 ? ks1 + 1 : ks1;
+      stage_slab(kn, cur ^ 1);
+      bf16x8 c_hi[2], c_lo[2];
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        c_hi[mf] = an_hi[mf];
+        c_lo[mf] = an_lo[mf];
+      }
+      load_a1(kn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = 0; nf < NF1; ++nf) {
+        const bf16x8 wh = lds_frag(&sW[cur][nf * 512 + lane * 8]);
+        if (SPLIT) {
+          const bf16x8 wl = lds_frag(&sW[cur][(NF1 + nf) * 512 + lane * 8]);
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf) {
+            acc1[nf][mf] = mfma16(wl, c_hi[mf], acc1[nf][mf]);
+            acc1[nf][mf] = mfma16(wh, c_lo[mf], acc1[nf][mf]);
+          }
+        }
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) acc1[nf][mf] = mfma16(wh, c_hi[mf], acc1[nf][mf]);
+      }
+      __syncthreads();
+    };
+    for (int k0 = 0; k0 < nks1; k0 += 2) {  // even number of k-steps (checked on the host)
+      slab_step(k0, std::integral_constant<int, 0>{});
+      slab_step(k0 + 1, std::integral_constant<int, 1>{});
+    }
+    stage_chunk(0, 0);  // first weight chunk of phase 2 flies while the LayerNorm below runs
+
+    // ---- transition: residual add, store the new hidden state, LayerNorm, split -> fragments --------------
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      float* xrow = p.x_io + (size_t)(m0 + mf * 16 + l15) * K + g * 8;
+      float sum = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < NF1; ++nf) {
+        float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
+        float4 r4 = *px;
+        r4.x += acc1[nf][mf][0];
+        r4.y += acc1[nf][mf][1];
+        r4.z += acc1[nf][mf][2];
+        r4.w += acc1[nf][mf][3];
+        *px = r4;
+        acc1[nf][mf] = f32x4{r4.x, r4.y, r4.z, r4.w};
+        sum += (r4.x + r4.y) + (r4.z + r4.w);
+        // keep the scheduler from hoisting all 16 row loads (64 more registers) on top of the accumulators
+        if ((nf & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum / (float)K;
+      float q = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < NF1; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc1[nf][mf][r] - mean;
+          q += d * d;
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = 1.0f / sqrtf(q / (float)K + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8 + 4);
+        const float v[8] = {(acc1[2 * ks][mf][0] - mean) * rstd * w0.x,     (acc1[2 * ks][mf][1] - mean) * rstd * w0.y,
+                            (acc1[2 * ks][mf][2] - mean) * rstd * w0.z,     (acc1[2 * ks][mf][3] - mean) * rstd * w0.w,
+                            (acc1[2 * ks + 1][mf][0] - mean) * rstd * w1.x, (acc1[2 * ks + 1][mf][1] - mean) * rstd * w1.y,
+                            (acc1[2 * ks + 1][mf][2] - mean) * rstd * w1.z, (acc1[2 * ks + 1][mf][3] - mean) * rstd * w1.w};
+        pack8<SPLIT>(v, a_hi[mf][ks], a_lo[mf][ks]);
+      }
+    }
+  } else {
+    stage_chunk(0, 0);
+  }
 
   // ---- prologue: this wave's 32 rows as fragments ---------------------------------------------
-  bf16x8 a_hi[2][KS], a_lo[2][KS];
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
+    if (PRO == RP_KSTREAM) break;
     const size_t row = (size_t)(m0 + mf * 16 + l15);
     if (PRO == RP_PLANES) {  // fragment-packed input: piece (row block, k-step, plane), 16 bytes per lane
       const u16* base = p.a_hi + (((size_t)((m0 >> 4) + mf) * KS) * 2) * 512 + lane * 8;
@@ -1138,7 +1272,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
 // ----------------------------------------------------------------------------------------------
 
 // dst[ks][plane][nf][g][i][e] <- W[nf*16 + i][ks*32 + g*8 + e]   (W is [N][K]; chunk = one k-step of all N)
-__global__ void pack_kstream_kernel(const float* __restrict__ src, int N, int K, u16* __restrict__ dst) {
+__global__ void pack_kstream_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * K) return;
   const int NF = N / 16;
@@ -1148,7 +1282,10 @@ __global__ void pack_kstream_kernel(const float* __restrict__ src, int N, int K,
   const int g = (int)(t & 3); t >>= 2;
   const int nf = (int)(t % NF);
   const int ks = (int)(t / NF);
-  const float v = src[(size_t)(nf * 16 + i) * K + ks * 32 + g * 8 + e];
+  // permute: accumulator slot (nf, i = 4g' + r) holds output feature 32(nf>>1) + 8g' + 4(nf&1) + r, so that the
+  // accumulators of fragments (2s, 2s+1) ARE the 8 k-values of lane slot g' of k-step s of the next GEMM.
+  const int row = permute ? (32 * (nf >> 1) + 8 * (i >> 2) + 4 * (nf & 1) + (i & 3)) : (nf * 16 + i);
+  const float v = src[(size_t)row * K + ks * 32 + g * 8 + e];
   const u16 h = f2bf(v);
   const size_t base = ((size_t)ks * 2 * NF + nf) * 512 + (size_t)g * 128 + i * 8 + e;
   dst[base] = h;
@@ -1255,13 +1392,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void kstream_gemm_kernel(KStreamPara
     }
   }
 
-  // x += acc : lane owns features 16nf + 4g + (0..3) of token m0 + 16mf + l15
+  // x += acc : the weights are packed with permuted output features (pack_kstream_kernel), accumulator slot
+  // (nf, g, r) is feature 32(nf>>1) + 8g + 4(nf&1) + r of token m0 + 16mf + l15
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
-    float* xrow = p.x + (size_t)(m0 + mf * 16 + l15) * (NF * 16) + g * 4;
+    float* xrow = p.x + (size_t)(m0 + mf * 16 + l15) * (NF * 16) + g * 8;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-      float4* px = reinterpret_cast<float4*>(xrow + nf * 16);
+      float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
       float4 r4 = *px;
       r4.x += acc[nf][mf][0];
       r4.y += acc[nf][mf][1];
@@ -1547,8 +1685,10 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
 
   // DMA one key tile: wave w copies pieces w, w+4, ... of the stage [K: m, ks, plane | V: t, plane, n]
   auto stage_tile = [&](int kt, int stage) {
-    const size_t k_rb0 = (size_t)((r0 + kt * ATT_BK) >> 4);
-    const size_t v_tb0 = (size_t)((r0 + kt * ATT_BK) >> 5);
+    // A tile may reach past the last computed row (the last sequence need not fill its final 64-key tile): such
+    // pieces are clamped onto the last valid one -- their keys are masked, they only have to be finite.
+    const int k_rb0 = (r0 + kt * ATT_BK) >> 4, k_rb_max = (p.r_pad >> 4) - 1;
+    const int v_tb0 = (r0 + kt * ATT_BK) >> 5, v_tb_max = (p.r_pad >> 5) - 1;
 #pragma unroll
     for (int u = 0; u < (K_PIECES + V_PIECES) / 4; ++u) {
       const int piece = wave + 4 * u;  // wave-uniform
@@ -1556,12 +1696,14 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
       if (piece < K_PIECES) {
         const int m = piece / (2 * PLANES), rem = piece % (2 * PLANES);
         const int ks = rem / PLANES, plane = rem % PLANES;
-        src = p.k_fp + (((k_rb0 + m) * kbn + head * 2 + ks) * 2 + plane) * 512;
+        const size_t rb = (size_t)(k_rb0 + m < k_rb_max ? k_rb0 + m : k_rb_max);
+        src = p.k_fp + ((rb * kbn + head * 2 + ks) * 2 + plane) * 512;
       } else {
         const int pv = piece - K_PIECES;
         const int t = pv / (4 * PLANES), rem = pv % (4 * PLANES);
         const int plane = rem / 4, n = rem % 4;
-        src = p.vt_fp + ((((size_t)head * (p.r_pad >> 5) + v_tb0 + t) * 2 + plane) * 4 + n) * 512;
+        const size_t tb = (size_t)(v_tb0 + t < v_tb_max ? v_tb0 + t : v_tb_max);
+        src = p.vt_fp + ((((size_t)head * (p.r_pad >> 5) + tb) * 2 + plane) * 4 + n) * 512;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
                                        (__attribute__((address_space(3))) void*)(&sT[stage][piece * 512]), 16, 0, 0);
