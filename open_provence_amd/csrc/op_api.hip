@@ -361,7 +361,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
 
   auto attention = [&](bool is_global) -> int {
     OP_TRY(L.begin(is_global ? PK_ATTN_GLOBAL : PK_ATTN_LOCAL));
-    const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
+    const int q_blocks_fp = (max_len + ATT_FP_BQ - 1) / ATT_FP_BQ;
+    const dim3 grid(h->row_path ? (unsigned)q_blocks_fp : (unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
     const int window = is_global ? -1 : h->cfg.local_attention / 2;
     if (h->row_path) {
       AttnFpParams ap;  // q_hi/q_lo (k, vt, o likewise) are adjacent: together they hold the fragment-packed tensor

@@ -1152,7 +1152,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
         const bool is_q = cc < per_block;
         const int cq = is_q ? cc : cc - per_block;
         u16* out = is_q ? p.o0_hi : p.o1_hi;
-        const float qscale = is_q ? 0.125f : 1.0f;  // head_dim^-0.5, exact
+        // head_dim^-0.5 * log2(e): the fragment-packed attention kernel exponentiates with exp2
+        const float qscale = is_q ? 0.125f * 1.44269504088896340736f : 1.0f;
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
           // half-head index j = cq & 1 equals the chunk parity PP (even number of chunks per block)
@@ -1634,6 +1635,10 @@ struct AttnFpParams {
   int window;
 };
 
+constexpr int ATT_FP_BQ = 128;  // queries per block of the fragment-packed attention kernel (4 waves x 32)
+
+// Scores arrive pre-multiplied by log2(e) (folded into the q scale by the QKV epilogue), so the softmax uses
+// exp2 directly: p = 2^(s - max).
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
   constexpr int PLANES = SPLIT ? 2 : 1;
@@ -1644,7 +1649,7 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
 
   const int s = blockIdx.z;
   const int head = blockIdx.y;
-  const int q0 = blockIdx.x * ATT_BQ;
+  const int q0 = blockIdx.x * ATT_FP_BQ;
   const int len = p.cu[p.s0 + s + 1] - p.cu[p.s0 + s];
   if (q0 >= len) return;
   const int r0 = p.roff[s];
@@ -1657,38 +1662,43 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
   const int g = lane >> 4;
   const int kbn = p.H >> 5;  // k-steps per row block
 
-  const int qbase = q0 + wave * 16;
-  const bool active = qbase < alloc;  // alloc is a multiple of 32
-  const int qpos = qbase + l15;
+  const int qbase = q0 + wave * 32;   // this wave's 32 queries = two fragments
+  const bool active = qbase < alloc;  // alloc is a multiple of 32: both fragments in or out
   const size_t q_rb = (size_t)((r0 + (active ? qbase : q0)) >> 4);
 
-  bf16x8 qf_hi[2], qf_lo[2];
+  bf16x8 qf_hi[2][2], qf_lo[2][2];  // [query fragment][k-step]
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const u16* src = p.q_fp + ((q_rb * kbn + head * 2 + ks) * 2) * 512 + lane * 8;
-    qf_hi[ks] = *reinterpret_cast<const bf16x8*>(src);
-    if (SPLIT) qf_lo[ks] = *reinterpret_cast<const bf16x8*>(src + 512);
-  }
+  for (int qf = 0; qf < 2; ++qf)
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {  // retire the loads before the tile loop (see rowgemm_kernel)
-    asm volatile("" : "+v"(qf_hi[ks]));
-    if (SPLIT) asm volatile("" : "+v"(qf_lo[ks]));
-  }
+    for (int ks = 0; ks < 2; ++ks) {
+      const u16* src = p.q_fp + (((q_rb + qf) * kbn + head * 2 + ks) * 2) * 512 + lane * 8;
+      qf_hi[qf][ks] = *reinterpret_cast<const bf16x8*>(src);
+      qf_lo[qf][ks] = SPLIT ? *reinterpret_cast<const bf16x8*>(src + 512) : qf_hi[qf][ks];
+    }
+#pragma unroll
+  for (int qf = 0; qf < 2; ++qf)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // retire the loads before the tile loop (see rowgemm_kernel)
+      asm volatile("" : "+v"(qf_hi[qf][ks]));
+      asm volatile("" : "+v"(qf_lo[qf][ks]));
+    }
 
+  const int win = p.window >= 0 ? p.window : (1 << 30);
   int kt_lo = 0, kt_hi = (len - 1) / ATT_BK;
   if (p.window >= 0) {
     const int lo_key = q0 - p.window;
     kt_lo = lo_key > 0 ? lo_key / ATT_BK : 0;
-    const int hi_t = (q0 + ATT_BQ - 1 + p.window) / ATT_BK;
+    const int hi_t = (q0 + ATT_FP_BQ - 1 + p.window) / ATT_BK;
     kt_hi = hi_t < kt_hi ? hi_t : kt_hi;
   }
 
   // DMA one key tile: wave w copies pieces w, w+4, ... of the stage [K: m, ks, plane | V: t, plane, n]
+  const int k_rb_max = (p.r_pad >> 4) - 1, v_tb_max = (p.r_pad >> 5) - 1;
   auto stage_tile = [&](int kt, int stage) {
     // A tile may reach past the last computed row (the last sequence need not fill its final 64-key tile): such
     // pieces are clamped onto the last valid one -- their keys are masked, they only have to be finite.
-    const int k_rb0 = (r0 + kt * ATT_BK) >> 4, k_rb_max = (p.r_pad >> 4) - 1;
-    const int v_tb0 = (r0 + kt * ATT_BK) >> 5, v_tb_max = (p.r_pad >> 5) - 1;
+    const int k_rb0 = (r0 + kt * ATT_BK) >> 4;
+    const int v_tb0 = (r0 + kt * ATT_BK) >> 5;
 #pragma unroll
     for (int u = 0; u < (K_PIECES + V_PIECES) / 4; ++u) {
       const int piece = wave + 4 * u;  // wave-uniform
@@ -1710,94 +1720,125 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
     }
   };
 
-  float m_run = -1e30f;
-  float l_run = 0.f;
-  f32x4 oacc[4];
+  float m_run[2] = {-1e30f, -1e30f};
+  float l_run[2] = {0.f, 0.f};
+  f32x4 oacc[4][2];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) oacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int qf = 0; qf < 2; ++qf) oacc[n][qf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto tile = [&](int kt, auto cur_tag) {
     constexpr int cur = decltype(cur_tag)::value;
     stage_tile(kt + 1 <= kt_hi ? kt + 1 : kt, cur ^ 1);  // unconditional prefetch into the idle stage
     const u16* st = &sT[cur][lane * 8];
     const int kbase = kt * ATT_BK;
-
-    f32x4 sacc[4];
+    // wave-uniform tile classification: skip tiles entirely outside this wave's window (other waves of the block
+    // may need them), and use the mask-free path when every (query, key) pair of the tile is visible
+    const bool outside = (kbase > qbase + 31 + win) || (kbase + ATT_BK - 1 < qbase - win);
+    const bool all_valid = (kbase + ATT_BK - 1 < len) && (kbase + ATT_BK - 1 - qbase <= win) && (qbase + 31 - kbase <= win);
+    if (!outside) {
+      f32x4 sacc[4][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) sacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+        for (int qf = 0; qf < 2; ++qf) sacc[m][qf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const bf16x8 kh = lds_frag(st + ((m * 2 + ks) * PLANES) * 512);
-        if (SPLIT) {
-          const bf16x8 kl = lds_frag(st + ((m * 2 + ks) * PLANES + 1) * 512);
-          sacc[m] = mfma16(kl, qf_hi[ks], sacc[m]);
-          sacc[m] = mfma16(kh, qf_lo[ks], sacc[m]);
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const bf16x8 kh = lds_frag(st + ((m * 2 + ks) * PLANES) * 512);
+          const bf16x8 kl = SPLIT ? lds_frag(st + ((m * 2 + ks) * PLANES + 1) * 512) : kh;
+#pragma unroll
+          for (int qf = 0; qf < 2; ++qf) {
+            if (SPLIT) {
+              sacc[m][qf] = mfma16(kl, qf_hi[qf][ks], sacc[m][qf]);
+              sacc[m][qf] = mfma16(kh, qf_lo[qf][ks], sacc[m][qf]);
+            }
+            sacc[m][qf] = mfma16(kh, qf_hi[qf][ks], sacc[m][qf]);
+          }
         }
-        sacc[m] = mfma16(kh, qf_hi[ks], sacc[m]);
       }
-    }
 
-    // element (m, r) of this lane: key = kbase + 16m + 4g + r (natural order inside a 16-row piece)
-    // masked scores become -3e30 (below the running-max initial value -1e30): exp(masked - max) underflows to
-    // exactly 0 even when a whole tile is masked for this query; branch-free (selects only).
-    const int win = p.window >= 0 ? p.window : (1 << 30);
-    float tile_max = -3e30f;
+      if (!all_valid) {
+        // masked scores become -3e30 (below the running-max initial value -1e30): 2^(masked - max) underflows to
+        // exactly 0 even when the whole tile is masked for a query; selects only, no branches.
+        // element (m, r) of this lane: key = kbase + 16m + 4g + r
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+        for (int qf = 0; qf < 2; ++qf) {
+          const int qpos = qbase + 16 * qf + l15;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kbase + 16 * m + 4 * g + r;
-        const int d = key - qpos;
-        const bool ok = (key < len) & (d <= win) & (d >= -win);
-        sacc[m][r] = ok ? sacc[m][r] : -3e30f;
-        tile_max = fmaxf(tile_max, sacc[m][r]);
-      }
-    }
-    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 16, 64));
-    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
-    const float m_new = fmaxf(m_run, tile_max);
-    const float alpha = __expf(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-    float pv[4][4];
+          for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(sacc[m][r] - m_new);
-        pv[m][r] = e;
-        psum += e;
-      }
-    }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      oacc[n][0] *= alpha;
-      oacc[n][1] *= alpha;
-      oacc[n][2] *= alpha;
-      oacc[n][3] *= alpha;
-    }
-
-    // O^T += V^T P^T: k-step t covers keys 32t..32t+31; lane slot e < 4 -> key 32t + 4g + e (piece m = 2t),
-    // e >= 4 -> key 32t + 16 + 4g + (e-4) (piece m = 2t+1): the order the QKV epilogue stored v^T in.
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      uint2 h0, l0, h1, l1;
-      split4<SPLIT>(pv[2 * t], h0, l0);
-      split4<SPLIT>(pv[2 * t + 1], h1, l1);
-      const bf16x8 ph = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
-      const bf16x8 pl = as_frag(make_uint4(l0.x, l0.y, l1.x, l1.y));
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const bf16x8 vh = lds_frag(st + (K_PIECES + (t * PLANES) * 4 + n) * 512);
-        if (SPLIT) {
-          const bf16x8 vl = lds_frag(st + (K_PIECES + (t * PLANES + 1) * 4 + n) * 512);
-          oacc[n] = mfma16(vl, ph, oacc[n]);
-          oacc[n] = mfma16(vh, pl, oacc[n]);
+            for (int r = 0; r < 4; ++r) {
+              const int key = kbase + 16 * m + 4 * g + r;
+              const int d = key - qpos;
+              const bool ok = (key < len) & (d <= win) & (d >= -win);
+              sacc[m][qf][r] = ok ? sacc[m][qf][r] : -3e30f;
+            }
         }
-        oacc[n] = mfma16(vh, ph, oacc[n]);
+      }
+
+      bf16x8 ph[2][2], pl[2][2];  // [k-step t][query fragment]
+#pragma unroll
+      for (int qf = 0; qf < 2; ++qf) {
+        float tile_max = -3e30f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile_max = fmaxf(tile_max, sacc[m][qf][r]);
+        tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 16, 64));
+        tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
+        const float m_new = fmaxf(m_run[qf], tile_max);
+        const float alpha = exp2f(m_run[qf] - m_new);
+        m_run[qf] = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = exp2f(sacc[m][qf][r] - m_new);
+            sacc[m][qf][r] = e;
+            psum += e;
+          }
+        l_run[qf] = l_run[qf] * alpha + psum;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          oacc[n][qf][0] *= alpha;
+          oacc[n][qf][1] *= alpha;
+          oacc[n][qf][2] *= alpha;
+          oacc[n][qf][3] *= alpha;
+        }
+        // lane slot e < 4 -> key 32t + 4g + e (piece m = 2t), e >= 4 -> key 32t + 16 + 4g + (e-4) (piece 2t+1):
+        // the order the QKV epilogue stored v^T in
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float v0[4] = {sacc[2 * t][qf][0], sacc[2 * t][qf][1], sacc[2 * t][qf][2], sacc[2 * t][qf][3]};
+          const float v1[4] = {sacc[2 * t + 1][qf][0], sacc[2 * t + 1][qf][1], sacc[2 * t + 1][qf][2], sacc[2 * t + 1][qf][3]};
+          uint2 h0, l0, h1, l1;
+          split4<SPLIT>(v0, h0, l0);
+          split4<SPLIT>(v1, h1, l1);
+          ph[t][qf] = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
+          pl[t][qf] = as_frag(make_uint4(l0.x, l0.y, l1.x, l1.y));
+        }
+      }
+
+      // O^T += V^T P^T
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const bf16x8 vh = lds_frag(st + (K_PIECES + (t * PLANES) * 4 + n) * 512);
+          const bf16x8 vl = SPLIT ? lds_frag(st + (K_PIECES + (t * PLANES + 1) * 4 + n) * 512) : vh;
+#pragma unroll
+          for (int qf = 0; qf < 2; ++qf) {
+            if (SPLIT) {
+              oacc[n][qf] = mfma16(vl, ph[t][qf], oacc[n][qf]);
+              oacc[n][qf] = mfma16(vh, pl[t][qf], oacc[n][qf]);
+            }
+            oacc[n][qf] = mfma16(vh, ph[t][qf], oacc[n][qf]);
+          }
+        }
       }
     }
     __syncthreads();
@@ -1810,22 +1851,26 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
     if (kt + 1 <= kt_hi) tile(kt + 1, std::integral_constant<int, 1>{});
   }
 
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (active) {
-    // oacc[n][r]: d = 32(n>>1) + 8g + 4(n&1) + r  ->  lane owns d = 8g..8g+7 of k-step (n>>1) of this head
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const float v0[4] = {oacc[2 * half][0] * inv, oacc[2 * half][1] * inv, oacc[2 * half][2] * inv, oacc[2 * half][3] * inv};
-      const float v1[4] = {oacc[2 * half + 1][0] * inv, oacc[2 * half + 1][1] * inv, oacc[2 * half + 1][2] * inv,
-                           oacc[2 * half + 1][3] * inv};
-      uint2 h0, l0, h1, l1;
-      split4<SPLIT>(v0, h0, l0);
-      split4<SPLIT>(v1, h1, l1);
-      u16* dst = p.o_fp + ((q_rb * kbn + head * 2 + half) * 2) * 512 + lane * 8;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-      if (SPLIT) *reinterpret_cast<uint4*>(dst + 512) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    for (int qf = 0; qf < 2; ++qf) {
+      float l_tot = l_run[qf] + __shfl_xor(l_run[qf], 16, 64);
+      l_tot += __shfl_xor(l_tot, 32, 64);
+      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+      // oacc[n][qf][r]: d = 32(n>>1) + 8g + 4(n&1) + r  ->  lane owns d = 8g..8g+7 of k-step (n>>1) of this head
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const float v0[4] = {oacc[2 * half][qf][0] * inv, oacc[2 * half][qf][1] * inv, oacc[2 * half][qf][2] * inv,
+                             oacc[2 * half][qf][3] * inv};
+        const float v1[4] = {oacc[2 * half + 1][qf][0] * inv, oacc[2 * half + 1][qf][1] * inv,
+                             oacc[2 * half + 1][qf][2] * inv, oacc[2 * half + 1][qf][3] * inv};
+        uint2 h0, l0, h1, l1;
+        split4<SPLIT>(v0, h0, l0);
+        split4<SPLIT>(v1, h1, l1);
+        u16* dst = p.o_fp + (((q_rb + qf) * kbn + head * 2 + half) * 2) * 512 + lane * 8;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        if (SPLIT) *reinterpret_cast<uint4*>(dst + 512) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+      }
     }
   }
 }
