@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate passes, TCC slots) into per-launch HBM
+traffic of each kernel kind bench.py names.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
+128-byte requests of wide coalesced streams as 64 bytes, so reads are doubled
+(/opt/skills/guides/MI355X_MICROARCH.md, section HBM).  Usage: collect_traffic.py <fetch_dir> <write_dir> <precision> <out.json>"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+KIND = [
+    (r"rowgemm_kernel<\d+, 2, 3,", "fused_attnout_ln_wi_geglu"),
+    (r"rowgemm_kernel<\d+, 0, 3,", "fused_mlpout_ln_qkv_rope"),
+    (r"rowgemm_kernel<\d+, 0, [01],", "rowgemm_ln_qkv_rope"),
+    (r"rowgemm_kernel<\d+, 1, 2,", "rowgemm_attn_out"),
+    (r"rowgemm_kernel<\d+, 2, 0,", "rowgemm_ln_wi_geglu"),
+    (r"kstream_gemm_kernel", "kstream_mlp_out"),
+    (r"attn_fp_kernel", "attn_fp"),
+    (r"attn_kernel", "attn"),
+    (r"gemm_kernel<3,", "gemm_wi_geglu"),
+    (r"gemm_kernel<2,", "gemm_residual"),
+    (r"gemm_kernel<0,", "gemm_qk_rope"),
+    (r"gemm_kernel<1,", "gemm_v_t"),
+]
+
+
+def per_kernel(directory, counter):
+    acc, cnt = defaultdict(float), defaultdict(set)
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            for pat, kind in KIND:
+                if re.search(pat, r["Kernel_Name"]):
+                    acc[kind] += float(r["Counter_Value"])
+                    cnt[kind].add(r["Dispatch_Id"])
+                    break
+    return {k: acc[k] / len(cnt[k]) for k in acc}
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+precision = sys.argv[3]
+out_path = sys.argv[4]
+out = json.load(open(out_path)) if os.path.exists(out_path) else {}
+for kind in sorted(set(fetch) | set(write)):
+    f_kb, w_kb = fetch.get(kind, 0.0), write.get(kind, 0.0)
+    out[f"{kind}:{precision}"] = {
+        "fetch_size_kib_raw": f_kb,
+        "write_size_kib_raw": w_kb,
+        "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0,
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; reads x2 (gfx950 correction)",
+    }
+    print(kind, precision, f"fetch {f_kb/1024:.1f} MiB raw, write {w_kb/1024:.1f} MiB -> {out[f'{kind}:{precision}']['hbm_bytes_per_launch']/1e6:.1f} MB/launch")
+json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)

@@ -12,8 +12,9 @@ root = sys.argv[1]
 
 def short(name: str) -> str:
     name = name.replace("void ", "")
-    for key in ("gemm_kernel", "attn_kernel", "ln_kernel", "embed_ln_kernel", "final_ln_prune_kernel", "rank_head_kernel",
-                "row_map_kernel", "seq_offsets_kernel", "capture_rows_kernel"):
+    for key in ("rowgemm_kernel", "kstream_gemm_kernel", "attn_fp_kernel", "gemm_kernel", "attn_kernel", "embed_ln_kernel",
+                "ln_kernel", "final_ln_prune_kernel", "rank_head_kernel", "row_map_kernel", "seq_offsets_kernel",
+                "capture_rows_kernel"):
         if key in name:
             tail = name[name.index(key):]
             return tail[:60]

@@ -42,3 +42,16 @@ def test_chunking_does_not_change_results(chunk_rows):
     b = run_fixture_on_gpu("g1_xsmall", "bf16x3", chunk_rows=chunk_rows, capture=False)
     assert b["prune_max_err"] < TOL and b["rank_max_err"] < TOL
     assert abs(a["prune_max_err"] - b["prune_max_err"]) < 1e-4
+
+
+@pytest.mark.parametrize("env", [{"OPEN_PROVENCE_FORCE_TILED": "1"}, {"OPEN_PROVENCE_NO_FUSE": "1"}])
+def test_alternative_kernel_paths_agree(env, monkeypatch):
+    """The tiled kernels (what hidden > 256 models use) and the unfused row-stationary kernels must give the same
+    answers as the default fused path on an xsmall-shaped fixture."""
+
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
+    rep = run_fixture_on_gpu("g1_xsmall", "bf16x3")
+    assert rep["finite"] and rep["prune_max_err"] < TOL and rep["rank_max_err"] < TOL, rep
+    rep = run_fixture_on_gpu("g0c_hd64_synth", "bf16x3")
+    assert rep["finite"] and rep["prune_max_err"] < TOL and rep["rank_max_err"] < TOL, rep
