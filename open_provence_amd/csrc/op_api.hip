@@ -356,7 +356,6 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
 
   const int q_tiles = (max_len + ATT_BQ - 1) / ATT_BQ;
 
-  const int dbg_flags = getenv("OPEN_PROVENCE_DEBUG_FLAGS") ? atoi(getenv("OPEN_PROVENCE_DEBUG_FLAGS")) : 0;
   const bool fuse = getenv("OPEN_PROVENCE_NO_FUSE") == nullptr;
 
   auto attention = [&](bool is_global) -> int {
@@ -417,7 +416,6 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     rp.rope_cos = h->rope_cos[is_global ? 1 : 0];
     rp.rope_sin = h->rope_sin[is_global ? 1 : 0];
     rp.max_pos = h->max_pos;
-    rp.debug_flags = dbg_flags;
     rp.x_in = ws.x;
     rp.ln_w = lw.attn_norm;
     rp.wp = lw.wqkv_pk;
@@ -451,7 +449,6 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       rp.eps = h->cfg.norm_eps;
       rp.hidden = H;
       rp.r_pad = r_pad;
-      rp.debug_flags = dbg_flags;
       rp.ln_w = lw.mlp_norm;
       rp.wp = lw.wi_pk;
       rp.n_chunks = 2 * I / ROW_CHUNK;
@@ -469,7 +466,6 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         memset(&ro, 0, sizeof(ro));
         ro.hidden = H;
         ro.r_pad = r_pad;
-        ro.debug_flags = dbg_flags;
         ro.a_hi = ws.o_hi;
         ro.wp = lw.wo_pk;
         ro.n_chunks = H / ROW_CHUNK;

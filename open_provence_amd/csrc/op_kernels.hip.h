@@ -95,19 +95,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// GELU (exact-erf form) = 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7 absolute, i.e. fp32-roundoff class) instead of the library erff: branch-free, one v_exp_f32
-// and one v_rcp_f32.  Written as x * (1 - e/2) for x >= 0 and x * e/2 for x < 0, e = erfc(|x|/sqrt 2): no
-// cancellation on the negative side.  Max |gelu - exact| = 2.1e-7 over [-6, 6] (checked offline in fp64).
+// GELU (exact-erf form) = 0.5 x (1 + erf(x / sqrt 2)), with erfc from Abramowitz & Stegun 7.1.28,
+//   erfc(z) = (1 + a1 z + ... + a6 z^6)^-16   (|error| <= 3e-7),
+// instead of the library erff: branch-free, six FMAs, four squarings and ONE quarter-rate instruction (v_rcp_f32).
+// z = |x|/sqrt 2 and the factor 1/2 are folded into the coefficients (c_k = a_k 2^(-k/2) 2^(1/16)), so that
+// he = 1/p^16 = erfc(|x|/sqrt 2)/2 and gelu(x) = max(x, 0) - |x| he on both sides of zero (no cancellation for
+// x < 0).  Max |gelu - exact| = 7.1e-7 over [-10, 10] evaluated in fp32 (checked offline against fp64 erf);
+// |x| large: p^16 -> inf, he -> 0.
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float e = poly * t * __expf(-z * z);  // erfc(z)
-  return x * (x >= 0.f ? 1.0f - 0.5f * e : 0.5f * e);
+  const float ax = fabsf(x);
+  float p = fmaf(5.6212998061e-06f, ax, 5.1055209042e-05f);
+  p = fmaf(p, ax, 3.9686136006e-05f);
+  p = fmaf(p, ax, 3.4227392171e-03f);
+  p = fmaf(p, ax, 2.2076997906e-02f);
+  p = fmaf(p, ax, 5.2075162530e-02f);
+  p = fmaf(p, ax, 1.0442737341e+00f);
+  p *= p;
+  p *= p;
+  p *= p;
+  p *= p;
+  const float he = __builtin_amdgcn_rcpf(p);
+  // max(x, 0) as med3(x, 0, +inf): one instruction (fmaxf adds a NaN-quieting v_max x,x in front)
+  return fmaf(-he, ax, __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -757,7 +766,6 @@ struct RowGemmParams {
   const u16* w1p;
   int k1_steps;
   float* x_io;
-  int debug_flags;  // experiments only (OPEN_PROVENCE_DEBUG_FLAGS): 1 skip epilogue, 2 skip DMA, 4 skip MFMA
 };
 
 // source row of packed row `pr` (0..31) of chunk `c`
@@ -829,7 +837,9 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const 
     }
     // The three product terms are issued term-major over the four accumulators: an accumulator is touched every
     // fourth MFMA, so no MFMA waits for the result of the previous one (back-to-back MFMAs on one accumulator
-    // stall on the read-after-write).
+    // stall on the read-after-write).  (A unit-major software pipeline that prefetches the next (k-step, 16-feature)
+    // fragment pair during six MFMAs measured the same: the fragment-read latency is already covered by the
+    // partner wave on the SIMD.)
 #pragma unroll
     for (int term = SPLIT ? 0 : 2; term < 3; ++term) {
 #pragma unroll
@@ -1108,8 +1118,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   auto epilogue = [&](int cc, auto parity_tag, const f32x4 (&av)[2][2]) {
     constexpr int PP = decltype(parity_tag)::value;
     const bool sw = (EPI != RE_QKV) || (cc < p.n_swapped);
-    if ((p.debug_flags & 1) && av[0][0][0] != 12345.f) {
-    } else if (EPI == RE_RESIDUAL) {
+    if (EPI == RE_RESIDUAL) {
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
         const size_t row = (size_t)(m0 + mf * 16 + l15);
@@ -1217,8 +1226,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   // The q/k/v variant needs its registers for the RoPE rows and the half-head hold, so it runs each chunk's
   // epilogue right away; the other variants defer it by one iteration (see above).
   constexpr bool LATE = (EPI != RE_QKV);
-  auto iteration = [&](int c, auto cur_tag) {
+  auto iteration = [&](int c, auto cur_tag, auto first_tag) {
     constexpr int cur = decltype(cur_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
     // every wave passed the barrier that ended iteration c-1, so nobody reads stage cur^1 any more.
     // Unconditional (the last iteration harmlessly re-copies its own chunk into the idle stage): a DMA issued
     // under a branch makes the compiler drain it at the join, in front of the first fragment read.
@@ -1229,9 +1239,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
         rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + cur * 4);
       }
     }
-    if (!(p.debug_flags & 2)) stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
+    stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
     if (EPI == RE_QKV) __builtin_amdgcn_sched_barrier(0);  // keep those loads up here, ahead of the MFMAs
-    if (LATE && c > 0) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, acc_prev);
+    if (LATE && !FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, acc_prev);
 
     const bool swapped = (EPI != RE_QKV) || (c < p.n_swapped);
     f32x4 acc[2][2];
@@ -1239,9 +1249,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.debug_flags & 4) {
-      acc[0][0][0] = (float)c;
-    } else if (swapped) {
+    if (swapped) {
       rowgemm_chunk_mfma<KS, SPLIT, true>(&sW[cur][lane * 8], a_hi, a_lo, acc);
     } else {
       rowgemm_chunk_mfma<KS, SPLIT, false>(&sW[cur][lane * 8], a_hi, a_lo, acc);
@@ -1254,11 +1262,34 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     } else {
       epilogue(c, cur_tag, acc);
     }
+    if (LATE && !FIRST) {
+      // Scheduling recipe for this iteration: the first k-step's fragment reads, then per MFMA two (bf16x3) or
+      // five (bf16) VALU instructions of the deferred epilogue and, every third (second) MFMA, one fragment read
+      // for the k-step ahead.  An MFMA holds the issue port for ~4 of its 16 cycles; the epilogue's VALU work
+      // fits into the remaining slots instead of running as a block in front of the MFMA phase.
+      constexpr int N_MFMA = KS * 4 * (SPLIT ? 3 : 1);
+      constexpr int N_DS = KS * 2 * PLANES;
+      constexpr int DS_EVERY = SPLIT ? 3 : 2;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * PLANES, 0);
+#pragma unroll
+      for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, SPLIT ? 2 : 5, 0);
+        if (i % DS_EVERY == 0 && i / DS_EVERY < N_DS - 2 * PLANES) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
     __syncthreads();
   };
-  for (int c0 = 0; c0 < p.n_chunks; c0 += 2) {  // even chunk count (checked on the host)
-    iteration(c0, std::integral_constant<int, 0>{});
-    iteration(c0 + 1, std::integral_constant<int, 1>{});
+  // even chunk count (checked on the host).  The first pair is peeled so that the deferred epilogue is
+  // unconditional in the steady-state loop: one basic block per iteration, in which the scheduler is free to
+  // slot the epilogue's VALU work and stores of chunk c-1 between the MFMAs of chunk c.
+  const std::integral_constant<int, 0> even{};
+  const std::integral_constant<int, 1> odd{};
+  iteration(0, even, std::true_type{});
+  iteration(1, odd, std::false_type{});
+  for (int c0 = 2; c0 < p.n_chunks; c0 += 2) {
+    iteration(c0, even, std::false_type{});
+    iteration(c0 + 1, odd, std::false_type{});
   }
   // the host guarantees an even number of chunks, so the last chunk has parity 1
   if (LATE) epilogue(p.n_chunks - 1, std::integral_constant<int, 1>{}, acc_prev);
