@@ -641,7 +641,10 @@ int op_create(const op_config* cfg, op_handle** out) {
   h->split = cfg->precision == OP_PRECISION_BF16X3;
   h->chunk_rows = cfg->chunk_rows > 0 ? align_up(cfg->chunk_rows, ROW_ALIGN) : 262144;  // grids must cover the chip several times over
   h->layers.resize(N);
-  h->row_path = (H <= 256) && (H % 32 == 0) && (I % 32 == 0) && getenv("OPEN_PROVENCE_FORCE_TILED") == nullptr;
+  // H % 64 and I % 32: every row-GEMM streams an EVEN number of 32-feature chunks on each side of the q/k -> v
+  // boundary (H/16 q/k chunks, H/32 v chunks, H/32 out-projection chunks, I/16 Wi chunks) -- rowgemm_kernel's
+  // two-stage loop is unrolled by two.
+  h->row_path = (H <= 256) && (H % 64 == 0) && (I % 32 == 0) && getenv("OPEN_PROVENCE_FORCE_TILED") == nullptr;
 
 #define OP_CREATE_TRY(expr)  \
   do {                       \

@@ -1115,9 +1115,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   // Epilogue of chunk `cc` (compile-time parity PP = cc & 1) from accumulators `av`.  It is issued one iteration
   // LATE -- at the top of the iteration that runs the MFMAs of chunk cc+1 -- so that its stores have a whole MFMA
   // phase to retire before the s_waitcnt vmcnt(0) in front of the next barrier (vmcnt counts stores on CDNA4).
-  auto epilogue = [&](int cc, auto parity_tag, const f32x4 (&av)[2][2]) {
+  auto epilogue = [&](int cc, auto parity_tag, auto sw_tag, const f32x4 (&av)[2][2]) {
     constexpr int PP = decltype(parity_tag)::value;
-    const bool sw = (EPI != RE_QKV) || (cc < p.n_swapped);
+    constexpr bool sw = decltype(sw_tag)::value;  // q/k chunk ("swapped" MFMA orientation) or v chunk
     if (EPI == RE_RESIDUAL) {
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
@@ -1223,46 +1223,39 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   // Unrolled by two so that the LDS stage index is a compile-time constant in each copy: the compiler can
   // then tell the DMA into stage cur^1 from the fragment reads of stage cur and does NOT drain the DMA
   // (s_waitcnt vmcnt(0)) before the first ds_read -- the wait sits only in front of the barrier.
-  // The q/k/v variant needs its registers for the RoPE rows and the half-head hold, so it runs each chunk's
-  // epilogue right away; the other variants defer it by one iteration (see above).
-  constexpr bool LATE = (EPI != RE_QKV);
-  auto iteration = [&](int c, auto cur_tag, auto first_tag) {
+  // Every iteration is ONE basic block: the MFMA orientation of the chunk (SW) and the kind of the deferred
+  // epilogue (SWP: q/k or v for RE_QKV) are compile-time tags, the chunk loop is split at the q/k -> v boundary.
+  constexpr bool LATE = true;
+  auto iteration = [&](int c, auto cur_tag, auto first_tag, auto sw_tag, auto swp_tag) {
     constexpr int cur = decltype(cur_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr bool SW = decltype(sw_tag)::value;
+    constexpr bool SWP = decltype(swp_tag)::value;
     // every wave passed the barrier that ended iteration c-1, so nobody reads stage cur^1 any more.
     // Unconditional (the last iteration harmlessly re-copies its own chunk into the idle stage): a DMA issued
     // under a branch makes the compiler drain it at the join, in front of the first fragment read.
-    if (EPI == RE_QKV) {  // RoPE rows for this chunk's half-head (j = cur); harmless extra loads on v chunks
+    if (EPI == RE_QKV && SWP && !FIRST) {  // RoPE rows for the half-head (j = cur ^ 1) of the chunk finished last
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
-        rope_c[mf] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + cur * 4);
-        rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + cur * 4);
+        rope_c[mf] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + (cur ^ 1) * 4);
+        rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + (cur ^ 1) * 4);
       }
     }
     stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
-    if (EPI == RE_QKV) __builtin_amdgcn_sched_barrier(0);  // keep those loads up here, ahead of the MFMAs
-    if (LATE && !FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, acc_prev);
+    if (EPI == RE_QKV) __builtin_amdgcn_sched_barrier(0);  // keep those loads up here, ahead of the DMA's wait
+    if (!FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag, acc_prev);
 
-    const bool swapped = (EPI != RE_QKV) || (c < p.n_swapped);
     f32x4 acc[2][2];
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (swapped) {
-      rowgemm_chunk_mfma<KS, SPLIT, true>(&sW[cur][lane * 8], a_hi, a_lo, acc);
-    } else {
-      rowgemm_chunk_mfma<KS, SPLIT, false>(&sW[cur][lane * 8], a_hi, a_lo, acc);
-    }
-    if (LATE) {
+    rowgemm_chunk_mfma<KS, SPLIT, SW>(&sW[cur][lane * 8], a_hi, a_lo, acc);
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
+    for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) acc_prev[nf][mf] = acc[nf][mf];
-    } else {
-      epilogue(c, cur_tag, acc);
-    }
-    if (LATE && !FIRST) {
+      for (int mf = 0; mf < 2; ++mf) acc_prev[nf][mf] = acc[nf][mf];
+    if (!FIRST) {
       // Scheduling recipe for this iteration: the first k-step's fragment reads, then per MFMA two (bf16x3) or
       // five (bf16) VALU instructions of the deferred epilogue and, every third (second) MFMA, one fragment read
       // for the k-step ahead.  An MFMA holds the issue port for ~4 of its 16 cycles; the epilogue's VALU work
@@ -1280,19 +1273,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     }
     __syncthreads();
   };
-  // even chunk count (checked on the host).  The first pair is peeled so that the deferred epilogue is
-  // unconditional in the steady-state loop: one basic block per iteration, in which the scheduler is free to
-  // slot the epilogue's VALU work and stores of chunk c-1 between the MFMAs of chunk c.
+  // Even chunk counts on both sides of the q/k -> v boundary (checked on the host).  The first pair is peeled so
+  // that the deferred epilogue is unconditional in the steady-state loops.
   const std::integral_constant<int, 0> even{};
   const std::integral_constant<int, 1> odd{};
-  iteration(0, even, std::true_type{});
-  iteration(1, odd, std::false_type{});
-  for (int c0 = 2; c0 < p.n_chunks; c0 += 2) {
-    iteration(c0, even, std::false_type{});
-    iteration(c0 + 1, odd, std::false_type{});
+  const std::true_type yes{};
+  const std::false_type no{};
+  const int n_sw = (EPI == RE_QKV) ? p.n_swapped : p.n_chunks;
+  iteration(0, even, yes, yes, yes);
+  iteration(1, odd, no, yes, yes);
+  for (int c0 = 2; c0 < n_sw; c0 += 2) {
+    iteration(c0, even, no, yes, yes);
+    iteration(c0 + 1, odd, no, yes, yes);
   }
-  // the host guarantees an even number of chunks, so the last chunk has parity 1
-  if (LATE) epilogue(p.n_chunks - 1, std::integral_constant<int, 1>{}, acc_prev);
+  if (EPI == RE_QKV) {
+    iteration(n_sw, even, no, no, yes);  // first v chunk; finishes the last k chunk
+    iteration(n_sw + 1, odd, no, no, no);
+    for (int c0 = n_sw + 2; c0 < p.n_chunks; c0 += 2) {
+      iteration(c0, even, no, no, no);
+      iteration(c0 + 1, odd, no, no, no);
+    }
+    epilogue(p.n_chunks - 1, odd, no, acc_prev);
+  } else {
+    epilogue(p.n_chunks - 1, odd, yes, acc_prev);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
