@@ -262,6 +262,8 @@ template <int EPI, int PRO>
 int launch_rowgemm(Launcher& L, int kind, const RowGemmParams& p, int hidden, int r_pad, bool split) {
   OP_TRY(L.begin(kind));
   const dim3 grid((unsigned)(r_pad / ROW_BM));
+  // 4 waves x 32 rows.  (rowgemm_kernel also compiles as 8 waves x 16 rows = 4 waves per SIMD at <= 128 VGPRs;
+  // measured on MI355X it is equal on the q/k/v kernel and 10 % slower on the GeGLU kernel, which spills.)
   const dim3 block(256);
   const int ks = hidden / 32;
 #define OPK_ROW_LAUNCH(KS_)                                                                           \

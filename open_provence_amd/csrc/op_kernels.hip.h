@@ -823,9 +823,9 @@ __device__ __forceinline__ void pack8(const float v[8], bf16x8& hi, bf16x8& lo) 
 // One weight chunk (32 output features x K) against this wave's 32 rows: 2 x 2 accumulators, K/32 k-steps of
 // 12 (split) or 4 MFMAs.  (hipcc hoists the fragment reads one k-step ahead of their MFMAs by itself; an explicit
 // register double buffer only cost 16 VGPRs.)
-template <int KS, bool SPLIT, bool SWAPPED>
-__device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const bf16x8 (&a_hi)[2][KS],
-                                                   const bf16x8 (&a_lo)[2][KS], f32x4 (&acc)[2][2]) {
+template <int KS, int MF, bool SPLIT, bool SWAPPED>
+__device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const bf16x8 (&a_hi)[MF][KS],
+                                                   const bf16x8 (&a_lo)[MF][KS], f32x4 (&acc)[2][MF]) {
   constexpr int PLANES = SPLIT ? 2 : 1;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -845,7 +845,7 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const 
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
+        for (int mf = 0; mf < MF; ++mf) {
           const bf16x8 w = term == 0 ? wl[nf] : wh[nf];
           const bf16x8 a = term == 1 ? a_lo[mf][ks] : a_hi[mf][ks];
           acc[nf][mf] = SWAPPED ? mfma16(w, a, acc[nf][mf]) : mfma16(a, w, acc[nf][mf]);
@@ -856,7 +856,12 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const 
 }
 
 template <int KS, int EPI, int PRO, bool SPLIT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel(RowGemmParams p) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void rowgemm_kernel(RowGemmParams p) {
+  // A block is ROW_BM = 128 rows: 4 waves x 32 rows (MF = 2 row fragments per wave, <= 256 VGPRs, 2 waves per
+  // SIMD) or 8 waves x 16 rows (MF = 1, <= 128 VGPRs, 4 waves per SIMD: twice the weight-fragment LDS reads per
+  // MFMA, twice the waves to cover waits).
+  constexpr int MF = 8 / WAVES;
+  static_assert(MF == 1 || MF == 2, "4 or 8 waves per block");
   constexpr int PLANES = SPLIT ? 2 : 1;
   constexpr int K = KS * 32;
   constexpr int CHUNK_SRC = KS * 2 * 1024;        // elements per packed chunk in global memory
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
   const int l15 = lane & 15;
   const int g = lane >> 4;
-  const int m0 = blockIdx.x * (WAVES * 32) + wave * 32;
+  const int m0 = blockIdx.x * ROW_BM + wave * (16 * MF);
 
   // ---- weight streaming: global -> LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction) --
   // Stage layout = [ks][plane][frag][512] = a sequence of 1 KiB pieces; wave w copies pieces w, w+4, ...
@@ -891,7 +896,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
           (__attribute__((address_space(3))) void*)(&sW[stage][elem]), 16, 0, 0);
     }
   };
-  bf16x8 a_hi[2][KS], a_lo[2][KS];
+  bf16x8 a_hi[MF][KS], a_lo[MF][KS];
   if (PRO == RP_KSTREAM) {
     // ---- fused phase 1: x_new[32 rows, H] = x + A1[32 rows, K1] W1[H, K1]^T, K1 streamed ----------------
     // Same structure as kstream_gemm_kernel (one [H x 32] weight slab per k-step by DMA, A1 fragments straight
@@ -914,28 +919,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     };
     const int nks1 = p.k1_steps;
     const u16* a_base0 = p.a1_fp + ((size_t)(m0 >> 4) * nks1 * 2) * 512 + lane * 8;
-    const u16* a_base1 = a_base0 + (size_t)nks1 * 2 * 512;
-    bf16x8 an_hi[2], an_lo[2];
+    const size_t a_block = (size_t)nks1 * 2 * 512;  // elements per 16-row block of A1
+    bf16x8 an_hi[MF], an_lo[MF];
     auto load_a1 = [&](int ks1) {
-      an_hi[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks1 * 1024);
-      an_hi[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks1 * 1024);
-      if (SPLIT) {
-        an_lo[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks1 * 1024 + 512);
-        an_lo[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks1 * 1024 + 512);
-      } else {
-        an_lo[0] = an_hi[0];
-        an_lo[1] = an_hi[1];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        an_hi[mf] = *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks1 * 1024);
+        an_lo[mf] = SPLIT ? *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks1 * 1024 + 512) : an_hi[mf];
       }
     };
-    f32x4 acc1[NF1][2];
+    f32x4 acc1[NF1][MF];
 #pragma unroll
     for (int nf = 0; nf < NF1; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) acc1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
     stage_slab(0, 0);
     load_a1(0);
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
+    for (int mf = 0; mf < MF; ++mf) {
       asm volatile("" : "+v"(an_hi[mf]));
       asm volatile("" : "+v"(an_lo[mf]));
     }
@@ -944,9 +945,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
       constexpr int cur = decltype(cur_tag)::value;
       const int kn = ks1 + 1 < nks1 ? ks1 + 1 : ks1;
       stage_slab(kn, cur ^ 1);
-      bf16x8 c_hi[2], c_lo[2];
+      bf16x8 c_hi[MF], c_lo[MF];
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
+      for (int mf = 0; mf < MF; ++mf) {
         c_hi[mf] = an_hi[mf];
         c_lo[mf] = an_lo[mf];
       }
@@ -958,13 +959,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
         if (SPLIT) {
           const bf16x8 wl = lds_frag(&sW[cur][(NF1 + nf) * 512 + lane * 8]);
 #pragma unroll
-          for (int mf = 0; mf < 2; ++mf) {
+          for (int mf = 0; mf < MF; ++mf) {
             acc1[nf][mf] = mfma16(wl, c_hi[mf], acc1[nf][mf]);
             acc1[nf][mf] = mfma16(wh, c_lo[mf], acc1[nf][mf]);
           }
         }
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) acc1[nf][mf] = mfma16(wh, c_hi[mf], acc1[nf][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(wh, c_hi[mf], acc1[nf][mf]);
       }
       __syncthreads();
     };
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
 
     // ---- transition: residual add, store the new hidden state, LayerNorm, split -> fragments --------------
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
+    for (int mf = 0; mf < MF; ++mf) {
       float* xrow = p.x_io + (size_t)(m0 + mf * 16 + l15) * K + g * 8;
       float sum = 0.f;
 #pragma unroll
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
 
   // ---- prologue: this wave's 32 rows as fragments ---------------------------------------------
 #pragma unroll
-  for (int mf = 0; mf < 2; ++mf) {
+  for (int mf = 0; mf < MF; ++mf) {
     if (PRO == RP_KSTREAM) break;
     const size_t row = (size_t)(m0 + mf * 16 + l15);
     if (PRO == RP_PLANES) {  // fragment-packed input: piece (row block, k-step, plane), 16 bytes per lane
@@ -1088,12 +1089,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   // RE_QKV: RoPE rows of this lane's two tokens: cos/sin [pos][8g + 4j .. +3] for the half-head j of the chunk
   // being computed are fetched at the top of each q/k iteration (before the DMA is issued, so the epilogue can
   // wait for them with a counted vmcnt) and used after its 96 MFMAs.
-  const float* rope_c_row[2];
-  const float* rope_s_row[2];
-  f32x4 rope_c[2], rope_s[2];
+  const float* rope_c_row[MF];
+  const float* rope_s_row[MF];
+  f32x4 rope_c[MF], rope_s[MF];
   if (EPI == RE_QKV) {
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
+    for (int mf = 0; mf < MF; ++mf) {
       int pos = p.row_pos[m0 + mf * 16 + l15];
       pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
       rope_c_row[mf] = p.rope_cos + (size_t)pos * ROPE_HALF + g * 8;
@@ -1104,23 +1105,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
   __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
 
   // ---- stream the weight chunks ---------------------------------------------------------------
-  uint2 hold_hi[2], hold_lo[2];  // RE_GEGLU: first half of a chunk pair
-  uint2 qk_hold[2][4];           // RE_QKV: first half-head of a q/k chunk pair: [mf][d<32 hi, lo, d>=32 hi, lo]
+  uint2 hold_hi[MF], hold_lo[MF];  // RE_GEGLU: first half of a chunk pair
+  uint2 qk_hold[MF][4];            // RE_QKV: first half-head of a q/k chunk pair: [mf][d<32 hi, lo, d>=32 hi, lo]
 #pragma unroll
-  for (int mf = 0; mf < 2; ++mf)
+  for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
     for (int t = 0; t < 4; ++t) qk_hold[mf][t] = make_uint2(0u, 0u);
 #pragma unroll
-  for (int mf = 0; mf < 2; ++mf) hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
+  for (int mf = 0; mf < MF; ++mf) hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
   // Epilogue of chunk `cc` (compile-time parity PP = cc & 1) from accumulators `av`.  It is issued one iteration
   // LATE -- at the top of the iteration that runs the MFMAs of chunk cc+1 -- so that its stores have a whole MFMA
   // phase to retire before the s_waitcnt vmcnt(0) in front of the next barrier (vmcnt counts stores on CDNA4).
-  auto epilogue = [&](int cc, auto parity_tag, auto sw_tag, const f32x4 (&av)[2][2]) {
+  auto epilogue = [&](int cc, auto parity_tag, auto sw_tag, const f32x4 (&av)[2][MF]) {
     constexpr int PP = decltype(parity_tag)::value;
     constexpr bool sw = decltype(sw_tag)::value;  // q/k chunk ("swapped" MFMA orientation) or v chunk
     if (EPI == RE_RESIDUAL) {
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
+      for (int mf = 0; mf < MF; ++mf) {
         const size_t row = (size_t)(m0 + mf * 16 + l15);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
@@ -1139,7 +1140,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
       // pair the lane owns the 8 consecutive k-values of ITS OWN fragment slot for k-step t of the next GEMM
       // and the wave stores one contiguous 1 KiB piece per (16-row block, plane).
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
+      for (int mf = 0; mf < MF; ++mf) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(av[0][mf][r]) * av[1][mf][r];
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
         // head_dim^-0.5 * log2(e): the fragment-packed attention kernel exponentiates with exp2
         const float qscale = is_q ? 0.125f * 1.44269504088896340736f : 1.0f;
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
+        for (int mf = 0; mf < MF; ++mf) {
           // half-head index j = cq & 1 equals the chunk parity PP (even number of chunks per block)
           const f32x4 c4 = rope_c[mf];
           const f32x4 s4 = rope_s[mf];
@@ -1193,32 +1194,40 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
           }
         }
       } else {
-        // C rows = tokens 4g + r of block mf, column = feature slot l15: the two row blocks of this wave's
-        // 32-row group are the two halves of the 8 key slots of one v^T fragment lane.
+        // C rows = tokens 4g + r of block mf, column = feature slot l15: the two 16-row blocks of a 32-row
+        // group are the two halves of the 8 key slots of one v^T fragment lane.  With 32 rows per wave the lane
+        // stores all 16 bytes, with 16 rows per wave the 8 bytes of its half.
         const int cv = cc - p.n_swapped;
         const size_t head = (size_t)(cv >> 1);
         const size_t tb = (size_t)(m0 >> 5);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
-          const float v0[4] = {av[nf][0][0], av[nf][0][1], av[nf][0][2], av[nf][0][3]};
-          const float v1[4] = {av[nf][1][0], av[nf][1][1], av[nf][1][2], av[nf][1][3]};
-          uint2 h0, l0, h1, l1;
-          split4<SPLIT>(v0, h0, l0);
-          split4<SPLIT>(v1, h1, l1);
           const size_t n = (size_t)((cv & 1) * 2 + nf);
           const size_t off = (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + n) * 512 + lane * 8;
-          *reinterpret_cast<uint4*>(p.o2_hi + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-          if (SPLIT) *reinterpret_cast<uint4*>(p.o2_hi + off + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          const float v0[4] = {av[nf][0][0], av[nf][0][1], av[nf][0][2], av[nf][0][3]};
+          uint2 h0, l0;
+          split4<SPLIT>(v0, h0, l0);
+          if (MF == 2) {
+            const float v1[4] = {av[nf][MF - 1][0], av[nf][MF - 1][1], av[nf][MF - 1][2], av[nf][MF - 1][3]};
+            uint2 h1, l1;
+            split4<SPLIT>(v1, h1, l1);
+            *reinterpret_cast<uint4*>(p.o2_hi + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            if (SPLIT) *reinterpret_cast<uint4*>(p.o2_hi + off + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          } else {
+            const int half = ((m0 >> 4) & 1) * 4;
+            *reinterpret_cast<uint2*>(p.o2_hi + off + half) = h0;
+            if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + off + 2048 + half) = l0;
+          }
         }
       }
     }
   };
 
-  f32x4 acc_prev[2][2];
+  f32x4 acc_prev[2][MF];
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) acc_prev[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Unrolled by two so that the LDS stage index is a compile-time constant in each copy: the compiler can
   // then tell the DMA into stage cur^1 from the fragment reads of stage cur and does NOT drain the DMA
@@ -1236,7 +1245,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     // under a branch makes the compiler drain it at the join, in front of the first fragment read.
     if (EPI == RE_QKV && SWP && !FIRST) {  // RoPE rows for the half-head (j = cur ^ 1) of the chunk finished last
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
+      for (int mf = 0; mf < MF; ++mf) {
         rope_c[mf] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + (cur ^ 1) * 4);
         rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + (cur ^ 1) * 4);
       }
@@ -1245,30 +1254,31 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void rowgemm_kernel
     if (EPI == RE_QKV) __builtin_amdgcn_sched_barrier(0);  // keep those loads up here, ahead of the DMA's wait
     if (!FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag, acc_prev);
 
-    f32x4 acc[2][2];
+    f32x4 acc[2][MF];
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rowgemm_chunk_mfma<KS, SPLIT, SW>(&sW[cur][lane * 8], a_hi, a_lo, acc);
+      for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rowgemm_chunk_mfma<KS, MF, SPLIT, SW>(&sW[cur][lane * 8], a_hi, a_lo, acc);
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) acc_prev[nf][mf] = acc[nf][mf];
+      for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = acc[nf][mf];
     if (!FIRST) {
       // Scheduling recipe for this iteration: the first k-step's fragment reads, then per MFMA two (bf16x3) or
       // five (bf16) VALU instructions of the deferred epilogue and, every third (second) MFMA, one fragment read
       // for the k-step ahead.  An MFMA holds the issue port for ~4 of its 16 cycles; the epilogue's VALU work
       // fits into the remaining slots instead of running as a block in front of the MFMA phase.
-      constexpr int N_MFMA = KS * 4 * (SPLIT ? 3 : 1);
+      constexpr int N_MFMA = KS * 2 * MF * (SPLIT ? 3 : 1);
       constexpr int N_DS = KS * 2 * PLANES;
-      constexpr int DS_EVERY = SPLIT ? 3 : 2;
+      constexpr int DS_LATE = N_DS - 2 * PLANES;  // reads placed between the MFMAs, spread evenly
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * PLANES, 0);
 #pragma unroll
       for (int i = 0; i < N_MFMA; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, SPLIT ? 2 : 5, 0);
-        if (i % DS_EVERY == 0 && i / DS_EVERY < N_DS - 2 * PLANES) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (((i + 1) * DS_LATE) / N_MFMA - (i * DS_LATE) / N_MFMA == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (((i + 1) * DS_LATE) / N_MFMA - (i * DS_LATE) / N_MFMA == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
     }
     __syncthreads();
@@ -1727,31 +1737,39 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
     kt_hi = hi_t < kt_hi ? hi_t : kt_hi;
   }
 
-  // DMA one key tile: wave w copies pieces w, w+4, ... of the stage [K: m, ks, plane | V: t, plane, n]
+  // DMA one key tile: wave w copies pieces w, w+4, ... of the stage [K: m, ks, plane | V: t, plane, n].
+  // Everything about a piece except the tile's row block is wave-constant and computed once, in 32-bit element
+  // offsets (the buffers are < 2^31 elements): per tile a piece costs one clamp, one multiply and one add.
   const int k_rb_max = (p.r_pad >> 4) - 1, v_tb_max = (p.r_pad >> 5) - 1;
+  const int k_stride = kbn * 1024;  // elements per 16-row block of k
+  // K pieces of this wave: row block m = k_m0 + k_mstep * u, fixed (k-step, plane)
+  const int k_m0 = SPLIT ? 0 : (wave >> 1), k_mstep = SPLIT ? 1 : 2;
+  const int k_const = SPLIT ? ((head * 2 + (wave >> 1)) * 2 + (wave & 1)) * 512 : (head * 2 + (wave & 1)) * 1024;
+  // V^T pieces of this wave: n = wave; (t, plane) = (u >> 1, u & 1) when split, (u, 0) otherwise
+  const int v_const = head * (p.r_pad >> 5) * 4096 + wave * 512;
   auto stage_tile = [&](int kt, int stage) {
     // A tile may reach past the last computed row (the last sequence need not fill its final 64-key tile): such
     // pieces are clamped onto the last valid one -- their keys are masked, they only have to be finite.
     const int k_rb0 = (r0 + kt * ATT_BK) >> 4;
     const int v_tb0 = (r0 + kt * ATT_BK) >> 5;
 #pragma unroll
-    for (int u = 0; u < (K_PIECES + V_PIECES) / 4; ++u) {
-      const int piece = wave + 4 * u;  // wave-uniform
-      const u16* src;
-      if (piece < K_PIECES) {
-        const int m = piece / (2 * PLANES), rem = piece % (2 * PLANES);
-        const int ks = rem / PLANES, plane = rem % PLANES;
-        const size_t rb = (size_t)(k_rb0 + m < k_rb_max ? k_rb0 + m : k_rb_max);
-        src = p.k_fp + ((rb * kbn + head * 2 + ks) * 2 + plane) * 512;
-      } else {
-        const int pv = piece - K_PIECES;
-        const int t = pv / (4 * PLANES), rem = pv % (4 * PLANES);
-        const int plane = rem / 4, n = rem % 4;
-        const size_t tb = (size_t)(v_tb0 + t < v_tb_max ? v_tb0 + t : v_tb_max);
-        src = p.vt_fp + ((((size_t)head * (p.r_pad >> 5) + tb) * 2 + plane) * 4 + n) * 512;
-      }
+    for (int u = 0; u < K_PIECES / 4; ++u) {
+      int rb = k_rb0 + k_m0 + k_mstep * u;
+      rb = rb < k_rb_max ? rb : k_rb_max;
+      const u16* src = p.k_fp + (unsigned)(rb * k_stride + k_const);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
-                                       (__attribute__((address_space(3))) void*)(&sT[stage][piece * 512]), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(&sT[stage][(wave + 4 * u) * 512]), 16, 0,
+                                       0);
+    }
+#pragma unroll
+    for (int u = 0; u < V_PIECES / 4; ++u) {
+      const int t = SPLIT ? (u >> 1) : u, plane = SPLIT ? (u & 1) : 0;
+      int tb = v_tb0 + t;
+      tb = tb < v_tb_max ? tb : v_tb_max;
+      const u16* src = p.vt_fp + (unsigned)(tb * 4096 + plane * 2048 + v_const);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + lane * 8),
+          (__attribute__((address_space(3))) void*)(&sT[stage][(K_PIECES + wave + 4 * u) * 512]), 16, 0, 0);
     }
   };
 
@@ -1797,18 +1815,24 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
 
       if (!all_valid) {
         // masked scores become -3e30 (below the running-max initial value -1e30): 2^(masked - max) underflows to
-        // exactly 0 even when the whole tile is masked for a query; selects only, no branches.
-        // element (m, r) of this lane: key = kbase + 16m + 4g + r
+        // exactly 0 even when the whole tile is masked for a query.  A query sees the keys [lo, hi] =
+        // [max(q - win, 0), min(q + win, len - 1)]; element (m, r) of this lane is key kbase + 4g + (16m + r), so
+        // with lo_rel = lo - kbase - 4g the test is one unsigned compare of the constant (16m + r) - lo_rel
+        // against hi - lo (an empty interval is moved out of reach).
 #pragma unroll
         for (int qf = 0; qf < 2; ++qf) {
           const int qpos = qbase + 16 * qf + l15;
+          int lo = qpos - win, hi = qpos + win;
+          lo = lo > 0 ? lo : 0;
+          hi = hi < len - 1 ? hi : len - 1;
+          const int span = hi - lo;
+          const int lo_rel = span >= 0 ? lo - kbase - 4 * g : (1 << 29);
+          const unsigned uspan = span >= 0 ? (unsigned)span : 0u;
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int key = kbase + 16 * m + 4 * g + r;
-              const int d = key - qpos;
-              const bool ok = (key < len) & (d <= win) & (d >= -win);
+              const bool ok = (unsigned)(16 * m + r - lo_rel) <= uspan;
               sacc[m][qf][r] = ok ? sacc[m][qf][r] : -3e30f;
             }
         }
@@ -1824,26 +1848,35 @@ __global__ __launch_bounds__(256, 2) void attn_fp_kernel(AttnFpParams p) {
           for (int r = 0; r < 4; ++r) tile_max = fmaxf(tile_max, sacc[m][qf][r]);
         tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 16, 64));
         tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
-        const float m_new = fmaxf(m_run[qf], tile_max);
-        const float alpha = exp2f(m_run[qf] - m_new);
-        m_run[qf] = m_new;
+        // Lazy reference: the exponent reference m_run only moves when this tile's maximum exceeds it by more
+        // than 2^6 (p stays <= 64, harmless in fp32 and in the hi/lo split), and the 16 accumulator rescales run
+        // only in the tiles where some query of the wave moved -- a wave-uniform branch, rare after the first tile.
+        const bool moved = tile_max > m_run[qf] + 6.0f;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+          const float m_new = moved ? tile_max : m_run[qf];
+          const float alpha = __builtin_amdgcn_exp2f(m_run[qf] - m_new);
+          m_run[qf] = m_new;
+          l_run[qf] *= alpha;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            oacc[n][qf][0] *= alpha;
+            oacc[n][qf][1] *= alpha;
+            oacc[n][qf][2] *= alpha;
+            oacc[n][qf][3] *= alpha;
+          }
+        }
+        const float m_ref = m_run[qf];
         float psum = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = exp2f(sacc[m][qf][r] - m_new);
+            // raw v_exp_f32: the argument is <= 6 and a result below 2^-126 may flush to zero
+            const float e = __builtin_amdgcn_exp2f(sacc[m][qf][r] - m_ref);
             sacc[m][qf][r] = e;
             psum += e;
           }
-        l_run[qf] = l_run[qf] * alpha + psum;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          oacc[n][qf][0] *= alpha;
-          oacc[n][qf][1] *= alpha;
-          oacc[n][qf][2] *= alpha;
-          oacc[n][qf][3] *= alpha;
-        }
+        l_run[qf] += psum;
         // lane slot e < 4 -> key 32t + 4g + e (piece m = 2t), e >= 4 -> key 32t + 16 + 4g + (e-4) (piece 2t+1):
         // the order the QKV epilogue stored v^T in
 #pragma unroll
