@@ -362,7 +362,10 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
 
   auto attention = [&](bool is_global) -> int {
     OP_TRY(L.begin(is_global ? PK_ATTN_GLOBAL : PK_ATTN_LOCAL));
-    const int q_blocks_fp = (max_len + ATT_FP_BQ - 1) / ATT_FP_BQ;
+    // fragment-packed attention: 8 waves (256 queries per block) once sequences are longer than 128 tokens
+    const int att_waves = getenv("OPEN_PROVENCE_ATT_WAVES") ? atoi(getenv("OPEN_PROVENCE_ATT_WAVES")) : (max_len > 128 ? 8 : 4);
+    const int att_bq = att_waves * 32;
+    const int q_blocks_fp = (max_len + att_bq - 1) / att_bq;
     const dim3 grid(h->row_path ? (unsigned)q_blocks_fp : (unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
     const int window = is_global ? -1 : h->cfg.local_attention / 2;
     if (h->row_path) {
@@ -377,10 +380,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.H = H;
       ap.r_pad = r_pad;
       ap.window = window;
-      if (split)
-        hipLaunchKernelGGL((attn_fp_kernel<true>), grid, dim3(256), 0, st, ap);
+      if (split && att_waves == 8)
+        hipLaunchKernelGGL((attn_fp_kernel<true, 8>), grid, dim3(512), 0, st, ap);
+      else if (split)
+        hipLaunchKernelGGL((attn_fp_kernel<true, 4>), grid, dim3(256), 0, st, ap);
+      else if (att_waves == 8)
+        hipLaunchKernelGGL((attn_fp_kernel<false, 8>), grid, dim3(512), 0, st, ap);
       else
-        hipLaunchKernelGGL((attn_fp_kernel<false>), grid, dim3(256), 0, st, ap);
+        hipLaunchKernelGGL((attn_fp_kernel<false, 4>), grid, dim3(256), 0, st, ap);
     } else {
       AttnParams ap;
       ap.q_hi = ws.q_hi;
