@@ -855,13 +855,13 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const 
   }
 }
 
-template <int KS, int EPI, int PRO, bool SPLIT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void rowgemm_kernel(RowGemmParams p) {
-  // A block is ROW_BM = 128 rows: 4 waves x 32 rows (MF = 2 row fragments per wave, <= 256 VGPRs, 2 waves per
-  // SIMD) or 8 waves x 16 rows (MF = 1, <= 128 VGPRs, 4 waves per SIMD: twice the weight-fragment LDS reads per
-  // MFMA, twice the waves to cover waits).
-  constexpr int MF = 8 / WAVES;
-  static_assert(MF == 1 || MF == 2, "4 or 8 waves per block");
+template <int KS, int EPI, int PRO, bool SPLIT, int WAVES, int MF = 2>
+__global__ __launch_bounds__(WAVES * 64, MF == 1 ? 4 : 2) void rowgemm_kernel(RowGemmParams p) {
+  // A block is WAVES x MF x 16 rows; the library launches 4 waves x 2 fragments = 128 rows, two blocks per CU.
+  // Measured alternatives on MI355X (xsmall, 256 x 512): 8 waves x 2 (256 rows, one block per CU, half the DMA
+  // instructions and L2 -> LDS traffic per row) is within +-2 % on both fused kernels; 8 waves x 1 (16 rows per wave,
+  // <= 128 VGPRs, 4 waves per SIMD, twice the fragment reads per MFMA) is equal on q/k/v and 10 % slower on GeGLU.
+  static_assert(MF == 1 || MF == 2, "one or two 16-row fragments per wave");
   constexpr int PLANES = SPLIT ? 2 : 1;
   constexpr int K = KS * 32;
   constexpr int CHUNK_SRC = KS * 2 * 1024;        // elements per packed chunk in global memory
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void rowgemm_kernel
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
   const int l15 = lane & 15;
   const int g = lane >> 4;
-  const int m0 = blockIdx.x * ROW_BM + wave * (16 * MF);
+  const int m0 = blockIdx.x * (WAVES * 16 * MF) + wave * (16 * MF);
 
   // ---- weight streaming: global -> LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction) --
   // Stage layout = [ks][plane][frag][512] = a sequence of 1 KiB pieces; wave w copies pieces w, w+4, ...
