@@ -1,0 +1,231 @@
+// Microbenchmark (measurement aid, not product code): the steady-state loop of the row-stationary GEMM
+// -- A operand in registers (32 rows x K=256, hi/lo planes), one 32-feature weight chunk (32 KiB) per iteration
+// streamed global -> LDS by DMA into a two-stage ring, one block barrier per chunk -- built twice:
+//   variant 0: v_mfma_f32_16x16x32_bf16  (96 MFMAs per chunk per wave, as open_provence_amd's rowgemm_kernel)
+//   variant 1: v_mfma_f32_32x32x16_bf16  (48 MFMAs per chunk per wave)
+// with a configurable amount of dummy epilogue VALU work per chunk (a Horner chain per accumulator value) and
+// switches for the DMA and the barrier.  Prints ms and the bf16 TFLOP/s of the MFMA stream for each case.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o mfma_loop mfma_loop.hip && ./mfma_loop
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+#define CHECK(x)                                                                   \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));               \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+constexpr int KS = 8;                  // K = 256
+constexpr int STAGE = KS * 2 * 1024;   // u16 elements per stage: [ks][plane][2 fragments][512]
+
+__device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// STORE: 0 = no global stores; 1 = the epilogue stores 2 x 16 B per lane per chunk and the iteration ends with
+// __syncthreads() (fence: s_waitcnt vmcnt(0) covers the just-issued stores); 2 = s_waitcnt vmcnt(0) BEFORE the
+// stores (only the weight DMA issued at the top of the iteration is outstanding then) and a bare s_barrier.
+template <int VARIANT, int HORNER, bool DMA, bool BARRIER, bool LDS = true, int STORE = 0, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void loop_kernel(const u16* __restrict__ w, int n_chunks, float* __restrict__ sink,
+                                                      uint4* __restrict__ out) {
+  // OCC = 1: pad the static LDS to 96 KiB so that only one block fits a CU (one wave per SIMD)
+  __shared__ __attribute__((aligned(16))) u16 sW[OCC == 1 ? 3 : 2][STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  bf16x8 a_hi[2][KS], a_lo[2][KS];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u16* src = w + ((size_t)(blockIdx.x & 7) * 16 + mf * 8 + ks) * 1024 + lane * 8;
+      a_hi[mf][ks] = *reinterpret_cast<const bf16x8*>(src);
+      a_lo[mf][ks] = *reinterpret_cast<const bf16x8*>(src + 512);
+    }
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("" : "+v"(a_hi[mf][ks]));
+      asm volatile("" : "+v"(a_lo[mf][ks]));
+    }
+
+  auto stage_chunk = [&](int chunk, int stage) {
+    const u16* src = w + (size_t)chunk * STAGE;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int piece = wave + 4 * u;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+    }
+  };
+  stage_chunk(0, 0);
+  stage_chunk(1, 1);
+  __syncthreads();
+
+  float acc_prev[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc_prev[i] = 0.f;
+  float total = 0.f;
+  // accumulators persist over the chunks (never re-zeroed), so no chunk's MFMAs are dead code
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x16 acc2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+
+  auto iteration = [&](int c, auto cur_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
+    if (DMA) stage_chunk(c + 1 < n_chunks ? c + 1 : c, cur ^ 1);
+    // dummy epilogue of the previous chunk: HORNER dependent FMAs per accumulator value
+    if (HORNER > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float x = acc_prev[i], pz = 0.3f;
+#pragma unroll
+        for (int t = 0; t < HORNER; ++t) pz = fmaf(pz, x, 0.25f + 0.125f * t);
+        total += pz;
+        acc_prev[i] = pz;
+      }
+    }
+    uint4 pend0, pend1;
+    if (STORE > 0) {
+      pend0 = make_uint4(__float_as_uint(acc_prev[0]), __float_as_uint(acc_prev[1]), __float_as_uint(acc_prev[2]), __float_as_uint(acc_prev[3]));
+      pend1 = make_uint4(__float_as_uint(acc_prev[4]), __float_as_uint(acc_prev[5]), __float_as_uint(acc_prev[6]), __float_as_uint(acc_prev[7]));
+    }
+    uint4* dst = out + ((size_t)(blockIdx.x * 4 + wave) * n_chunks + c) * 128 + lane;
+    if (STORE == 1) {
+      dst[0] = pend0;
+      dst[64] = pend1;
+    }
+    const u16* st = &sW[cur][lane * 8];
+    if (VARIANT == 0) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 wh[2], wl[2];
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          wh[nf] = LDS ? lds_frag(st + (ks * 2) * 1024 + nf * 512) : a_hi[nf][(ks + 1) % KS];
+          wl[nf] = LDS ? lds_frag(st + (ks * 2 + 1) * 1024 + nf * 512) : a_lo[nf][(ks + 1) % KS];
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+              const bf16x8 wv = term == 0 ? wl[nf] : wh[nf];
+              const bf16x8 av = term == 1 ? a_lo[mf][ks] : a_hi[mf][ks];
+              acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, av, acc[nf][mf], 0, 0, 0);
+            }
+      }
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_prev[(nf * 2 + mf) * 4 + r] = acc[nf][mf][r];
+    } else {
+      // 32x32x16: the same registers reinterpreted as 16 k-steps of 16 (the values are arbitrary): per k-step one
+      // hi and one lo weight fragment (1 KiB each), three MFMAs onto two alternating accumulators
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const bf16x8 wh = LDS ? lds_frag(st + kk * 1024) : a_hi[(kk + 1) & 1][((kk + 1) >> 1) % KS];
+        const bf16x8 wl = LDS ? lds_frag(st + kk * 1024 + 512) : a_lo[(kk + 1) & 1][((kk + 1) >> 1) % KS];
+        const bf16x8 ah = a_hi[kk & 1][kk >> 1], al = a_lo[kk & 1][kk >> 1];
+        // the two accumulators strictly alternate: 0 1 0 | 1 0 1 | ...
+        const int x = kk & 1;
+        acc2[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc2[x], 0, 0, 0);
+        acc2[x ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc2[x ^ 1], 0, 0, 0);
+        acc2[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc2[x], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_prev[r] = acc2[0][r] + acc2[1][r];
+    }
+    if (BARRIER && STORE == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight DMA issued at the top; last iteration's stores
+      dst[0] = pend0;
+      dst[64] = pend1;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (BARRIER) {
+      __syncthreads();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  for (int c0 = 0; c0 < n_chunks; c0 += 2) {
+    iteration(c0, std::integral_constant<int, 0>{});
+    iteration(c0 + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) total += acc_prev[i];
+  if (total == 123.456f) sink[tid] = total;
+}
+
+template <int VARIANT, int HORNER, bool DMA, bool BARRIER, bool LDS = true, int STORE = 0, int OCC = 2>
+void run(const char* label, const u16* w, float* sink, int n_chunks, int blocks) {
+  static uint4* out = nullptr;
+  if (!out) CHECK(hipMalloc(&out, (size_t)blocks * 4 * n_chunks * 128 * sizeof(uint4)));
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((loop_kernel<VARIANT, HORNER, DMA, BARRIER, LDS, STORE, OCC>), dim3(blocks), dim3(256), 0, 0, w, n_chunks, sink, out);
+  CHECK(hipEventRecord(a, 0));
+  const int reps = 20;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((loop_kernel<VARIANT, HORNER, DMA, BARRIER, LDS, STORE, OCC>), dim3(blocks), dim3(256), 0, 0, w, n_chunks, sink, out);
+  CHECK(hipEventRecord(b, 0));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  ms /= reps;
+  // MFMA flops: rows (blocks * 128) x 32 features x K 256 x 2 x 3 terms per chunk
+  const double flops = (double)blocks * 128 * 32 * 256 * 2 * 3 * n_chunks;
+  printf("%-58s %8.3f ms  %7.1f TFLOP/s (MFMA stream)\n", label, ms, flops / ms * 1e-9);
+}
+
+int main() {
+  const int n_chunks = 64, blocks = 1024;
+  std::vector<u16> host((size_t)n_chunks * STAGE);
+  for (size_t i = 0; i < host.size(); ++i) host[i] = (u16)(0x3c00 + (i * 2654435761u >> 24));  // ~0.0078..0.03
+  u16* w;
+  float* sink;
+  CHECK(hipMalloc(&w, host.size() * 2));
+  CHECK(hipMalloc(&sink, 4096));
+  CHECK(hipMemcpy(w, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+  printf("1024 blocks x 4 waves x 32 rows, K=256 bf16x3, 64 chunks of 32 features (one Wi GEMM of ModernBERT-xsmall)\n");
+#define CASES(V, NAME)                                                                        \
+  run<V, 0, false, false, false>(NAME "  registers only (no LDS reads)     ", w, sink, n_chunks, blocks); \
+  run<V, 0, false, false, false>(NAME "  registers only (no LDS reads) again", w, sink, n_chunks, blocks); \
+  run<V, 8, false, false, false>(NAME "  registers only, epilogue 16x8 fma ", w, sink, n_chunks, blocks); \
+  run<V, 0, false, false>(NAME "  no dma, no barrier  epilogue 0", w, sink, n_chunks, blocks);     \
+  run<V, 0, true, false>(NAME "  dma,    no barrier  epilogue 0", w, sink, n_chunks, blocks);      \
+  run<V, 0, true, true>(NAME "  dma,    barrier     epilogue 0", w, sink, n_chunks, blocks);       \
+  run<V, 2, true, true>(NAME "  dma,    barrier     epilogue 16x2 fma", w, sink, n_chunks, blocks); \
+  run<V, 4, true, true>(NAME "  dma,    barrier     epilogue 16x4 fma", w, sink, n_chunks, blocks); \
+  run<V, 8, true, true>(NAME "  dma,    barrier     epilogue 16x8 fma", w, sink, n_chunks, blocks); \
+  run<V, 8, false, false>(NAME "  no dma, no barrier  epilogue 16x8 fma", w, sink, n_chunks, blocks); \
+  run<V, 8, true, true, true, 1>(NAME "  dma, __syncthreads  epilogue 16x8 fma + stores", w, sink, n_chunks, blocks); \
+  run<V, 8, true, true, true, 2>(NAME "  dma, wait-then-store + bare barrier, 16x8 fma", w, sink, n_chunks, blocks); \
+  run<V, 0, false, false, false, 0, 1>(NAME "  1 wave/SIMD: registers only", w, sink, n_chunks, blocks); \
+  run<V, 0, false, false, true, 0, 1>(NAME "  1 wave/SIMD: LDS reads, no dma, no barrier", w, sink, n_chunks, blocks); \
+  run<V, 0, true, true, true, 0, 1>(NAME "  1 wave/SIMD: dma, barrier, epilogue 0", w, sink, n_chunks, blocks); \
+  run<V, 8, true, true, true, 0, 1>(NAME "  1 wave/SIMD: dma, barrier, epilogue 16x8 fma", w, sink, n_chunks, blocks);
+  CASES(0, "16x16x32")
+  CASES(1, "32x32x16")
+  return 0;
+}
