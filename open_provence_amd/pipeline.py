@@ -8,6 +8,7 @@ the G3 golden fixtures without a GPU.  No arithmetic of the encoder lives here.
 
 from __future__ import annotations
 
+import functools
 import math
 import os
 from collections import defaultdict
@@ -486,7 +487,9 @@ def prepare_block_inputs(
 #   _auto_tune_preprocess_loader :2567-2623).  The reference runs one inference pass per DataLoader
 #   batch, so these numbers cap the effective forward batch.
 # ---------------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=1)
 def default_preprocess_workers() -> int:
+    # cached: psutil walks /sys/devices/system/cpu (~4 ms per call on a 256-thread host) and the answer is static
     try:
         import psutil
 

@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""GPU-box probe: end-to-end ``process()`` (host pipeline + HIP forward) on a synthetic 1-query x N-context
+request with the char tokenizer of the tests; prints the reference-style timing breakdown and, with
+--profile, the top of a cProfile run.  Usage: scripts/process_e2e.py [--contexts 256] [--chars 470] [--profile]"""
+import argparse
+import cProfile
+import io
+import json
+import os
+import pstats
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np
+import torch
+
+from helpers import CharTokenizer, period_splitter
+
+
+def make_request(n_contexts: int, chars: int, seed: int = 5):
+    rng = np.random.default_rng(seed)
+    words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "iota", "kappa", "lambda", "mu"]
+    contexts = []
+    for _ in range(n_contexts):
+        parts, total = [], 0
+        while total < chars:
+            n = int(rng.integers(5, 12))
+            sent = " ".join(words[int(i)] for i in rng.integers(0, len(words), n)) + ". "
+            parts.append(sent)
+            total += len(sent)
+        contexts.append("".join(parts)[:chars].rstrip() + ".")
+    return "which greek letters appear here", contexts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--contexts", type=int, default=256)
+    ap.add_argument("--chars", type=int, default=470)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--profile", action="store_true")
+    args = ap.parse_args()
+
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.modeling import OpenProvenceModel
+    from open_provence_amd.synthetic import named_dims, synth_state_dict
+
+    dims = named_dims("xsmall")
+    cfg = OpenProvenceConfig(base_model_config=dims.to_base_model_config(), tokenizer_name_or_path="x",
+                             pruning_config={"hidden_size": dims.hidden_size}, max_length=512)
+    model = OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=synth_state_dict(dims, 7))
+    model.tokenizer.model_max_length = 512
+    question, contexts = make_request(args.contexts, args.chars)
+
+    def call():
+        return model.process(question, contexts, threshold=0.1, batch_size=args.batch_size, sentence_splitter=period_splitter,
+                             show_progress=False)
+
+    call()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(args.reps):
+        t0 = time.perf_counter()
+        out = call()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, out["timing"])
+    dt, timing = best
+    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "wall_s": dt, "contexts_per_s": args.contexts / dt,
+                      "timing": {k: round(float(v), 5) for k, v in timing.items()}}))
+    if args.profile:
+        pr = cProfile.Profile()
+        pr.enable()
+        call()
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(35)
+        print(buf.getvalue()[:6000])
+
+
+if __name__ == "__main__":
+    main()
