@@ -74,7 +74,8 @@ struct op_handle {
   op_config cfg;
   int H = 0, I = 0, N = 0, nh = 0, V = 0, nl = 0, max_pos = 0;
   bool split = true;
-  bool row_path = false;  // hidden <= 256: row-stationary GEMMs with fused LayerNorm
+  bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
+  bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
   int chunk_rows = 0;
   float* emb = nullptr;
   float* emb_norm = nullptr;
@@ -305,7 +306,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   // Row path: exactly the computed rows, rounded to the 128-row block -- no slack rows: a 131072-row batch is 1024
   // blocks = two full rounds of 2 blocks per CU; two extra (empty) blocks would cost a third round.  The tiled path
   // keeps 64 slack rows for its attention kernel's tile over-read.
-  const int r_pad = h->row_path ? align_up(rows, ROW_BM) : align_up(rows + 64, 256);
+  const bool fp_layout = h->row_path || h->panel_path;  // fragment-packed activations, attn_fp_kernel
+  const int r_pad = fp_layout ? align_up(rows, ROW_BM) : align_up(rows + 64, 256);
   const int m_tiles = r_pad / GEMM_BM;
   const unsigned row_blocks = (unsigned)((r_pad + 3) / 4);
   const bool split = h->split;
@@ -318,7 +320,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   OP_TRY(L.end());
 
   // rows >= `rows` are never produced by the attention kernel: keep its output finite there
-  if (h->row_path) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
+  if (fp_layout) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
     const size_t tail_off = (size_t)(rows / 16) * (H / 32) * 2 * 512;
     const size_t tail_bytes = (size_t)((r_pad - rows) / 16) * (H / 32) * 2 * 512 * sizeof(u16);
     OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
@@ -366,9 +368,9 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     const int att_waves = getenv("OPEN_PROVENCE_ATT_WAVES") ? atoi(getenv("OPEN_PROVENCE_ATT_WAVES")) : (max_len > 128 ? 8 : 4);
     const int att_bq = att_waves * 32;
     const int q_blocks_fp = (max_len + att_bq - 1) / att_bq;
-    const dim3 grid(h->row_path ? (unsigned)q_blocks_fp : (unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
+    const dim3 grid(fp_layout ? (unsigned)q_blocks_fp : (unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
     const int window = is_global ? -1 : h->cfg.local_attention / 2;
-    if (h->row_path) {
+    if (fp_layout) {
       AttnFpParams ap;  // q_hi/q_lo (k, vt, o likewise) are adjacent: together they hold the fragment-packed tensor
       ap.q_fp = ws.q_hi;
       ap.k_fp = ws.k_hi;
@@ -504,7 +506,75 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       continue;
     }
 
-    // ---- tiled path (hidden > 256): separate LayerNorm kernels, 128 x 128 x 32 tiles, row-major planes ----
+    if (h->panel_path) {
+      // ---- panel path (hidden % 256 == 0): LayerNorm -> fragment-packed planes, k-streamed panel GEMMs ----
+      const dim3 ln_grid((unsigned)(r_pad / 16));
+      auto layer_norm_fp = [&](const float* w) -> int {
+        OP_TRY(L.begin(PK_LN));
+        if (split)
+          hipLaunchKernelGGL((ln_fp_kernel<true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                             w ? 1 : 0, ws.ln_hi);
+        else
+          hipLaunchKernelGGL((ln_fp_kernel<false>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                             w ? 1 : 0, ws.ln_hi);
+        return L.end();
+      };
+      auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles) -> int {
+        OP_TRY(L.begin(kind));
+        const dim3 grid((unsigned)(r_pad / ROW_BM), (unsigned)n_tiles);
+#define OPK_PANEL(EPI_)                                                                         \
+  do {                                                                                          \
+    if (split)                                                                                  \
+      hipLaunchKernelGGL((panel_gemm_kernel<EPI_, true>), grid, dim3(256), 0, st, pp);          \
+    else                                                                                        \
+      hipLaunchKernelGGL((panel_gemm_kernel<EPI_, false>), grid, dim3(256), 0, st, pp);         \
+  } while (0)
+        if (epi == PE_RESIDUAL) OPK_PANEL(PE_RESIDUAL);
+        else if (epi == PE_QK) OPK_PANEL(PE_QK);
+        else if (epi == PE_V) OPK_PANEL(PE_V);
+        else OPK_PANEL(PE_GEGLU);
+#undef OPK_PANEL
+        return L.end();
+      };
+      OP_TRY(layer_norm_fp(li != 0 ? lw.attn_norm : nullptr));  // layer 0: attn_norm is Identity -> plain split
+      PanelParams pp;
+      memset(&pp, 0, sizeof(pp));
+      pp.r_pad = r_pad;
+      pp.hidden = H;
+      pp.row_pos = ws.row_pos;
+      pp.rope_cos = h->rope_cos[is_global ? 1 : 0];
+      pp.rope_sin = h->rope_sin[is_global ? 1 : 0];
+      pp.max_pos = h->max_pos;
+      pp.a_fp = ws.ln_hi;
+      pp.n_ksteps = H / 32;
+      pp.wp = lw.wqkv_pk;
+      pp.o0 = ws.q_hi;
+      pp.o1 = ws.k_hi;
+      OP_TRY(panel(PK_GEMM_QK_ROPE, PE_QK, pp, 2 * H / 256));
+      pp.wp = lw.wqkv_pk + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
+      pp.o0 = ws.vt_hi;
+      OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
+      OP_TRY(attention(is_global));
+      pp.a_fp = ws.o_hi;
+      pp.wp = lw.wo_ks;
+      pp.x = ws.x;
+      pp.ld_out = H;
+      OP_TRY(panel(PK_GEMM_ATTN_OUT, PE_RESIDUAL, pp, H / 256));
+      OP_TRY(layer_norm_fp(lw.mlp_norm));
+      pp.a_fp = ws.ln_hi;
+      pp.wp = lw.wi_pk;
+      pp.o0 = ws.h_hi;
+      pp.ld_out = I;
+      OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128));
+      pp.a_fp = ws.h_hi;
+      pp.n_ksteps = I / 32;
+      pp.wp = lw.wo2_pk;
+      pp.ld_out = H;
+      OP_TRY(panel(PK_GEMM_MLP_OUT, PE_RESIDUAL, pp, H / 256));
+      continue;
+    }
+
+    // ---- tiled path (any hidden % 128 == 0): separate LayerNorm kernels, 128 x 128 x 32 tiles, row-major planes ----
     if (li != 0) OP_TRY(layer_norm(lw.attn_norm));
     GemmParams p;
     memset(&p, 0, sizeof(p));
@@ -653,7 +723,10 @@ int op_create(const op_config* cfg, op_handle** out) {
   // H % 64 and I % 32: every row-GEMM streams an EVEN number of 32-feature chunks on each side of the q/k -> v
   // boundary (H/16 q/k chunks, H/32 v chunks, H/32 out-projection chunks, I/16 Wi chunks) -- rowgemm_kernel's
   // two-stage loop is unrolled by two.
-  h->row_path = (H <= 256) && (H % 64 == 0) && (I % 32 == 0) && getenv("OPEN_PROVENCE_FORCE_TILED") == nullptr;
+  const bool force_tiled = getenv("OPEN_PROVENCE_FORCE_TILED") != nullptr;
+  h->row_path = (H <= 256) && (H % 64 == 0) && (I % 32 == 0) && !force_tiled;
+  // panels of 256 output features (4 heads; 128 GeGLU input + 128 gate columns), an even number of k-steps
+  h->panel_path = !h->row_path && (H % 256 == 0) && (I % 128 == 0) && !force_tiled;
 
 #define OP_CREATE_TRY(expr)  \
   do {                       \
@@ -696,17 +769,18 @@ int op_create(const op_config* cfg, op_handle** out) {
       h->missing.push_back(pre + "attn_norm.weight");
     }
     OP_CREATE_TRY(dev_alloc(h, &lw.mlp_norm, H));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_hi, 3 * HH));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_lo, 3 * HH));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wo_hi, HH));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wo_lo, HH));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wi_hi, (size_t)2 * I * H));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wi_lo, (size_t)2 * I * H));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wo2_hi, (size_t)H * I));
-    OP_CREATE_TRY(dev_alloc(h, &lw.wo2_lo, (size_t)H * I));
-    if (h->row_path) {
+    if (!h->row_path && !h->panel_path) {  // tiled path: row-major hi / lo planes
+      OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_hi, 3 * HH));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_lo, 3 * HH));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wo_hi, HH));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wo_lo, HH));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wi_hi, (size_t)2 * I * H));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wi_lo, (size_t)2 * I * H));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wo2_hi, (size_t)H * I));
+      OP_CREATE_TRY(dev_alloc(h, &lw.wo2_lo, (size_t)H * I));
+    } else {  // fragment-ordered layouts (hi and lo planes interleaved): chunk-major (row path) or panel-major
       OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_pk, 2 * 3 * HH));
-      OP_CREATE_TRY(dev_alloc(h, &lw.wo_pk, 2 * HH));
+      if (h->row_path) OP_CREATE_TRY(dev_alloc(h, &lw.wo_pk, 2 * HH));
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
@@ -835,11 +909,32 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       hipLaunchKernelGGL(transpose_f32_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, dst_f32);
       break;
     case PLANES:
-      hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 0, dst_hi, dst_lo);
+      if (dst_hi)
+        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 0, dst_hi, dst_lo);
       break;
     case PLANES_GEGLU:
-      hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, I, dst_hi, dst_lo);
+      if (dst_hi)
+        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, I, dst_hi, dst_lo);
       break;
+  }
+  if (h->panel_path && (dst_pk || dst_ks)) {
+    // panel-major packing: [panel][k-step][plane][16 fragments][512], rows permuted per consumer (panel_source_row)
+    const int K = (int)d1;
+    auto pack = [&](int n_tiles, int mode, u16* dst) {
+      const size_t total = (size_t)n_tiles * 256 * K;
+      hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, f32, n_tiles, K, mode,
+                         H, I, dst);
+    };
+    if (pk_mode == RE_QKV) {
+      pack(2 * H / 256, PE_QK, dst_pk);
+      pack(H / 256, PE_V, dst_pk + (size_t)(2 * H / 256) * (K / 32) * 2 * 8192);
+    } else if (pk_mode == RE_RESIDUAL) {
+      pack(H / 256, PE_RESIDUAL, dst_ks);  // attention output projection
+    } else if (pk_mode == RE_GEGLU) {
+      pack(I / 128, PE_GEGLU, dst_pk);
+    } else {
+      pack(H / 256, PE_RESIDUAL, dst_pk);  // MLP output projection
+    }
   }
   if (dst_pk && h->row_path) {
     if (pk_mode == 100)
