@@ -30,7 +30,7 @@ sys.path.insert(0, str(ROOT))
 from open_provence_amd.config import EncoderDims  # noqa: E402
 from open_provence_amd.engine import HipEncoder  # noqa: E402
 from open_provence_amd.packing import pack_rows  # noqa: E402
-from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict  # noqa: E402
+from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict, synth_varlen_lengths  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -105,6 +105,8 @@ def main() -> None:
     parser.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     parser.add_argument("--chunk-rows", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--varlen", action="store_true",
+                        help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
     args = parser.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,8 +133,16 @@ def main() -> None:
     encoder.load_state_dict(state)
 
     # 1 query x (pairs * world) contexts; this rank owns a contiguous slice (weak scaling: fixed per-GPU work)
-    rows_all = synth_pair_batch(dims, args.pairs * world, args.seq_len, seed=1234)
-    rows = rows_all[rank * args.pairs : (rank + 1) * args.pairs]
+    if args.varlen:  # ragged stress (single GPU): a mixed-length batch of ~pairs*seq_len tokens
+        if world > 1:
+            raise SystemExit("--varlen is a single-GPU workload")
+        lengths = synth_varlen_lengths(args.pairs * args.seq_len, seed=1234 + rank)
+        rows = [synth_pair_batch(dims, 1, n, seed=1234 + 7 * i + rank)[0] for i, n in enumerate(lengths)]
+        n_pairs_rank = len(rows)
+    else:
+        rows_all = synth_pair_batch(dims, args.pairs * world, args.seq_len, seed=1234)
+        rows = rows_all[rank * args.pairs : (rank + 1) * args.pairs]
+        n_pairs_rank = args.pairs
     ids_np, cu_np, max_len = pack_rows(rows)
     ids = torch.from_numpy(ids_np).to(device)
     cu = torch.from_numpy(cu_np).to(device)
@@ -140,7 +150,7 @@ def main() -> None:
 
     gather_rank = gather_prune = None
     if world > 1 and rank == 0:
-        gather_rank = [torch.empty((args.pairs, dims.num_labels), dtype=torch.float32, device=device) for _ in range(world)]
+        gather_rank = [torch.empty((n_pairs_rank, dims.num_labels), dtype=torch.float32, device=device) for _ in range(world)]
         gather_prune = [torch.empty((total_tokens, 2), dtype=torch.float32, device=device) for _ in range(world)]
 
     def step():
@@ -184,8 +194,10 @@ def main() -> None:
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    pairs_per_s = args.pairs * world * args.steps / elapsed
-    flops_pair = algorithmic_flops_per_pair(dims, args.seq_len)
+    pairs_per_s = n_pairs_rank * world * args.steps / elapsed
+    row_lengths = [len(r) for r in rows]
+    flops_forward = sum(algorithmic_flops_per_pair(dims, n) for n in sorted(set(row_lengths)) for _ in range(row_lengths.count(n)))
+    flops_pair = flops_forward / n_pairs_rank
     whole_tflops = pairs_per_s / world * flops_pair / 1e12  # per GPU
 
     dominant = max(profile.items(), key=lambda kv: kv[1]["total_ms"])[0]
@@ -193,8 +205,12 @@ def main() -> None:
     n_layers = dims.num_layers
     n_global = sum(dims.layer_is_global)
     w = dims.half_window
-    idx = np.arange(args.seq_len)
-    local_keys = float((np.minimum(idx + w, args.seq_len - 1) - np.maximum(idx - w, 0) + 1).mean())
+    # attended (query, key) pairs of this rank's batch: full, and inside the +-w window
+    pairs_global = float(sum(n * n for n in row_lengths))
+    pairs_local = 0.0
+    for n in set(row_lengths):
+        idx = np.arange(n)
+        pairs_local += row_lengths.count(n) * float((np.minimum(idx + w, n - 1) - np.maximum(idx - w, 0) + 1).sum())
     flops_per_forward = {  # algorithmic FLOPs of each kernel kind over one forward of this rank's batch
         "gemm_qk_rope": 2.0 * total_tokens * H * 2 * H * n_layers,
         "gemm_v_t": 2.0 * total_tokens * H * H * n_layers,
@@ -207,8 +223,8 @@ def main() -> None:
         "rowgemm_ln_qkv_rope": 2.0 * total_tokens * H * 3 * H * n_layers,
         "rowgemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
         "rowgemm_ln_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,
-        "attn_global": 4.0 * total_tokens * H * args.seq_len * n_global,
-        "attn_local": 4.0 * total_tokens * H * local_keys * (n_layers - n_global),
+        "attn_global": 4.0 * H * pairs_global * n_global,
+        "attn_local": 4.0 * H * pairs_local * (n_layers - n_global),
     }
     roofline = None
     if dominant in flops_per_forward:
@@ -238,7 +254,8 @@ def main() -> None:
         }
 
     line = {
-        "metric": "query-context pairs/sec @ seq_len %d, %s-v1" % (args.seq_len, args.model),
+        "metric": ("query-context pairs/sec @ mixed seq_len 128-2048, %s-v1" % args.model) if args.varlen
+        else "query-context pairs/sec @ seq_len %d, %s-v1" % (args.seq_len, args.model),
         "value": pairs_per_s,
         "unit": "pairs/s",
         "n_gpus": world,
@@ -252,10 +269,14 @@ def main() -> None:
         "data": "synthetic",
         "config": {
             "workload": f"open-provence-reranker-{args.model}-v1 dims (H={H}, I={I}, {n_layers} layers, {dims.num_heads} heads, "
-            f"V={dims.vocab_size}), {args.pairs} pairs/GPU x seq_len {args.seq_len}, 1 query x N contexts, random-init weights",
-            "pairs_per_gpu": args.pairs,
+            f"V={dims.vocab_size}), "
+            + (f"{n_pairs_rank} pairs/GPU of mixed length 128..2048 ({total_tokens} tokens, varlen-packed)" if args.varlen
+               else f"{args.pairs} pairs/GPU x seq_len {args.seq_len}")
+            + ", 1 query x N contexts, random-init weights",
+            "pairs_per_gpu": n_pairs_rank,
             "seq_len": args.seq_len,
-            "global_pairs": args.pairs * world,
+            "global_pairs": n_pairs_rank * world,
+            "tokens_per_s": total_tokens * world * args.steps / elapsed,
             "precision": args.precision + (" (bf16 hi/lo split operands, 3 MFMA passes, fp32 accumulate)" if args.precision == "bf16x3" else " (single-pass bf16 operands, fp32 accumulate)"),
             "parallelism": f"dp{world} (pairs sharded, RCCL gather of per-pair outputs)" if world > 1 else "single GPU",
             "algorithmic_gflop_per_pair": flops_pair / 1e9,

@@ -203,7 +203,7 @@ struct Workspace {
   u16 *vt_hi, *vt_lo;
   u16 *o_hi, *o_lo;
   u16 *h_hi, *h_lo;
-  int32_t *row_seq, *row_pos, *row_tok, *roff;
+  int32_t *row_seq, *row_pos, *row_tok, *roff, *qboff;
   float* cls;
   size_t bytes;
 };
@@ -243,6 +243,7 @@ void carve(const op_handle* h, char* base, int cap_rows_pad, int n_seqs, Workspa
   ws.row_pos = (int32_t*)take(R * 4);
   ws.row_tok = (int32_t*)take(R * 4);
   ws.roff = (int32_t*)take(((size_t)n_seqs + 1) * 4);
+  ws.qboff = (int32_t*)take(((size_t)n_seqs + 1) * 4);
   ws.cls = (float*)take(std::max<size_t>((size_t)n_seqs, 1) * H * 4);
   ws.bytes = off;
 }
@@ -301,7 +302,8 @@ int launch_kstream(Launcher& L, int kind, const KStreamParams& p, int hidden, in
 }
 
 int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t* ids_dev, const int32_t* cu_dev, int s0,
-                  int ns, int rows, int max_len, int total_tokens, float* prune_out, float* rank_out) {
+                  int ns, int rows, int max_len, int total_tokens, int att_waves, int att_items, float* prune_out,
+                  float* rank_out) {
   const int H = h->H, I = h->I;
   // Row path: exactly the computed rows, rounded to the 128-row block -- no slack rows: a 131072-row batch is 1024
   // blocks = two full rounds of 2 blocks per CU; two extra (empty) blocks would cost a third round.  The tiled path
@@ -314,7 +316,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   hipStream_t st = L.stream;
 
   OP_TRY(L.begin(PK_ROWMAP));
-  hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, ws.roff);
+  hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, ROW_ALIGN, ROW_ALIGN, ws.roff);
+  if (fp_layout) hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, att_waves * 32, 1, ws.qboff);
   hipLaunchKernelGGL(row_map_kernel, dim3((unsigned)((r_pad + 255) / 256)), dim3(256), 0, st, cu_dev, s0, ns, ws.roff,
                      r_pad, ws.row_seq, ws.row_pos, ws.row_tok);
   OP_TRY(L.end());
@@ -364,11 +367,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
 
   auto attention = [&](bool is_global) -> int {
     OP_TRY(L.begin(is_global ? PK_ATTN_GLOBAL : PK_ATTN_LOCAL));
-    // fragment-packed attention: 8 waves (256 queries per block) once sequences are longer than 128 tokens
-    const int att_waves = getenv("OPEN_PROVENCE_ATT_WAVES") ? atoi(getenv("OPEN_PROVENCE_ATT_WAVES")) : (max_len > 128 ? 8 : 4);
-    const int att_bq = att_waves * 32;
-    const int q_blocks_fp = (max_len + att_bq - 1) / att_bq;
-    const dim3 grid(fp_layout ? (unsigned)q_blocks_fp : (unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
+    // fragment-packed attention: one block per (sequence, block of att_waves * 32 queries, head) work item
+    const dim3 grid(fp_layout ? (unsigned)att_items : (unsigned)q_tiles, (unsigned)h->nh, fp_layout ? 1u : (unsigned)ns);
     const int window = is_global ? -1 : h->cfg.local_attention / 2;
     if (fp_layout) {
       AttnFpParams ap;  // q_hi/q_lo (k, vt, o likewise) are adjacent: together they hold the fragment-packed tensor
@@ -379,6 +379,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.cu = cu_dev;
       ap.s0 = s0;
       ap.roff = ws.roff;
+      ap.qboff = ws.qboff;
+      ap.ns = ns;
       ap.H = H;
       ap.r_pad = r_pad;
       ap.window = window;
@@ -1076,8 +1078,14 @@ int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_de
       ++s1;
     }
     if (rows > cap) return fail(h, OP_ERR_WORKSPACE, "internal: chunk of %d rows exceeds capacity %d", rows, cap);
+    // attention work items: 256-query blocks (8 waves) once a sequence is longer than 128 tokens, else 128
+    const char* aw = getenv("OPEN_PROVENCE_ATT_WAVES");
+    const int att_waves = aw ? (atoi(aw) == 4 ? 4 : 8) : (max_len > 128 ? 8 : 4);
+    int att_items = 0;
+    for (int s = s0; s < s1; ++s) att_items += (cu[s + 1] - cu[s] + att_waves * 32 - 1) / (att_waves * 32);
     if (rows > 0) {
-      OP_TRY(forward_chunk(h, L, ws, ids_dev, cu_dev, s0, s1 - s0, rows, max_len, total_tokens, prune_out, rank_out));
+      OP_TRY(forward_chunk(h, L, ws, ids_dev, cu_dev, s0, s1 - s0, rows, max_len, total_tokens, att_waves, att_items,
+                           prune_out, rank_out));
     } else {
       // only empty sequences in this chunk
       OP_HIP(h, hipMemsetAsync(rank_out + (size_t)s0 * h->nl, 0, (size_t)(s1 - s0) * h->nl * sizeof(float), stream));

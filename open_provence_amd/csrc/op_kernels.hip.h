@@ -122,8 +122,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // ----------------------------------------------------------------------------------------------
 // row map: sequence offsets (aligned) and per-row (seq, pos, token index)
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void seq_offsets_kernel(const int32_t* __restrict__ cu, int s0, int ns,
-                                                           int32_t* __restrict__ roff) {
+// roff[i] = sum_{j<i} ceil(len_j / unit) * scale  (exclusive prefix; roff[ns] = total).  unit = scale = ROW_ALIGN gives
+// the aligned row offsets, unit = queries per attention block with scale = 1 the first work item of each sequence.
+__global__ __launch_bounds__(1024) void seq_offsets_kernel(const int32_t* __restrict__ cu, int s0, int ns, int unit,
+                                                           int scale, int32_t* __restrict__ roff) {
   __shared__ int sh[1024];
   __shared__ int carry;
   const int tid = threadIdx.x;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(1024) void seq_offsets_kernel(const int32_t* __rest
     int v = 0;
     if (i < ns) {
       const int len = cu[s0 + i + 1] - cu[s0 + i];
-      v = (len + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+      v = (len + unit - 1) / unit * scale;
     }
     sh[tid] = v;
     __syncthreads();
@@ -1981,6 +1983,8 @@ struct AttnFpParams {
   const int32_t* cu;
   int s0;
   const int32_t* roff;
+  const int32_t* qboff;  // first work item (query block) of each sequence, [ns + 1]: the grid has no empty blocks
+  int ns;
   int H;
   int r_pad;
   int window;
@@ -2000,9 +2004,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
   constexpr int STAGE = (K_PIECES + V_PIECES) * 512;
   __shared__ __attribute__((aligned(16))) u16 sT[2][STAGE];
 
-  const int s = blockIdx.z;
+  // work item -> (sequence, query block): binary search in the per-sequence prefix of ceil(len / ATT_FP_BQ)
+  int s = 0;
+  {
+    const int item = blockIdx.x;
+    int lo_s = 0, hi_s = p.ns - 1;
+    while (lo_s < hi_s) {
+      const int mid = (lo_s + hi_s + 1) >> 1;
+      if (p.qboff[mid] <= item) lo_s = mid; else hi_s = mid - 1;
+    }
+    s = lo_s;
+  }
   const int head = blockIdx.y;
-  const int q0 = blockIdx.x * ATT_FP_BQ;
+  const int q0 = ((int)blockIdx.x - p.qboff[s]) * ATT_FP_BQ;
   const int len = p.cu[p.s0 + s + 1] - p.cu[p.s0 + s];
   if (q0 >= len) return;
   const int r0 = p.roff[s];
