@@ -294,6 +294,172 @@ def process_fixture(name: str, cfg: dict[str, Any], *, weight_seed: int, max_len
     print(f"[golden] {name}: {len(cases_out)} process() cases")
 
 
+def eval_dataset_examples() -> list[dict[str, Any]]:
+    """Small span-annotated dataset in the schema scripts/eval_datasets.py reads (query, texts, context_spans,
+    context_spans_relevance), exercising both relevance encodings (0/1 mask and index list), missing spans, empty and
+    out-of-range spans, a missing query and a context without relevance labels."""
+
+    def spans_of(text: str) -> list[list[int]]:
+        out, start = [], 0
+        for i, ch in enumerate(text):
+            if ch == ".":
+                end = i + 1
+                while end < len(text) and text[end] == " ":
+                    end += 1
+                out.append([start, end])
+                start = end
+        if start < len(text):
+            out.append([start, len(text)])
+        return out
+
+    t1 = "The tower is tall. It was built long ago. Many people visit it. Bread is made from flour."
+    t2 = "Rivers flow to the sea. Mountains are tall. Rivers carry water and silt."
+    t3 = "A single unsplit passage about nothing in particular"
+    t4 = "Alpha one. Alpha two is longer than one. Alpha three. Alpha four closes the passage."
+    t5 = "Short. Tiny. Brief one here. And the last sentence of this passage is the longest of them all."
+    return [
+        {"query": "how tall is the tower?", "texts": [t1, t2], "context_spans": [spans_of(t1), spans_of(t2)],
+         "context_spans_relevance": [[1, 1, 0, 0], [1]]},
+        {"query": "what do rivers carry?", "texts": [t2, t3, t4], "context_spans": [spans_of(t2), [], spans_of(t4)],
+         "context_spans_relevance": [[0, 2], [], [0, 0, 0, 1]]},
+        {"query": None, "texts": [t1], "context_spans": [spans_of(t1)], "context_spans_relevance": [[1, 0, 0, 0]]},
+        {"query": "which sentence is longest?", "texts": [t5, t1],
+         "context_spans": [spans_of(t5) + [[200, 300], [10, 5]], spans_of(t1)[:2]],
+         "context_spans_relevance": [[3, 9], None]},
+        {"query": "alpha?", "texts": [t4], "context_spans": [spans_of(t4)]},
+    ]
+
+
+def eval_fixture(name: str, cfg: dict[str, Any], *, max_length: int) -> None:
+    """G4: the reference's evaluation loop (scripts/eval_datasets.py:247-486 ``evaluate_dataset``) run on the dataset
+    above with the stub forward of G3, two thresholds.  The script needs Python 3.11's ``datetime.UTC`` and the
+    ``open_provence`` package path: both are shimmed here (alias + module registration), nothing else is touched."""
+
+    import datetime as _dt
+
+    if not hasattr(_dt, "UTC"):
+        _dt.UTC = _dt.timezone.utc  # type: ignore[attr-defined]
+    ref = load_reference(emit_specials=True)
+    pkg = types.ModuleType("open_provence")
+    pkg.__path__ = []  # type: ignore[attr-defined]
+    sys.modules["open_provence"] = pkg
+    sys.modules["open_provence.modeling_open_provence_standalone"] = ref
+    spec = importlib.util.spec_from_file_location("reference_eval_datasets", "/root/reference/scripts/eval_datasets.py")
+    script = importlib.util.module_from_spec(spec)
+    sys.modules["reference_eval_datasets"] = script  # dataclasses resolve their module through sys.modules
+    spec.loader.exec_module(script)
+
+    model, _dims = build_model(ref, cfg, max_length=max_length, seed=0, weight_seed=5)
+
+    def stub_forward(input_ids=None, attention_mask=None, **_kw):
+        b, length = input_ids.shape
+        pos = torch.arange(length, dtype=torch.float32)[None, :].expand(b, length)
+        tok = input_ids.to(torch.float32)
+        keep = torch.sin(0.37 * pos + 0.011 * tok) * 3.0
+        prune = torch.stack([torch.zeros_like(keep), keep], dim=-1)
+        rank = (input_ids.sum(dim=1, keepdim=True).to(torch.float32) % 17.0) / 4.0 - 2.0
+        return {"ranking_logits": rank, "pruning_logits": prune}
+
+    model.forward = stub_forward  # type: ignore[method-assign]
+    dataset = eval_dataset_examples()
+    runs = []
+    for threshold in (0.5, 0.1):
+        result = script.evaluate_dataset(model, dataset, threshold=threshold, batch_size=4, dataset_label="synthetic",
+                                         show_progress=False, debug_messages=False, print_timing_summary=False, silent=True)
+        result.pop("process_time_seconds")
+        result.pop("timing")
+        runs.append({"threshold": threshold, "expected": _jsonable(result)})
+    meta = {
+        "name": name,
+        "base_model_config": cfg,
+        "max_length": max_length,
+        "dataset": dataset,
+        "runs": runs,
+        "generator": "tests/golden/make_golden.py (reference scripts/eval_datasets.py evaluate_dataset, stub forward)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: {[(r['threshold'], r['expected']['confusion_matrix']) for r in runs]}")
+
+
+def mldr_rows() -> list[dict[str, Any]]:
+    """MLDR-shaped rows (query_id, query, positive_passages / negative_passages of {docid, title, text}) with string,
+    list, blank and missing titles, a row without passages and a single-query / single-doc variant."""
+
+    doc_a = "The tower is 300 m tall. It was built in 1889. Many people visit it every year."
+    doc_b = "Bread is made from flour. Water is wet. Salt is salty."
+    doc_c = "Rivers flow to the sea. Mountains are tall. Rivers carry water and silt to the delta."
+    doc_d = " ".join(f"Sentence number {i} talks about topic {i % 5} in some detail." for i in range(14))
+    return [
+        {"query_id": "q1", "query": "how tall is the tower?",
+         "positive_passages": [{"docid": "d1", "title": "Tower", "text": doc_a}],
+         "negative_passages": [{"docid": "d2", "title": ["Bread", " and ", None, "water"], "text": doc_b},
+                               {"docid": "d3", "title": "   ", "text": doc_c}]},
+        {"query_id": "q2", "query": "nothing here?", "positive_passages": [], "negative_passages": []},
+        {"query_id": "q3", "query": "what do rivers carry?",
+         "positive_passages": [{"docid": "d4", "text": doc_c}, {"docid": "d5", "title": None, "text": doc_d}],
+         "negative_passages": [{"docid": "d6", "title": "Loaf", "text": doc_b}]},
+    ]
+
+
+def mldr_fixture(name: str, cfg: dict[str, Any], *, max_length: int) -> None:
+    """G5: the reference's MLDR record builder (scripts/eval_mldr.py:238-524 ``build_records``) on the rows above with
+    the stub forward, for the multi-query set and for a single query with a single passage (where process() un-nests
+    its outputs).  Shims for the import only: ``datetime.UTC`` is not needed here, ``litellm`` (absent, used by the
+    LLM-judge half of the script) is an empty stub module, ``open_provence`` resolves to the standalone file."""
+
+    ref = load_reference(emit_specials=True)
+    pkg = types.ModuleType("open_provence")
+    pkg.__path__ = []  # type: ignore[attr-defined]
+    sys.modules["open_provence"] = pkg
+    sys.modules["open_provence.modeling_open_provence_standalone"] = ref
+    sys.modules.setdefault("litellm", types.ModuleType("litellm"))
+    spec = importlib.util.spec_from_file_location("reference_eval_mldr", "/root/reference/scripts/eval_mldr.py")
+    script = importlib.util.module_from_spec(spec)
+    sys.modules["reference_eval_mldr"] = script
+    spec.loader.exec_module(script)
+
+    model, _dims = build_model(ref, cfg, max_length=max_length, seed=0, weight_seed=5)
+
+    def stub_forward(input_ids=None, attention_mask=None, **_kw):
+        b, length = input_ids.shape
+        pos = torch.arange(length, dtype=torch.float32)[None, :].expand(b, length)
+        tok = input_ids.to(torch.float32)
+        keep = torch.sin(0.37 * pos + 0.011 * tok) * 3.0
+        prune = torch.stack([torch.zeros_like(keep), keep], dim=-1)
+        rank = (input_ids.sum(dim=1, keepdim=True).to(torch.float32) % 17.0) / 4.0 - 2.0
+        return {"ranking_logits": rank, "pruning_logits": prune}
+
+    model.forward = stub_forward  # type: ignore[method-assign]
+
+    def process_fn(**kwargs):  # the reference resolves its splitter by language; pin the test splitter instead
+        return model.process(sentence_splitter=period_splitter, **kwargs)
+
+    import inspect as _inspect
+
+    process_fn.__signature__ = _inspect.signature(model.process)  # type: ignore[attr-defined]
+    rows = mldr_rows()
+    single = [{"query_id": "s1", "query": "how tall is the tower?",
+               "positive_passages": [rows[0]["positive_passages"][0]], "negative_passages": []}]
+    runs = []
+    for label, data, best in (("multi", rows, True), ("multi_last_block_score", rows, False), ("single", single, True)):
+        records, stats, n_queries = script.build_records(process_fn, data, threshold=0.4, batch_size=4, log_timing=False,
+                                                         use_best_reranker_score=best, show_progress=False)
+        runs.append({"label": label, "rows": data, "use_best_reranker_score": best,
+                     "expected": _jsonable({"records": records, "stats": stats, "n_queries": n_queries})})
+    meta = {
+        "name": name,
+        "base_model_config": cfg,
+        "max_length": max_length,
+        "threshold": 0.4,
+        "runs": runs,
+        "generator": "tests/golden/make_golden.py (reference scripts/eval_mldr.py build_records, stub forward)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: {[(r['label'], len(r['expected']['records'])) for r in runs]}")
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--only", nargs="*", default=None)
@@ -364,6 +530,10 @@ def main() -> None:
         process_fixture("g3_process_stub_manual_specials", g3_cfg, weight_seed=41, max_length=96, emit_specials=False, stub=True)
     if want("g3_process_model"):
         process_fixture("g3_process_model", g3_cfg, weight_seed=41, max_length=96, emit_specials=True, stub=False)
+    if want("g4_eval_dataset"):
+        eval_fixture("g4_eval_dataset", g3_cfg, max_length=96)
+    if want("g5_mldr_records"):
+        mldr_fixture("g5_mldr_records", g3_cfg, max_length=96)
 
 
 if __name__ == "__main__":

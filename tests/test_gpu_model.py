@@ -197,6 +197,41 @@ def test_edge_cases_empty_single_token_and_long_sequence():
         assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3, i
 
 
+def test_panel_path_ragged_edge_cases():
+    """hidden % 256 == 0 models (base / large / en-gte shapes) take the k-streamed panel kernels: a 3-layer H=512
+    model (global + two local layers) on a ragged batch with an empty row, one-token rows, lengths that are not
+    multiples of anything and one row longer than a 256-query attention block, against the oracle."""
+
+    from open_provence_amd.config import EncoderDims
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import synth_state_dict
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = EncoderDims.from_base_model_config(
+        dict(model_type="modernbert", vocab_size=512, hidden_size=512, intermediate_size=384, num_hidden_layers=3,
+             num_attention_heads=8, local_attention=128, global_attn_every_n_layers=3, global_rope_theta=160000.0,
+             local_rope_theta=10000.0, max_position_embeddings=1024, pad_token_id=0, cls_token_id=1, sep_token_id=2),
+        num_labels=1,
+    )
+    state = synth_state_dict(dims, 11)
+    enc = HipEncoder(dims, device="cuda")
+    enc.load_state_dict(state)
+    rng = np.random.default_rng(9)
+    lengths = [1, 0, 33, 257, 700, 1, 130]
+    rows = [rng.integers(3, 500, size=n).tolist() for n in lengths]
+    prune, rank, cu = enc.forward_rows(rows)
+    assert prune.shape == (sum(lengths), 2) and torch.isfinite(prune).all() and torch.isfinite(rank).all()
+    assert rank[1].abs().max() == 0
+    for i, n in enumerate(lengths):
+        if n == 0:
+            continue
+        ids = torch.tensor([rows[i]], dtype=torch.long)
+        ref = oracle_forward(state, dims, ids, torch.ones_like(ids))
+        got = prune[cu[i] : cu[i + 1]].cpu()
+        assert (got - ref.pruning_logits[0]).abs().max() < 1e-3, (i, n)
+        assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3, (i, n)
+
+
 def test_batch_composition_invariance_at_baseline_size():
     """C2 size (256 pairs x 512 tokens, xsmall dims): every pair's outputs are bit-identical whatever the
     batch order, the companions in the batch or the chunking -- pairs are independent."""
