@@ -232,6 +232,29 @@ def test_panel_path_ragged_edge_cases():
         assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3, (i, n)
 
 
+@pytest.mark.parametrize("model_name,lengths", [("base", [512, 300, 77]), ("large", [512, 129]), ("en-gte", [640, 64])])
+def test_full_depth_published_shapes_match_oracle(model_name, lengths):
+    """BASELINE.json configs 3-5 at their real depth (19 / 25 / 22 layers, H = 512 / 768): error accumulation through
+    the whole stack of the panel kernels stays inside 1e-3 of the fp32 oracle (the H=768 golden fixture has 3 layers)."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = named_dims(model_name, vocab_size=4096)
+    state = synth_state_dict(dims, 17)
+    rows = [synth_pair_batch(dims, 1, n, seed=100 + n)[0] for n in lengths]
+    enc = HipEncoder(dims, device="cuda")
+    enc.load_state_dict(state)
+    prune, rank, cu = enc.forward_rows(rows)
+    for i, row in enumerate(rows):
+        ids = torch.tensor([row], dtype=torch.long)
+        ref = oracle_forward(state, dims, ids, torch.ones_like(ids))
+        err_p = (prune[cu[i] : cu[i + 1]].cpu() - ref.pruning_logits[0]).abs().max().item()
+        err_r = (rank[i].cpu() - ref.ranking_logits[0]).abs().max().item()
+        assert err_p < 1e-3 and err_r < 1e-3, (model_name, lengths[i], err_p, err_r)
+
+
 def test_batch_composition_invariance_at_baseline_size():
     """C2 size (256 pairs x 512 tokens, xsmall dims): every pair's outputs are bit-identical whatever the
     batch order, the companions in the batch or the chunking -- pairs are independent."""
