@@ -949,19 +949,23 @@ __global__ __launch_bounds__(WAVES * 64, MF == 1 ? 4 : 2) void rowgemm_kernel(Ro
       }
       load_a1(kn);
       __builtin_amdgcn_sched_barrier(0);
+      // two weight fragments at a time, the three product terms issued term-major over their 2 x MF accumulators:
+      // no MFMA reads the accumulator the previous one wrote (a dependent pair stalls the pipe)
 #pragma unroll
-      for (int nf = 0; nf < NF1; ++nf) {
-        const bf16x8 wh = lds_frag(&sW[cur][nf * 512 + lane * 8]);
-        if (SPLIT) {
-          const bf16x8 wl = lds_frag(&sW[cur][(NF1 + nf) * 512 + lane * 8]);
+      for (int nf = 0; nf < NF1; nf += 2) {
+        bf16x8 wh[2], wl[2];
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-            acc1[nf][mf] = mfma16(wl, c_hi[mf], acc1[nf][mf]);
-            acc1[nf][mf] = mfma16(wh, c_lo[mf], acc1[nf][mf]);
-          }
+        for (int j = 0; j < 2; ++j) {
+          wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
+          wl[j] = SPLIT ? lds_frag(&sW[cur][(NF1 + nf + j) * 512 + lane * 8]) : wh[j];
         }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(wh, c_hi[mf], acc1[nf][mf]);
+        for (int term = SPLIT ? 0 : 2; term < 3; ++term)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+              acc1[nf + j][mf] = mfma16(term == 0 ? wl[j] : wh[j], term == 1 ? c_lo[mf] : c_hi[mf], acc1[nf + j][mf]);
       }
       __syncthreads();
     };
@@ -1417,18 +1421,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void kstream_gemm_kernel(KStreamPara
       load_a(kn);                              // prefetch the next k-step's fragments ...
       __builtin_amdgcn_sched_barrier(0);       // ... and keep the loads up here, ahead of the MFMAs
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const bf16x8 wh = lds_frag(&sW[cur][nf * 512 + lane * 8]);
-        if (SPLIT) {
-          const bf16x8 wl = lds_frag(&sW[cur][(NF + nf) * 512 + lane * 8]);
+      for (int nf = 0; nf < NF; nf += 2) {  // term-major over 2 fragments x 2 row blocks (see rowgemm_kernel phase 1)
+        bf16x8 wh[2], wl[2];
 #pragma unroll
-          for (int mf = 0; mf < 2; ++mf) {
-            acc[nf][mf] = mfma16(wl, a_hi[mf], acc[nf][mf]);
-            acc[nf][mf] = mfma16(wh, a_lo[mf], acc[nf][mf]);
-          }
+        for (int j = 0; j < 2; ++j) {
+          wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
+          wl[j] = SPLIT ? lds_frag(&sW[cur][(NF + nf + j) * 512 + lane * 8]) : wh[j];
         }
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = mfma16(wh, a_hi[mf], acc[nf][mf]);
+        for (int term = SPLIT ? 0 : 2; term < 3; ++term)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+              acc[nf + j][mf] = mfma16(term == 0 ? wl[j] : wh[j], term == 1 ? a_lo[mf] : a_hi[mf], acc[nf + j][mf]);
       }
       __syncthreads();
     }
@@ -1591,19 +1597,23 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
     load_a(kn);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const bf16x8 wh = lds_frag(&sW[cur][nf * 512 + lane * 8]);
-      if (SPLIT) {
-        const bf16x8 wl = lds_frag(&sW[cur][(NF + nf) * 512 + lane * 8]);
+    for (int nf = 0; nf < NF; nf += 2) {  // term-major over 2 fragments x 2 row blocks: no dependent MFMA pairs
+      bf16x8 wh[2], wl[2];
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-          acc[nf][mf] = SWAPPED ? mfma16(wl, a_hi[mf], acc[nf][mf]) : mfma16(a_hi[mf], wl, acc[nf][mf]);
-          acc[nf][mf] = SWAPPED ? mfma16(wh, a_lo[mf], acc[nf][mf]) : mfma16(a_lo[mf], wh, acc[nf][mf]);
-        }
+      for (int j = 0; j < 2; ++j) {
+        wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
+        wl[j] = SPLIT ? lds_frag(&sW[cur][(NF + nf + j) * 512 + lane * 8]) : wh[j];
       }
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf)
-        acc[nf][mf] = SWAPPED ? mfma16(wh, a_hi[mf], acc[nf][mf]) : mfma16(a_hi[mf], wh, acc[nf][mf]);
+      for (int term = SPLIT ? 0 : 2; term < 3; ++term)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf) {
+            const bf16x8 w = term == 0 ? wl[j] : wh[j];
+            const bf16x8 a = term == 1 ? a_lo[mf] : a_hi[mf];
+            acc[nf + j][mf] = SWAPPED ? mfma16(w, a, acc[nf + j][mf]) : mfma16(a, w, acc[nf + j][mf]);
+          }
     }
     __syncthreads();
   };
