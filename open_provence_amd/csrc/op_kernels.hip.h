@@ -1086,9 +1086,8 @@ __global__ __launch_bounds__(WAVES * 64, MF == 1 ? 4 : 2) void rowgemm_kernel(Ro
     }
   }
 
-  // RE_QKV: RoPE rows of this lane's two tokens: cos/sin [pos][8g + 4j .. +3] for the half-head j of the chunk
-  // being computed are fetched at the top of each q/k iteration (before the DMA is issued, so the epilogue can
-  // wait for them with a counted vmcnt) and used after its 96 MFMAs.
+  // RE_QKV: RoPE rows of this lane's tokens: cos/sin [pos][8g + 4j .. +3] for the half-head j of the chunk whose
+  // (deferred) epilogue runs in this iteration are fetched at the top of the iteration, before the DMA is issued.
   const float* rope_c_row[MF];
   const float* rope_s_row[MF];
   f32x4 rope_c[MF], rope_s[MF];
@@ -1113,9 +1112,10 @@ __global__ __launch_bounds__(WAVES * 64, MF == 1 ? 4 : 2) void rowgemm_kernel(Ro
     for (int t = 0; t < 4; ++t) qk_hold[mf][t] = make_uint2(0u, 0u);
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
-  // Epilogue of chunk `cc` (compile-time parity PP = cc & 1) from accumulators `av`.  It is issued one iteration
-  // LATE -- at the top of the iteration that runs the MFMAs of chunk cc+1 -- so that its stores have a whole MFMA
-  // phase to retire before the s_waitcnt vmcnt(0) in front of the next barrier (vmcnt counts stores on CDNA4).
+  // Epilogue of chunk `cc` (compile-time parity PP = cc & 1) from accumulators `av`.  It runs one iteration late,
+  // inside the iteration that computes chunk cc+1, its VALU instructions scheduled between that chunk's MFMAs
+  // (sched_group_barrier recipe below): vector instructions of all kinds share the SIMD's issue port, so the
+  // epilogue costs its instruction count either way, but interleaved it no longer adds a serial VALU-only phase.
   auto epilogue = [&](int cc, auto parity_tag, auto sw_tag, const f32x4 (&av)[2][MF]) {
     constexpr int PP = decltype(parity_tag)::value;
     constexpr bool sw = decltype(sw_tag)::value;  // q/k chunk ("swapped" MFMA orientation) or v chunk
@@ -1234,7 +1234,6 @@ __global__ __launch_bounds__(WAVES * 64, MF == 1 ? 4 : 2) void rowgemm_kernel(Ro
   // (s_waitcnt vmcnt(0)) before the first ds_read -- the wait sits only in front of the barrier.
   // Every iteration is ONE basic block: the MFMA orientation of the chunk (SW) and the kind of the deferred
   // epilogue (SWP: q/k or v for RE_QKV) are compile-time tags, the chunk loop is split at the q/k -> v boundary.
-  constexpr bool LATE = true;
   auto iteration = [&](int c, auto cur_tag, auto first_tag, auto sw_tag, auto swp_tag) {
     constexpr int cur = decltype(cur_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -1265,10 +1264,11 @@ __global__ __launch_bounds__(WAVES * 64, MF == 1 ? 4 : 2) void rowgemm_kernel(Ro
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = acc[nf][mf];
     if (!FIRST) {
-      // Scheduling recipe for this iteration: the first k-step's fragment reads, then per MFMA two (bf16x3) or
-      // five (bf16) VALU instructions of the deferred epilogue and, every third (second) MFMA, one fragment read
-      // for the k-step ahead.  An MFMA holds the issue port for ~4 of its 16 cycles; the epilogue's VALU work
-      // fits into the remaining slots instead of running as a block in front of the MFMA phase.
+      // Scheduling recipe for this iteration: the first k-step's fragment reads, then per MFMA two (bf16x3) or five
+      // (bf16) VALU instructions of the deferred epilogue and the fragment reads for the k-step ahead, spread evenly.
+      // Measured (microbench/mfma_loop.hip and the GeLU rewrite): VALU work is NOT free beside MFMAs -- every vector
+      // instruction costs its issue slot -- so the gain of the interleave is only that no wave sits in a VALU-only
+      // phase while its partner waits for the same port; the lever that pays is fewer epilogue instructions.
       constexpr int N_MFMA = KS * 2 * MF * (SPLIT ? 3 : 1);
       constexpr int N_DS = KS * 2 * PLANES;
       constexpr int DS_LATE = N_DS - 2 * PLANES;  // reads placed between the MFMAs, spread evenly
