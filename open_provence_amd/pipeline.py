@@ -558,6 +558,24 @@ class PostprocessResult:
     sentence_probabilities: list[list[list[float]]] | None
 
 
+def mean_f32_slice(values: np.ndarray) -> float:
+    """``float(values.mean())`` for a non-empty 1-D float32 array, bit for bit, without ``ndarray.mean``'s Python-level
+    wrapper (numpy/_core/_methods.py:_mean: pairwise float32 sum, divided by the count as ``intp`` -- i.e. in float64
+    -- and cast back to float32).  ``process()`` averages thousands of short probability slices per request."""
+
+    if values.dtype != np.float32:
+        return float(values.mean())
+    return float(np.float32(np.add.reduce(values) / np.intp(values.shape[0])))
+
+
+def mean_of_floats(values: Sequence[float]) -> float:
+    """``float(np.mean(values))`` for a non-empty list of Python floats (float64 pairwise sum / count), bit for bit."""
+
+    if len(values) == 1:
+        return float(values[0])
+    return float(np.add.reduce(np.asarray(values, dtype=np.float64)) / np.intp(len(values)))
+
+
 def score_fragments(state: ContextState, use_best_reranker_score: bool) -> tuple[dict[int, list[float]], float | None]:
     """Mean keep-probability of every fragment in every block, and the context's rerank score.
 
@@ -576,7 +594,7 @@ def score_fragments(state: ContextState, use_best_reranker_score: bool) -> tuple
             end = max(start, end - offset)
             end = min(end, n)
             start = min(start, n)
-            per_fragment[fragment.global_index].append(1.0 if end <= start else float(probs[start:end].mean()))
+            per_fragment[fragment.global_index].append(1.0 if end <= start else mean_f32_slice(probs[start:end]))
         if raw.ranking_score is not None:
             if ranking is None:
                 ranking = raw.ranking_score
@@ -652,7 +670,7 @@ def postprocess_contexts(
             averages: list[float] = []
             for s_idx in range(len(sentences)):
                 values = per_sentence.get(s_idx)
-                avg = float(np.mean(values)) if values else 0.0
+                avg = mean_of_floats(values) if values else 0.0
                 averages.append(max(0.0, min(avg, 1.0)))
             any_above = any(a > threshold for a in averages)
             keep = [a > threshold for a in averages]

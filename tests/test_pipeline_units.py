@@ -287,3 +287,27 @@ def test_forward_boundary_accepts_mapping_and_tuple_protocol():
     assert model._extract_model_output(out, "ranking_logits") is out["logits"]
     with pytest.raises(KeyError):
         model._extract_model_output({}, "pruning_logits")
+
+
+def test_fast_means_are_bit_identical_to_numpy_mean():
+    """The post-processing averages go through ``ndarray.mean`` / ``np.mean`` in the reference (standalone.py:3075-3082,
+    3116-3120); the drop-in's cheaper formulations must return the same bits (sentence keep/drop is a strict ``>``)."""
+
+    import numpy as np
+
+    from open_provence_amd.pipeline import mean_f32_slice, mean_of_floats
+
+    rng = np.random.default_rng(0)
+    probs = rng.random(4096).astype(np.float32)
+    tiny = (rng.random(4096) * 1e-6).astype(np.float32)
+    for _ in range(3000):
+        n = int(rng.integers(1, 700))
+        start = int(rng.integers(0, 4096 - n))
+        for arr in (probs, tiny):
+            seg = arr[start : start + n]
+            assert mean_f32_slice(seg) == float(seg.mean())
+    assert mean_f32_slice(probs[:5].astype(np.float64)) == float(probs[:5].astype(np.float64).mean())
+    for _ in range(2000):
+        n = int(rng.integers(1, 12))
+        values = [float(v) for v in rng.random(n)]
+        assert mean_of_floats(values) == float(np.mean(values))
