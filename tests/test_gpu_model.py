@@ -255,6 +255,54 @@ def test_full_depth_published_shapes_match_oracle(model_name, lengths):
         assert err_p < 1e-3 and err_r < 1e-3, (model_name, lengths[i], err_p, err_r)
 
 
+SHAPE_SWEEP = [
+    # hidden (multiple of 128, head_dim 64), intermediate (multiple of 64), heads, layers, pooling, labels, GEMM family
+    (128, 64, 2, 2, "cls", 1, "row"),
+    (128, 192, 2, 3, "mean", 2, "row"),
+    (256, 320, 4, 2, "cls", 3, "row"),
+    (512, 128, 8, 2, "mean", 1, "panel"),
+    (768, 384, 12, 1, "cls", 2, "panel"),
+    (1024, 256, 16, 1, "cls", 1, "panel"),
+    (384, 192, 6, 2, "cls", 1, "tiled"),
+    (640, 320, 10, 1, "mean", 1, "tiled"),
+    (512, 192, 8, 1, "cls", 1, "tiled"),  # intermediate not a multiple of 128 -> falls back to the tiles
+]
+
+
+@pytest.mark.parametrize("hidden,inter,heads,layers,pooling,labels,path", SHAPE_SWEEP)
+def test_shape_sweep_against_oracle(hidden, inter, heads, layers, pooling, labels, path):
+    """Every GEMM family (row-stationary, panel, generic tiles) on shapes other than the published ones: odd chunk
+    counts, one head, mean pooling, several ranking labels, ragged rows around the 16 / 32 / 64 / 128 boundaries."""
+
+    from open_provence_amd.config import EncoderDims
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import synth_state_dict
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = EncoderDims.from_base_model_config(
+        dict(model_type="modernbert", vocab_size=300, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+             num_attention_heads=heads, local_attention=128, global_attn_every_n_layers=2, global_rope_theta=160000.0,
+             local_rope_theta=10000.0, max_position_embeddings=512, pad_token_id=0, cls_token_id=1, sep_token_id=2,
+             classifier_pooling=pooling),
+        num_labels=labels,
+    )
+    state = synth_state_dict(dims, 29)
+    enc = HipEncoder(dims, device="cuda")
+    enc.load_state_dict(state)
+    rng = np.random.default_rng(hidden + inter)
+    lengths = [1, 15, 16, 17, 31, 33, 63, 65, 127, 129, 200, 300]
+    rows = [rng.integers(3, 299, size=n).tolist() for n in lengths]
+    prune, rank, cu = enc.forward_rows(rows)
+    assert prune.shape == (sum(lengths), 2) and rank.shape == (len(rows), labels)
+    worst = 0.0
+    for i, row in enumerate(rows):
+        ids = torch.tensor([row], dtype=torch.long)
+        ref = oracle_forward(state, dims, ids, torch.ones_like(ids))
+        worst = max(worst, (prune[cu[i] : cu[i + 1]].cpu() - ref.pruning_logits[0]).abs().max().item(),
+                    (rank[i].cpu() - ref.ranking_logits[0]).abs().max().item())
+    assert worst < 1e-3, (path, worst)
+
+
 def test_batch_composition_invariance_at_baseline_size():
     """C2 size (256 pairs x 512 tokens, xsmall dims): every pair's outputs are bit-identical whatever the
     batch order, the companions in the batch or the chunking -- pairs are independent."""
