@@ -438,11 +438,11 @@ def prepare_block_inputs(
 ) -> tuple[list[int], list[int], list[int], list[tuple[int, int]]]:
     """(input_ids, attention_mask, token_type_ids, token range of every fragment inside input_ids)."""
 
-    query = [int(t) for t in query_tokens]
+    query = list(map(int, query_tokens))
     ctx: list[int] = []
     for frag in fragments:
-        ctx.extend(int(t) for t in frag.token_ids)
-    built = [int(t) for t in tokenizer.build_inputs_with_special_tokens(query, ctx)]
+        ctx.extend(map(int, frag.token_ids))
+    built = list(map(int, tokenizer.build_inputs_with_special_tokens(query, ctx)))
 
     if manual_specials:
         ids: list[int] = []
@@ -459,7 +459,7 @@ def prepare_block_inputs(
 
     try:
         type_ids = tokenizer.create_token_type_ids_from_sequences(query, ctx)
-        type_ids = [int(t) for t in type_ids] if type_ids is not None else None
+        type_ids = list(map(int, type_ids)) if type_ids is not None else None
     except Exception:
         type_ids = None
 
