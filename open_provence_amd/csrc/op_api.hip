@@ -76,6 +76,7 @@ struct op_handle {
   bool split = true;
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
+  int n_cus = 256;          // compute units of the device (hipDeviceProp multiProcessorCount)
   int chunk_rows = 0;
   float* emb = nullptr;
   float* emb_norm = nullptr;
@@ -263,17 +264,24 @@ int launch_gemm(Launcher& L, int kind, const GemmParams& p, bool split) {
 template <int EPI, int PRO>
 int launch_rowgemm(Launcher& L, int kind, const RowGemmParams& p, int hidden, int r_pad, bool split) {
   OP_TRY(L.begin(kind));
-  const dim3 grid((unsigned)(r_pad / ROW_BM));
-  // 4 waves x 32 rows.  (rowgemm_kernel also compiles as 8 waves x 16 rows = 4 waves per SIMD at <= 128 VGPRs;
-  // measured on MI355X it is equal on the q/k/v kernel and 10 % slower on the GeGLU kernel, which spills.)
+  // 4 waves x 32 rows = 128-row blocks, two per CU.  Small batches (at most one such block per CU) use 4 waves x
+  // 16 rows = 64-row blocks instead: twice the blocks, so a latency-bound request spreads over twice the CUs.
+  // (rowgemm_kernel also compiles as 8 waves x 16 rows = 4 waves per SIMD at <= 128 VGPRs; measured on MI355X it is
+  // equal on the q/k/v kernel and 10 % slower on the GeGLU kernel, which spills.)
+  const bool small = (r_pad / ROW_BM) <= L.h->n_cus && getenv("OPEN_PROVENCE_NO_SMALL_BLOCKS") == nullptr;
+  const dim3 grid((unsigned)(r_pad / (small ? 64 : ROW_BM)));
   const dim3 block(256);
   const int ks = hidden / 32;
-#define OPK_ROW_LAUNCH(KS_)                                                                           \
-  do {                                                                                                \
-    if (split)                                                                                        \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, 4>), grid, block, 0, L.stream, p);      \
-    else                                                                                              \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, 4>), grid, block, 0, L.stream, p);     \
+#define OPK_ROW_LAUNCH(KS_)                                                                              \
+  do {                                                                                                   \
+    if (split && small)                                                                                  \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, 4, 1>), grid, block, 0, L.stream, p);      \
+    else if (split)                                                                                      \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, 4, 2>), grid, block, 0, L.stream, p);      \
+    else if (small)                                                                                      \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, 4, 1>), grid, block, 0, L.stream, p);     \
+    else                                                                                                 \
+      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, 4, 2>), grid, block, 0, L.stream, p);     \
   } while (0)
   if (ks == 4) OPK_ROW_LAUNCH(4);
   else if (ks == 8) OPK_ROW_LAUNCH(8);
@@ -750,6 +758,11 @@ int op_create(const op_config* cfg, op_handle** out) {
   } while (0)
 
   OP_CREATE_HIP(hipSetDevice(cfg->device_id));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess && prop.multiProcessorCount > 0)
+      h->n_cus = prop.multiProcessorCount;
+  }
   const size_t HH = (size_t)H * H;
   OP_CREATE_TRY(dev_alloc(h, &h->emb, (size_t)h->V * H));
   OP_CREATE_TRY(dev_alloc(h, &h->emb_norm, H));

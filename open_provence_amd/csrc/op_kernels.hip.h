@@ -852,8 +852,10 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const 
 }
 
 template <int KS, int EPI, int PRO, bool SPLIT, int WAVES, int MF = 2>
-__global__ __launch_bounds__(WAVES * 64, MF == 1 ? 4 : 2) void rowgemm_kernel(RowGemmParams p) {
-  // A block is WAVES x MF x 16 rows; the library launches 4 waves x 2 fragments = 128 rows, two blocks per CU.
+__global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void rowgemm_kernel(RowGemmParams p) {
+  // A block is WAVES x MF x 16 rows; the library launches 4 waves x 2 fragments = 128 rows, two blocks per CU, and
+  // 4 waves x 1 fragment = 64 rows for small batches (fewer than one 128-row block per CU-slot: twice the blocks, so
+  // twice the CUs work on a latency-bound request).
   // Measured alternatives on MI355X (xsmall, 256 x 512): 8 waves x 2 (256 rows, one block per CU, half the DMA
   // instructions and L2 -> LDS traffic per row) is within +-2 % on both fused kernels; 8 waves x 1 (16 rows per wave,
   // <= 128 VGPRs, 4 waves per SIMD, twice the fragment reads per MFMA) is equal on q/k/v and 10 % slower on GeGLU.
