@@ -1092,10 +1092,19 @@ int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_de
     }
     if (rows > cap) return fail(h, OP_ERR_WORKSPACE, "internal: chunk of %d rows exceeds capacity %d", rows, cap);
     // attention work items: 256-query blocks (8 waves) once a sequence is longer than 128 tokens, else 128
+    // -- unless that leaves CUs idle (small request): then 128-query blocks, twice as many work items
     const char* aw = getenv("OPEN_PROVENCE_ATT_WAVES");
-    const int att_waves = aw ? (atoi(aw) == 4 ? 4 : 8) : (max_len > 128 ? 8 : 4);
-    int att_items = 0;
-    for (int s = s0; s < s1; ++s) att_items += (cu[s + 1] - cu[s] + att_waves * 32 - 1) / (att_waves * 32);
+    auto count_items = [&](int waves) {
+      int items = 0;
+      for (int s = s0; s < s1; ++s) items += (cu[s + 1] - cu[s] + waves * 32 - 1) / (waves * 32);
+      return items;
+    };
+    int att_waves = aw ? (atoi(aw) == 4 ? 4 : 8) : (max_len > 128 ? 8 : 4);
+    int att_items = count_items(att_waves);
+    if (!aw && att_waves == 8 && (long)att_items * h->nh <= h->n_cus) {
+      att_waves = 4;
+      att_items = count_items(4);
+    }
     if (rows > 0) {
       OP_TRY(forward_chunk(h, L, ws, ids_dev, cu_dev, s0, s1 - s0, rows, max_len, total_tokens, att_waves, att_items,
                            prune_out, rank_out));
