@@ -198,6 +198,120 @@ void run(const char* label, const u16* w, float* sink, int n_chunks, int blocks)
   printf("%-58s %8.3f ms  %7.1f TFLOP/s (MFMA stream)\n", label, ms, flops / ms * 1e-9);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k-streamed structure (kstream_gemm_kernel / panel_gemm_kernel / phase 1 of the fused kernels): all N = 256 outputs of
+// the wave's 32 rows in 32 persistent accumulators (128 VGPRs), per k-step one [256 x 32] weight slab (32 KiB) by DMA and
+// this wave's A fragments (hi/lo x 2 row blocks) either fixed registers (AGLOBAL = false) or four 16-byte global loads
+// prefetched one k-step ahead (AGLOBAL = true).
+template <bool AGLOBAL, bool DMA, bool BARRIER, bool ARESIDENT = false>
+__global__ __launch_bounds__(256, 2) void kstream_kernel(const u16* __restrict__ w, const u16* __restrict__ a, int n_ksteps,
+                                                         float* __restrict__ sink) {
+  __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto stage_slab = [&](int ks, int stage) {
+    const u16* src = w + (size_t)(ks & 63) * STAGE;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int piece = wave + 4 * u;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+    }
+  };
+  // ARESIDENT: every block reads the same few A rows (L2 hits) instead of streaming its own 128 KiB from HBM
+  const u16* a_base = a + ((size_t)((ARESIDENT ? (blockIdx.x & 7) : blockIdx.x) * 8 + wave * 2) * n_ksteps * 2) * 512 + lane * 8;
+  const size_t a_block = (size_t)n_ksteps * 2 * 512;
+  bf16x8 an_hi[2], an_lo[2];
+  auto load_a = [&](int ks) {
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      an_hi[mf] = *reinterpret_cast<const bf16x8*>(a_base + mf * a_block + (size_t)ks * 1024);
+      an_lo[mf] = *reinterpret_cast<const bf16x8*>(a_base + mf * a_block + (size_t)ks * 1024 + 512);
+    }
+  };
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int nf = 0; nf < 16; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  stage_slab(0, 0);
+  stage_slab(1, 1);
+  load_a(0);
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    asm volatile("" : "+v"(an_hi[mf]));
+    asm volatile("" : "+v"(an_lo[mf]));
+  }
+  __syncthreads();
+  auto step = [&](int ks, auto cur_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
+    const int kn = ks + 1 < n_ksteps ? ks + 1 : ks;
+    if (DMA) stage_slab(kn, cur ^ 1);
+    bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      a_hi[mf] = an_hi[mf];
+      a_lo[mf] = an_lo[mf];
+    }
+    if (AGLOBAL) {
+      load_a(kn);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nf = 0; nf < 16; nf += 2) {
+      bf16x8 wh[2], wl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
+        wl[j] = lds_frag(&sW[cur][(16 + nf + j) * 512 + lane * 8]);
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)
+            acc[nf + j][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? wl[j] : wh[j], term == 1 ? a_lo[mf] : a_hi[mf],
+                                                                      acc[nf + j][mf], 0, 0, 0);
+    }
+    if (BARRIER) {
+      __syncthreads();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  for (int k0 = 0; k0 < n_ksteps; k0 += 2) {
+    step(k0, std::integral_constant<int, 0>{});
+    step(k0 + 1, std::integral_constant<int, 1>{});
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int nf = 0; nf < 16; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) total += acc[nf][mf][0] + acc[nf][mf][1] + acc[nf][mf][2] + acc[nf][mf][3];
+  if (total == 123.456f) sink[tid] = total;
+}
+
+template <bool AGLOBAL, bool DMA, bool BARRIER, bool ARESIDENT = false>
+void run_kstream(const char* label, const u16* w, const u16* a, float* sink, int n_ksteps, int blocks) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL((kstream_kernel<AGLOBAL, DMA, BARRIER, ARESIDENT>), dim3(blocks), dim3(256), 0, 0, w, a, n_ksteps, sink);
+  CHECK(hipEventRecord(e0, 0));
+  const int reps = 20;
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL((kstream_kernel<AGLOBAL, DMA, BARRIER, ARESIDENT>), dim3(blocks), dim3(256), 0, 0, w, a, n_ksteps, sink);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double flops = (double)blocks * 128 * 256 * 32 * 2 * 3 * n_ksteps;
+  printf("%-58s %8.3f ms  %7.1f TFLOP/s (MFMA stream)\n", label, ms, flops / ms * 1e-9);
+}
+
 int main() {
   const int n_chunks = 64, blocks = 1024;
   std::vector<u16> host((size_t)n_chunks * STAGE);
@@ -227,5 +341,18 @@ int main() {
   run<V, 8, true, true, true, 0, 1>(NAME "  1 wave/SIMD: dma, barrier, epilogue 16x8 fma", w, sink, n_chunks, blocks);
   CASES(0, "16x16x32")
   CASES(1, "32x32x16")
+  {
+    // k-streamed structure: K = 1024 (32 k-steps), the MLP output projection of ModernBERT-xsmall
+    const int n_ksteps = 32;
+    u16* a;
+    CHECK(hipMalloc(&a, (size_t)blocks * 8 * n_ksteps * 2 * 512 * 2));
+    CHECK(hipMemset(a, 0x3c, (size_t)blocks * 8 * n_ksteps * 2 * 512 * 2));
+    printf("k-streamed structure, 32 accumulator fragments per wave, K = 1024:\n");
+    run_kstream<false, false, false>("kstream  A in registers, no dma, no barrier", w, a, sink, n_ksteps, blocks);
+    run_kstream<false, true, true>("kstream  A in registers, dma, barrier", w, a, sink, n_ksteps, blocks);
+    run_kstream<true, true, true>("kstream  A from global (prefetch 1), dma, barrier", w, a, sink, n_ksteps, blocks);
+    run_kstream<true, false, false>("kstream  A from global (prefetch 1), no dma, no barrier", w, a, sink, n_ksteps, blocks);
+    run_kstream<true, true, true, true>("kstream  A from L2 (same rows for all blocks), dma, barrier", w, a, sink, n_ksteps, blocks);
+  }
   return 0;
 }
