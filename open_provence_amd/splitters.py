@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import math
 import re
-from typing import Callable, Iterable, Mapping
+from typing import Any, Callable, Iterable, Mapping
 
 SentenceSplitter = Callable[[str], list[str]]
 
@@ -19,6 +19,7 @@ SUPPORTED_SPLITTER_LANGUAGES = {"ja", "en", "auto"}
 DEFAULT_ENGLISH_SENTENCE_MAX_CHARS = 1200
 
 _BUNKAI = None
+_ENGLISH_SENTENCE_TOKENIZER: Any = None  # nltk Punkt model (or any object with span_tokenize), cached
 _SIMPLE_PATTERN = re.compile(r".+?(?:。|！|？|!|\?|\n|$)", re.S)
 _BULLET_PREFIX_RE = re.compile(r"""^\s*(?:[\-\*••]+|\d{1,4}[:.)]|[A-Za-z]{1}[:.)])\s+""", re.UNICODE)
 
@@ -147,6 +148,9 @@ def create_english_sentence_splitter(max_chars: int = DEFAULT_ENGLISH_SENTENCE_M
         raise ValueError("max_chars must be positive")
 
     def _punkt():
+        global _ENGLISH_SENTENCE_TOKENIZER
+        if _ENGLISH_SENTENCE_TOKENIZER is not None:  # loaded once per process, as the reference does (:466-478)
+            return _ENGLISH_SENTENCE_TOKENIZER
         try:
             import nltk
             from nltk.tokenize import PunktSentenceTokenizer  # noqa: F401
@@ -156,7 +160,8 @@ def create_english_sentence_splitter(max_chars: int = DEFAULT_ENGLISH_SENTENCE_M
                 "sentence_splitter=<callable>, language='ja', or pre-split sentences instead."
             ) from exc
         try:
-            return nltk.data.load("tokenizers/punkt/english.pickle")
+            _ENGLISH_SENTENCE_TOKENIZER = nltk.data.load("tokenizers/punkt/english.pickle")
+            return _ENGLISH_SENTENCE_TOKENIZER
         except LookupError as exc:
             raise LookupError("Missing NLTK punkt tokenizer data. Run `python -m nltk.downloader punkt`.") from exc
 

@@ -460,6 +460,71 @@ def mldr_fixture(name: str, cfg: dict[str, Any], *, max_length: int) -> None:
     print(f"[golden] {name}: {[(r['label'], len(r['expected']['records'])) for r in runs]}")
 
 
+class RegexPunkt:
+    """Deterministic stand-in for nltk's Punkt model (absent here): spans of text up to and including a run of
+    ``.!?`` that is followed by whitespace or the end, trailing whitespace excluded -- the contract
+    ``span_tokenize`` has.  Used on BOTH sides (reference and this repo) so the fixture pins everything around the
+    model: block iteration, bullet grouping, whitespace stretching, over-long clipping."""
+
+    def span_tokenize(self, text: str):
+        import re as _re
+
+        start = None
+        for m in _re.finditer(r"\S+", text):
+            if start is None:
+                start = m.start()
+            if _re.search(r"[.!?]+[\"')\]]*$", m.group(0)):
+                yield (start, m.end())
+                start = None
+        if start is not None:
+            yield (start, len(text.rstrip()))
+
+
+def splitter_texts() -> list[str]:
+    long_sentence = "This sentence goes on and on " * 40 + "until it finally stops."
+    return [
+        "Cats purr. Dogs bark!  Birds sing?\nA new line starts here. And ends.",
+        "Intro paragraph before the list:\n- first bullet item. It has two sentences.\n- second bullet\n* star bullet here.\nTrailing text after list.",
+        "1. Numbered heading\nBody under heading one. More body.\n2) Second heading\n\nBody two.",
+        "   Leading spaces and trailing newline.\n\n",
+        "No terminal punctuation at all",
+        "",
+        "   \n  ",
+        long_sentence,
+        "Short one. " + long_sentence + " Tail sentence.",
+        "Semi; colon: and a very long clause " + "word " * 120 + "; then the end.",
+        "Line one without period\nLine two without period\n\u2022 unicode bullet item one.\n\u2022 unicode bullet two",
+        "Windows line endings.\r\nSecond line here.\r\n- bullet after CRLF.",
+    ]
+
+
+def splitter_fixture(name: str) -> None:
+    """G6: the reference's English splitter (standalone.py:1032-1126, helpers :481-612) and the auto splitter's language
+    routing (:1129-1143) with the Punkt model replaced by RegexPunkt on both sides."""
+
+    ref = load_reference(emit_specials=True)
+    ref._ENGLISH_SENTENCE_TOKENIZER = RegexPunkt()
+    runs = []
+    for max_chars in (ref.DEFAULT_ENGLISH_SENTENCE_MAX_CHARS, 120, 40):
+        split = ref.create_english_sentence_splitter(max_chars)
+        runs.append({"max_chars": max_chars, "outputs": [split(t) for t in splitter_texts()]})
+    auto = ref.create_auto_sentence_splitter(japanese_splitter=ref.simple_sentence_splitter,
+                                             english_splitter=ref.create_english_sentence_splitter())
+    auto_texts = ["寿司が好きです。ラーメンも好きです。", "Sushi is tasty. Ramen too.", "漢字だけ。Mixed kana が here.", ""]
+    meta = {
+        "name": name,
+        "texts": splitter_texts(),
+        "runs": runs,
+        "auto_texts": auto_texts,
+        "auto_outputs": [auto(t) for t in auto_texts],
+        "default_max_chars": ref.DEFAULT_ENGLISH_SENTENCE_MAX_CHARS,
+        "generator": "tests/golden/make_golden.py (reference create_english_sentence_splitter / create_auto_sentence_splitter, RegexPunkt stand-in)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: {[len(o) for o in runs[0]['outputs']]}")
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--only", nargs="*", default=None)
@@ -534,6 +599,8 @@ def main() -> None:
         eval_fixture("g4_eval_dataset", g3_cfg, max_length=96)
     if want("g5_mldr_records"):
         mldr_fixture("g5_mldr_records", g3_cfg, max_length=96)
+    if want("g6_english_splitter"):
+        splitter_fixture("g6_english_splitter")
 
 
 if __name__ == "__main__":
