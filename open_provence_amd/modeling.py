@@ -275,7 +275,62 @@ class OpenProvenceModel:
         return {(k if k.startswith("pruning_head.") else f"ranking_model.{k}"): v for k, v in state_dict.items()}
 
     def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = True) -> None:
-        self.encoder.load_state_dict(self._convert_legacy_state_dict(state_dict))
+        converted = self._convert_legacy_state_dict(state_dict)
+        self.encoder.load_state_dict(converted)
+        # The device library keeps only its re-packed copies; the original tensors are retained on the host (by
+        # reference when they already live there) so that state_dict() / save_pretrained() work like the reference's.
+        self._weights = {
+            key: value.detach().to("cpu") for key, value in converted.items() if "inv_freq" not in key
+        }
+
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        """Checkpoint tensors under the reference's keys (``ranking_model.*``, ``pruning_head.*``; ref :1452-1464)."""
+
+        weights = getattr(self, "_weights", None)
+        if weights is None:
+            raise RuntimeError("no weights have been loaded into this model")
+        return dict(weights)
+
+    def save_pretrained(self, save_directory: str | Path, *, safe_serialization: bool = True) -> None:
+        """Write a checkpoint directory in the reference's format (writer: encoder.py:1040-1094; reader:
+        standalone.py:1557-1664 and :func:`from_pretrained` here): ``config.json`` with the OpenProvence fields plus
+        ``architectures`` / ``auto_map`` / ``vocab_size`` / ``hidden_size``, ``model.safetensors`` with the prefixed
+        tensors, and the tokenizer's own files.  The reference additionally copies its standalone modeling file
+        next to the weights for ``AutoModel(trust_remote_code=True)``; that file belongs to the reference package and
+        is not reproduced here."""
+
+        directory = Path(save_directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        state = {key: value.contiguous() for key, value in self.state_dict().items()}
+        payload = self.config.to_dict()
+        base = payload.get("base_model_config") or {}
+        payload["max_length"] = int(self.max_length)
+        payload["num_labels"] = int(self.num_labels)
+        payload["num_pruning_labels"] = 2
+        payload.setdefault("mode", "reranking_pruning")
+        if payload.get("encoder_architecture") is None:
+            payload["encoder_architecture"] = base.get("model_type")
+        payload["vocab_size"] = base.get("vocab_size", self.dims.vocab_size)
+        payload["hidden_size"] = base.get("hidden_size", self.dims.hidden_size)
+        payload["architectures"] = ["OpenProvenceForSequenceClassification"]
+        module = "modeling_open_provence_standalone"
+        payload["auto_map"] = {
+            "AutoConfig": f"{module}.OpenProvenceConfig",
+            "AutoModel": f"{module}.OpenProvenceForSequenceClassification",
+            "AutoModelForSequenceClassification": f"{module}.OpenProvenceForSequenceClassification",
+            "AutoModelForTokenClassification": f"{module}.OpenProvenceForTokenClassification",
+        }
+        with open(directory / "config.json", "w", encoding="utf-8") as handle:
+            json.dump(payload, handle, indent=2, sort_keys=True)
+        if safe_serialization:
+            from safetensors.torch import save_file
+
+            save_file(state, str(directory / "model.safetensors"))
+        else:
+            torch.save(state, str(directory / "pytorch_model.bin"))
+        saver = getattr(self.tokenizer, "save_pretrained", None)
+        if callable(saver):
+            saver(str(directory))
 
     @classmethod
     def from_pretrained(

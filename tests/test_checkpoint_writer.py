@@ -1,0 +1,78 @@
+"""Checkpoint writer (reference writer encoder.py:1040-1094, reader standalone.py:1557-1664).
+CPU part: the files, keys and values ``save_pretrained`` produces.  (Checked once in the build container, where the
+reference is importable: the reference's own OpenProvenceConfig.from_pretrained reads this config.json, its model
+loads this model.safetensors with no missing / unexpected keys and reproduces the oracle's logits to 1.5e-6.)"""
+
+from __future__ import annotations
+
+import json
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from helpers import CharTokenizer
+from open_provence_amd import modeling
+from open_provence_amd.config import EncoderDims, OpenProvenceConfig
+from open_provence_amd.synthetic import state_dict_keys, synth_state_dict
+
+BASE = dict(model_type="modernbert", vocab_size=256, hidden_size=128, intermediate_size=128, num_hidden_layers=3,
+            num_attention_heads=2, local_attention=32, global_attn_every_n_layers=3, global_rope_theta=160000.0,
+            local_rope_theta=10000.0, max_position_embeddings=512, pad_token_id=0, cls_token_id=1, sep_token_id=2)
+
+
+class SavingTokenizer(CharTokenizer):
+    def save_pretrained(self, directory: str) -> None:
+        with open(f"{directory}/tokenizer_config.json", "w", encoding="utf-8") as handle:
+            json.dump({"tokenizer_class": "CharTokenizer"}, handle)
+
+
+def _writer_only_model(state, config, tokenizer):
+    model = modeling.OpenProvenceModel.__new__(modeling.OpenProvenceModel)  # no GPU: only the writer is exercised
+    model.config = config
+    model.max_length = 80
+    model.num_labels = 1
+    model.dims = EncoderDims.from_base_model_config(BASE, num_labels=1)
+    model.tokenizer = tokenizer
+    model._weights = dict(state)
+    return model
+
+
+def test_save_pretrained_writes_the_reference_format(tmp_path):
+    dims = EncoderDims.from_base_model_config(BASE, num_labels=1)
+    state = synth_state_dict(dims, 41)
+    config = OpenProvenceConfig(base_model_config=BASE, tokenizer_name_or_path="char", pruning_config={"hidden_size": 128},
+                                max_length=96, default_threadshold=0.2, some_future_key="kept")
+    model = _writer_only_model(state, config, SavingTokenizer())
+    model.save_pretrained(tmp_path)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["config.json", "model.safetensors", "tokenizer_config.json"]
+
+    payload = json.loads((tmp_path / "config.json").read_text(encoding="utf-8"))
+    assert payload["model_type"] == "open_provence" and payload["mode"] == "reranking_pruning"
+    assert payload["max_length"] == 80 and payload["num_labels"] == 1 and payload["num_pruning_labels"] == 2
+    assert payload["encoder_architecture"] == "modernbert" and payload["vocab_size"] == 256 and payload["hidden_size"] == 128
+    assert payload["architectures"] == ["OpenProvenceForSequenceClassification"]
+    assert payload["auto_map"]["AutoModelForTokenClassification"].endswith("OpenProvenceForTokenClassification")
+    assert payload["default_threadshold"] == 0.2 and payload["some_future_key"] == "kept"
+    assert payload["base_model_config"]["num_hidden_layers"] == 3
+
+    saved = load_file(str(tmp_path / "model.safetensors"))
+    assert set(saved) == set(state) == {name for name, _shape in state_dict_keys(dims)}
+    assert all(k.startswith(("ranking_model.", "pruning_head.")) for k in saved)
+    assert all(torch.equal(saved[k], state[k]) for k in saved)
+
+    again = OpenProvenceConfig.from_json_file(tmp_path / "config.json")
+    assert again.max_length == 80 and again.default_threshold == 0.2 and again.encoder_dims() == dims
+
+
+def test_state_dict_requires_loaded_weights_and_bin_format(tmp_path):
+    dims = EncoderDims.from_base_model_config(BASE, num_labels=1)
+    config = OpenProvenceConfig(base_model_config=BASE, tokenizer_name_or_path="char", pruning_config={"hidden_size": 128})
+    model = _writer_only_model({}, config, CharTokenizer())
+    model._weights = None
+    with pytest.raises(RuntimeError):
+        model.state_dict()
+    model._weights = dict(synth_state_dict(dims, 3))
+    model.save_pretrained(tmp_path, safe_serialization=False)
+    loaded = torch.load(str(tmp_path / "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    assert set(loaded) == set(model._weights)

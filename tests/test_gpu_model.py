@@ -139,6 +139,15 @@ def test_from_pretrained_roundtrip_including_legacy_keys_and_bf16_weights(tmp_pa
     p3, _, _ = m3.encoder.forward_rows(rows)
     assert torch.isfinite(p3).all() and (p3 - ref_prune).abs().max() < 0.3
 
+    # writer -> reader: save_pretrained of a loaded model (legacy keys come back prefixed) reloads bit-identically
+    d4 = tmp_path / "resaved"
+    m2.save_pretrained(d4)
+    assert set(m2.state_dict()) == set(state)
+    m4 = OpenProvenceModel.from_pretrained(d4, device="cuda", tokenizer=CharTokenizer())
+    p4, r4, _ = m4.encoder.forward_rows(rows)
+    assert torch.equal(p4, ref_prune) and torch.equal(r4, ref_rank)
+    assert m4.default_threshold == pytest.approx(0.2)
+
     with pytest.raises(FileNotFoundError):
         OpenProvenceModel.from_pretrained(tmp_path / "missing", device="cuda")
 
