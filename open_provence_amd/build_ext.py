@@ -41,6 +41,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         "-fPIC",
         "-shared",
         "-Wno-unused-result",
+        # no SLP vectorizer: it fuses adjacent scalar fp32 ops of the epilogues into v_pk_* instructions, which cost
+        # more issue time beside MFMAs than the two scalar ops they replace (measured: +1.1 % pairs/s without it)
+        "-fno-slp-vectorize",
         "-o",
         str(OUTPUT),
         *[str(s) for s in SOURCES],
