@@ -312,6 +312,130 @@ void run_kstream(const char* label, const u16* w, const u16* a, float* sink, int
   printf("%-58s %8.3f ms  %7.1f TFLOP/s (MFMA stream)\n", label, ms, flops / ms * 1e-9);
 }
 
+// A fragments through a private LDS region instead of VGPR-returning loads: per k-step each wave DMAs its own four
+// 1 KiB A pieces (issued BEFORE the weight slab's pieces, so that a counted s_waitcnt can wait for them alone), reads
+// them into registers two thirds into the step's MFMAs (the region was consumed a step ago, the data landed a while
+// ago), and uses them in the next step.  80 KiB of dynamic LDS per block: two blocks still fit a CU.
+template <bool DMA, bool BARRIER>
+__global__ __launch_bounds__(256, 2) void kstream_lds_kernel(const u16* __restrict__ w, const u16* __restrict__ a, int n_ksteps,
+                                                             float* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* sA = smem + 2 * STAGE + (threadIdx.x >> 6) * 2048;  // this wave's 4 pieces [mf][plane][512]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto stage_slab = [&](int ks, int stage) {
+    const u16* src = w + (size_t)(ks & 63) * STAGE;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int piece = wave + 4 * u;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(smem + stage * STAGE + piece * 512), 16, 0, 0);
+    }
+  };
+  const u16* a_base = a + ((size_t)(blockIdx.x * 8 + wave * 2) * n_ksteps * 2) * 512 + lane * 8;
+  const size_t a_block = (size_t)n_ksteps * 2 * 512;
+  auto stage_a = [&](int ks) {
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(a_base + mf * a_block + (size_t)ks * 1024 + pl * 512),
+            (__attribute__((address_space(3))) void*)(sA + (mf * 2 + pl) * 512), 16, 0, 0);
+  };
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int nf = 0; nf < 16; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a_hi[2], a_lo[2], n_hi[2], n_lo[2];
+  stage_a(0);
+  stage_slab(0, 0);
+  stage_slab(1, 1);
+  __syncthreads();
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    n_hi[mf] = lds_frag(sA + (mf * 2) * 512 + lane * 8);
+    n_lo[mf] = lds_frag(sA + (mf * 2 + 1) * 512 + lane * 8);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  auto step = [&](int ks, auto cur_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
+    const int kn = ks + 1 < n_ksteps ? ks + 1 : ks;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      a_hi[mf] = n_hi[mf];
+      a_lo[mf] = n_lo[mf];
+    }
+    stage_a(kn);                      // 4 pieces, oldest in the queue
+    if (DMA) stage_slab(kn, cur ^ 1); // 8 pieces
+#pragma unroll
+    for (int nf = 0; nf < 16; nf += 2) {
+      bf16x8 wh[2], wl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        wh[j] = lds_frag(smem + cur * STAGE + (nf + j) * 512 + lane * 8);
+        wl[j] = lds_frag(smem + cur * STAGE + (16 + nf + j) * 512 + lane * 8);
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)
+            acc[nf + j][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? wl[j] : wh[j], term == 1 ? a_lo[mf] : a_hi[mf],
+                                                                      acc[nf + j][mf], 0, 0, 0);
+      if (nf == 10) {
+        // two thirds in: this wave's A pieces of the next k-step have landed long ago; only the slab may still fly
+        if (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+          n_hi[mf] = lds_frag(sA + (mf * 2) * 512 + lane * 8);
+          n_lo[mf] = lds_frag(sA + (mf * 2 + 1) * 512 + lane * 8);
+        }
+      }
+    }
+    if (BARRIER) {
+      __syncthreads();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+  };
+  for (int k0 = 0; k0 < n_ksteps; k0 += 2) {
+    step(k0, std::integral_constant<int, 0>{});
+    step(k0 + 1, std::integral_constant<int, 1>{});
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int nf = 0; nf < 16; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) total += acc[nf][mf][0] + acc[nf][mf][1] + acc[nf][mf][2] + acc[nf][mf][3];
+  if (total == 123.456f) sink[tid] = total;
+}
+
+template <bool DMA, bool BARRIER>
+void run_kstream_lds(const char* label, const u16* w, const u16* a, float* sink, int n_ksteps, int blocks) {
+  const size_t lds = (size_t)(2 * STAGE + 4 * 2048) * sizeof(u16);  // 80 KiB
+  CHECK(hipFuncSetAttribute((const void*)kstream_lds_kernel<DMA, BARRIER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL((kstream_lds_kernel<DMA, BARRIER>), dim3(blocks), dim3(256), lds, 0, w, a, n_ksteps, sink);
+  CHECK(hipEventRecord(e0, 0));
+  const int reps = 20;
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL((kstream_lds_kernel<DMA, BARRIER>), dim3(blocks), dim3(256), lds, 0, w, a, n_ksteps, sink);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double flops = (double)blocks * 128 * 256 * 32 * 2 * 3 * n_ksteps;
+  printf("%-58s %8.3f ms  %7.1f TFLOP/s (MFMA stream)\n", label, ms, flops / ms * 1e-9);
+}
+
 int main() {
   const int n_chunks = 64, blocks = 1024;
   std::vector<u16> host((size_t)n_chunks * STAGE);
@@ -353,6 +477,9 @@ int main() {
     run_kstream<true, true, true>("kstream  A from global (prefetch 1), dma, barrier", w, a, sink, n_ksteps, blocks);
     run_kstream<true, false, false>("kstream  A from global (prefetch 1), no dma, no barrier", w, a, sink, n_ksteps, blocks);
     run_kstream<true, true, true, true>("kstream  A from L2 (same rows for all blocks), dma, barrier", w, a, sink, n_ksteps, blocks);
+    run_kstream_lds<true, true>("kstream  A through private LDS (DMA), dma, barrier", w, a, sink, n_ksteps, blocks);
+    run_kstream<true, true, true>("kstream  A from global (prefetch 1), dma, barrier  [again]", w, a, sink, n_ksteps, blocks);
+    run_kstream<false, true, true>("kstream  A in registers, dma, barrier  [again]", w, a, sink, n_ksteps, blocks);
   }
   return 0;
 }
