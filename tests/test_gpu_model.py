@@ -312,6 +312,37 @@ def test_shape_sweep_against_oracle(hidden, inter, heads, layers, pooling, label
     assert worst < 1e-3, (path, worst)
 
 
+@pytest.mark.parametrize("hidden,inter,heads", [(128, 64, 2), (512, 128, 8)])
+def test_maximum_length_sequences(hidden, inter, heads):
+    """max_position_embeddings-long rows (8192 tokens: 32 attention blocks, 128 key tiles per query block) next to a
+    short one, on the row-stationary and the panel path."""
+
+    from open_provence_amd.config import EncoderDims
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import synth_state_dict
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = EncoderDims.from_base_model_config(
+        dict(model_type="modernbert", vocab_size=300, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=3,
+             num_attention_heads=heads, local_attention=128, global_attn_every_n_layers=3, global_rope_theta=160000.0,
+             local_rope_theta=10000.0, max_position_embeddings=8192, pad_token_id=0, cls_token_id=1, sep_token_id=2),
+        num_labels=1,
+    )
+    state = synth_state_dict(dims, 5)
+    enc = HipEncoder(dims, device="cuda")
+    enc.load_state_dict(state)
+    rng = np.random.default_rng(1)
+    rows = [rng.integers(3, 299, size=n).tolist() for n in (8192, 257)]
+    prune, rank, cu = enc.forward_rows(rows)
+    for i, row in enumerate(rows):
+        ids = torch.tensor([row], dtype=torch.long)
+        ref = oracle_forward(state, dims, ids, torch.ones_like(ids))
+        assert (prune[cu[i] : cu[i + 1]].cpu() - ref.pruning_logits[0]).abs().max() < 1e-3
+        assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3
+    with pytest.raises(Exception):  # longer than max_position_embeddings: refused, not truncated
+        enc.forward_rows([rng.integers(3, 299, size=8193).tolist()])
+
+
 def test_batch_composition_invariance_at_baseline_size():
     """C2 size (256 pairs x 512 tokens, xsmall dims): every pair's outputs are bit-identical whatever the
     batch order, the companions in the batch or the chunking -- pairs are independent."""
