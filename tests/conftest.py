@@ -19,3 +19,22 @@ def hip_library():
 
     build_ext.build()
     return _lib.load_library()
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests need a HIP device: without one (the CPU build container) they are skipped rather
+    than failed, so a plain ``pytest tests`` is green there.  On a GPU box nothing is skipped -- a missing
+    library still fails loudly inside the tests (no silent fallback)."""
+
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (no HIP device visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
