@@ -102,7 +102,7 @@ def main() -> None:
     parser.add_argument("--pairs", type=int, default=256, help="pairs per GPU")
     parser.add_argument("--seq-len", type=int, default=512)
     parser.add_argument("--model", default="xsmall", choices=["xsmall", "base", "large", "en-gte"])
-    parser.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    parser.add_argument("--precision", default="bf16x3", help="bf16x3 | bf16x2 | bf16 | family=mask,... (see open_provence_amd.engine.parse_precision)")
     parser.add_argument("--chunk-rows", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--varlen", action="store_true",

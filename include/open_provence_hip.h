@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 1
+#define OP_ABI_VERSION 2
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
@@ -43,13 +43,41 @@ enum op_status {
 enum op_dtype { OP_DTYPE_F32 = 0, OP_DTYPE_BF16 = 1, OP_DTYPE_F16 = 2 };
 
 /* Arithmetic of the MFMA contractions (accumulation is always fp32; LayerNorm, softmax, GELU,
- * RoPE and the residual stream are always fp32):
- *   OP_PRECISION_BF16X3  each operand is carried as a (hi, lo) bf16 pair and every product is
- *                        hi*hi + lo*hi + hi*lo on the bf16 MFMA pipe (~16 mantissa bits): the
- *                        mode that meets the 1e-3 parity bar against the fp32 CPU reference;
- *   OP_PRECISION_BF16    single-pass bf16 operands (what the reference itself computes with on a
- *                        GPU: standalone.py:219-233 picks bf16), ~1e-2 on logits.            */
-enum op_precision { OP_PRECISION_BF16X3 = 0, OP_PRECISION_BF16 = 1 };
+ * RoPE and the residual stream are always fp32).  Every operand can be carried as a (hi, lo) bf16
+ * pair (hi = RNE(v), lo = RNE(v - hi), ~16 mantissa bits together); a contraction left x right then
+ * evaluates hi*hi plus the optional terms of its mask:
+ *   OP_TERM_LEFT_LO   lo(left) * hi(right)        OP_TERM_RIGHT_LO   hi(left) * lo(right)
+ * "left" is the activation-side operand.  One mask per contraction family (enum op_gemm_family):
+ *   OP_PRECISION_BF16X3  all masks 3: the mode that meets the 1e-3 parity bar against the fp32 CPU
+ *                        reference for any checkpoint;
+ *   OP_PRECISION_BF16X2  weights rounded to bf16 (no hi*lo(weight) term in the four weight GEMMs),
+ *                        activations (hi, lo), attention all terms;
+ *   OP_PRECISION_BF16    all masks 0: single-pass bf16 operands (what the reference itself computes
+ *                        with on a GPU: standalone.py:219-233 picks bf16), ~1e-2 on logits;
+ *   OP_PRECISION_CUSTOM  op_config.terms[] as given.
+ * Independently of the mode, the hi*lo(weight) term of a family is dropped -- without changing a bit
+ * of the result -- when every lo element of every weight of that family is zero, i.e. for bf16
+ * checkpoints (detected in op_load_weight, applied in op_weights_ready; see op_effective_policy). */
+enum op_precision { OP_PRECISION_BF16X3 = 0, OP_PRECISION_BF16 = 1, OP_PRECISION_BF16X2 = 2, OP_PRECISION_CUSTOM = 3 };
+enum op_term { OP_TERM_LEFT_LO = 1, OP_TERM_RIGHT_LO = 2 };
+enum op_gemm_family {
+  OP_FAM_WQKV = 0,     /* LN(x) x Wqkv        HF :272      */
+  OP_FAM_QK = 1,       /* q x k               HF :166-185  */
+  OP_FAM_PV = 2,       /* softmax(..) x v                  */
+  OP_FAM_ATTN_OUT = 3, /* attention out x Wo  HF :299      */
+  OP_FAM_WI = 4,       /* LN(x) x Wi          HF :90       */
+  OP_FAM_MLP_OUT = 5,  /* GeGLU out x Wo      HF :91       */
+  OP_FAM_COUNT = 6
+};
+
+/* op_config.flags */
+enum op_flags {
+  OP_FLAG_FORCE_TILED = 1,      /* generic 128x128x32 tiled kernels for every shape (test hook)             */
+  OP_FLAG_NO_SMALL_BLOCKS = 2,  /* never use the 64-row GEMM blocks of the latency regime (measurement hook) */
+  OP_FLAG_ATT_WAVES_4 = 4,      /* 128-query attention blocks for full-attention layers (measurement hook)   */
+  OP_FLAG_ATT_WAVES_8 = 8,      /* 256-query attention blocks for full-attention layers (measurement hook)   */
+  OP_FLAG_NO_POLICY_KERNELS = 16 /* always run the all-terms kernels with cleared lo operands (test hook)    */
+};
 
 enum op_pooling { OP_POOL_CLS = 0, OP_POOL_MEAN = 1 };
 
@@ -74,6 +102,15 @@ typedef struct op_config {
   float local_rope_theta;
   int32_t chunk_rows; /* rows of the packed batch processed per pass (0 = library default) */
   uint8_t layer_is_global[OP_MAX_LAYERS]; /* 1 = full attention, 0 = sliding window */
+  uint8_t terms[8];   /* OP_PRECISION_CUSTOM: term mask per op_gemm_family (entries >= OP_FAM_COUNT unused) */
+  uint32_t flags;     /* enum op_flags */
+  /* Which hidden state feeds the pruning head (standalone.py:1695 takes outputs.hidden_states[-1]):
+   * 0 = the final_norm output (transformers >= 5 ties hidden_states[-1] to last_hidden_state,
+   * utils/output_capturing.py:269-277 -- what the reference computes in this image), 1 = the last
+   * layer's output BEFORE final_norm (what transformers 4.x ModernBertModel.forward appended, i.e.
+   * what the reference computes under its own uv.lock pin 4.57.1).  The rank head always sees the
+   * normalised state. */
+  int32_t prune_pre_final_norm;
 } op_config;
 
 int op_abi_version(void);
@@ -97,6 +134,13 @@ int op_weights_ready(op_handle* h);
  * sequences, `total_tokens` tokens, longest sequence `max_seqlen`. */
 size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int max_seqlen);
 
+/* After op_weights_ready: the term masks actually evaluated (requested policy minus the weight-lo
+ * terms that are identically zero for this checkpoint), terms_out[OP_FAM_COUNT], and *kernel_set =
+ * index of the curated kernel set that implements them with exactly those MFMA passes (0 = all
+ * terms, 1 = bf16 weights, 2 = single pass), or -1 when the policy runs on the all-terms kernels
+ * with cleared lo operands (same numerics, no speed-up). */
+int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set);
+
 /* Replaces: OpenProvenceModel.forward (standalone.py:1666-1739) = HF
  * ModernBertForSequenceClassification.forward + OpenProvenceHead.forward (standalone.py:434-448),
  * on the UNPADDED batch: ids_dev[total_tokens] are the attention_mask==1 tokens of all rows laid
@@ -104,16 +148,18 @@ size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int 
  * then reads cu_seqlens_dev back, which synchronises the stream once).
  *   prune_logits_dev [total_tokens, 2]  fp32   (pruning_logits at attention_mask==1 positions)
  *   rank_logits_dev  [n_seqs, num_labels] fp32 (ranking_logits)
+ *   keep_prob_dev    [total_tokens] fp32 or NULL: softmax(pruning_logits, -1)[:, 1] evaluated as
+ *                    sigmoid(l1 - l0) in the same kernel (replaces standalone.py:2918-2924)
  * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream). */
 int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_seqlens_dev,
                       const int32_t* cu_seqlens_host, int n_seqs, int total_tokens, int max_seqlen,
-                      float* prune_logits_dev, float* rank_logits_dev, void* workspace_dev,
-                      size_t workspace_bytes, void* hip_stream);
+                      float* prune_logits_dev, float* rank_logits_dev, float* keep_prob_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
 /* Test hook.  Replaces: output_hidden_states=True of the reference forward (standalone.py:1689,
  * 1727).  When `hidden_dev` is non-NULL the next forwards also write the (num_layers+1) hidden
  * states, fp32 [num_layers+1, total_tokens, hidden]; entry num_layers is the post-final_norm
- * tensor, as in HF.  Pass NULL to switch capturing off. */
+ * tensor, as in HF (transformers >= 5).  Pass NULL to switch capturing off. */
 int op_debug_capture_hidden(op_handle* h, float* hidden_dev);
 
 /* Measurement hook: when enabled every kernel launch of the forward is bracketed by HIP events

@@ -12,11 +12,15 @@ import os
 from pathlib import Path
 
 OP_MAX_LAYERS = 128
-OP_ABI_VERSION = 1
+OP_ABI_VERSION = 2
 
 OP_OK = 0
 OP_DTYPE_F32, OP_DTYPE_BF16, OP_DTYPE_F16 = 0, 1, 2
-OP_PRECISION_BF16X3, OP_PRECISION_BF16 = 0, 1
+OP_PRECISION_BF16X3, OP_PRECISION_BF16, OP_PRECISION_BF16X2, OP_PRECISION_CUSTOM = 0, 1, 2, 3
+OP_TERM_LEFT_LO, OP_TERM_RIGHT_LO = 1, 2
+# enum op_gemm_family: one term mask per contraction
+OP_FAMILIES = ("wqkv", "qk", "pv", "attn_out", "wi", "mlp_out")
+OP_FLAG_FORCE_TILED, OP_FLAG_NO_SMALL_BLOCKS, OP_FLAG_ATT_WAVES_4, OP_FLAG_ATT_WAVES_8, OP_FLAG_NO_POLICY_KERNELS = 1, 2, 4, 8, 16
 OP_POOL_CLS, OP_POOL_MEAN = 0, 1
 
 LIB_NAME = "libopenprovence_hip.so"
@@ -27,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "op_create",
     "op_load_weight",
     "op_weights_ready",
+    "op_effective_policy",
     "op_workspace_bytes",
     "op_forward_packed",
     "op_debug_capture_hidden",
@@ -63,6 +68,9 @@ class OpConfig(ctypes.Structure):
         ("local_rope_theta", ctypes.c_float),
         ("chunk_rows", ctypes.c_int32),
         ("layer_is_global", ctypes.c_uint8 * OP_MAX_LAYERS),
+        ("terms", ctypes.c_uint8 * 8),
+        ("flags", ctypes.c_uint32),
+        ("prune_pre_final_norm", ctypes.c_int32),
     ]
 
 
@@ -109,7 +117,9 @@ def load_library() -> ctypes.CDLL:
     lib.op_workspace_bytes.restype = cs
     lib.op_workspace_bytes.argtypes = [vp, ci, ci, ci]
     lib.op_forward_packed.restype = ci
-    lib.op_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, cs, vp]
+    lib.op_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, cs, vp]
+    lib.op_effective_policy.restype = ci
+    lib.op_effective_policy.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ci)]
     lib.op_debug_capture_hidden.restype = ci
     lib.op_debug_capture_hidden.argtypes = [vp, vp]
     lib.op_profile_enable.restype = ci

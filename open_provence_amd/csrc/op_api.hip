@@ -14,9 +14,13 @@
 #include <string>
 #include <vector>
 
-#include "op_kernels.hip.h"
+#define OPK_PACK_KERNELS 1
+#include "op_internal.h"
+#include "opk_small.hip.h"
+#include "opk_tiled.hip.h"
 
 using namespace opk;
+using opl::Policy;
 
 namespace {
 
@@ -42,13 +46,15 @@ enum ProfileKind {
   PK_KSTREAM_MLP_OUT,
   PK_FUSED_ATTN_OUT_WI,
   PK_FUSED_MLP_OUT_QKV,
+  PK_CLEAR_LO,
   PK_COUNT
 };
 const char* kProfileNames[PK_COUNT] = {"rowmap",        "embed_ln",      "layer_norm",    "gemm_qk_rope", "gemm_v_t",
                                        "attn_global",   "attn_local",    "gemm_attn_out", "gemm_wi_geglu",
                                        "gemm_mlp_out",  "final_ln_prune", "rank_head",    "capture",
                                        "rowgemm_ln_qkv_rope", "rowgemm_attn_out", "rowgemm_ln_wi_geglu",
-                                       "kstream_mlp_out", "fused_attnout_ln_wi_geglu", "fused_mlpout_ln_qkv_rope"};
+                                       "kstream_mlp_out", "fused_attnout_ln_wi_geglu", "fused_mlpout_ln_qkv_rope",
+                                       "clear_lo_planes"};
 
 struct LayerWeights {
   float* attn_norm = nullptr;  // absent on layer 0
@@ -73,7 +79,12 @@ struct ProfileEvent {
 struct op_handle {
   op_config cfg;
   int H = 0, I = 0, N = 0, nh = 0, V = 0, nl = 0, max_pos = 0;
-  bool split = true;
+  Policy req = opl::kPolicies[0];  // requested term masks (op_config.precision / terms)
+  Policy eff = opl::kPolicies[0];  // evaluated term masks: req minus weight-lo terms that are identically zero
+  int pi = 0;                      // curated kernel set that runs `eff` (index into opl::kPolicies)
+  bool emulate = false;            // eff is not curated: kernel set 0 with the unused lo operands cleared
+  bool resolved = false;           // eff / pi / emulate are valid (set by op_weights_ready)
+  int* any_lo_dev = nullptr;       // [OP_FAM_COUNT] device flags: some weight of the family has a non-zero lo element
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
   int n_cus = 256;          // compute units of the device (hipDeviceProp multiProcessorCount)
@@ -204,7 +215,7 @@ struct Workspace {
   u16 *vt_hi, *vt_lo;
   u16 *o_hi, *o_lo;
   u16 *h_hi, *h_lo;
-  int32_t *row_seq, *row_pos, *row_tok, *roff, *qboff;
+  int32_t *row_seq, *row_pos, *row_tok, *roff, *qboff, *qboff_l;
   float* cls;
   size_t bytes;
 };
@@ -245,6 +256,7 @@ void carve(const op_handle* h, char* base, int cap_rows_pad, int n_seqs, Workspa
   ws.row_tok = (int32_t*)take(R * 4);
   ws.roff = (int32_t*)take(((size_t)n_seqs + 1) * 4);
   ws.qboff = (int32_t*)take(((size_t)n_seqs + 1) * 4);
+  ws.qboff_l = (int32_t*)take(((size_t)n_seqs + 1) * 4);
   ws.cls = (float*)take(std::max<size_t>((size_t)n_seqs, 1) * H * 4);
   ws.bytes = off;
 }
@@ -260,58 +272,24 @@ int launch_gemm(Launcher& L, int kind, const GemmParams& p, bool split) {
   return L.end();
 }
 
-
-template <int EPI, int PRO>
-int launch_rowgemm(Launcher& L, int kind, const RowGemmParams& p, int hidden, int r_pad, bool split) {
-  OP_TRY(L.begin(kind));
-  // 4 waves x 32 rows = 128-row blocks, two per CU.  Small batches (at most one such block per CU) use 4 waves x
-  // 16 rows = 64-row blocks instead: twice the blocks, so a latency-bound request spreads over twice the CUs.
-  // (rowgemm_kernel also compiles as 8 waves x 16 rows = 4 waves per SIMD at <= 128 VGPRs; measured on MI355X it is
-  // equal on the q/k/v kernel and 10 % slower on the GeGLU kernel, which spills.)
-  const bool small = (r_pad / ROW_BM) <= L.h->n_cus && getenv("OPEN_PROVENCE_NO_SMALL_BLOCKS") == nullptr;
-  const dim3 grid((unsigned)(r_pad / (small ? 64 : ROW_BM)));
-  const dim3 block(256);
-  const int ks = hidden / 32;
-#define OPK_ROW_LAUNCH(KS_)                                                                              \
-  do {                                                                                                   \
-    if (split && small)                                                                                  \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, 4, 1>), grid, block, 0, L.stream, p);      \
-    else if (split)                                                                                      \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, true, 4, 2>), grid, block, 0, L.stream, p);      \
-    else if (small)                                                                                      \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, 4, 1>), grid, block, 0, L.stream, p);     \
-    else                                                                                                 \
-      hipLaunchKernelGGL((rowgemm_kernel<KS_, EPI, PRO, false, 4, 2>), grid, block, 0, L.stream, p);     \
-  } while (0)
-  if (ks == 4) OPK_ROW_LAUNCH(4);
-  else if (ks == 8) OPK_ROW_LAUNCH(8);
-  else return fail(L.h, OP_ERR_UNSUPPORTED, "row-stationary GEMM supports hidden 128 or 256, got %d", hidden);
-#undef OPK_ROW_LAUNCH
+// Clear the lo plane of a fragment-packed tensor: a policy without that operand's lo term, evaluated on the
+// all-terms kernel set (the extra MFMA pass then adds exact zeros).
+int clear_lo(Launcher& L, u16* base, int unit, size_t n_pairs) {
+  OP_TRY(L.begin(PK_CLEAR_LO));
+  const size_t n = n_pairs * (size_t)(unit / 8);
+  hipLaunchKernelGGL(zero_odd_units_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L.stream, base, unit, n_pairs);
   return L.end();
 }
 
-int launch_kstream(Launcher& L, int kind, const KStreamParams& p, int hidden, int r_pad, bool split) {
-  OP_TRY(L.begin(kind));
-  const dim3 grid((unsigned)(r_pad / ROW_BM));
-  const dim3 block(256);
-  const int nf = hidden / 16;
-#define OPK_KS_LAUNCH(NF_)                                                                        \
-  do {                                                                                            \
-    if (split)                                                                                    \
-      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, true, 4>), grid, block, 0, L.stream, p);       \
-    else                                                                                          \
-      hipLaunchKernelGGL((kstream_gemm_kernel<NF_, false, 4>), grid, block, 0, L.stream, p);      \
-  } while (0)
-  if (nf == 8) OPK_KS_LAUNCH(8);
-  else if (nf == 16) OPK_KS_LAUNCH(16);
-  else return fail(L.h, OP_ERR_UNSUPPORTED, "k-streamed GEMM supports hidden 128 or 256, got %d", hidden);
-#undef OPK_KS_LAUNCH
-  return L.end();
-}
+struct AttnPlan {
+  int waves_g;  // waves per block of the full-attention layers (8 or 4); sliding-window layers always use 4
+  int items_g;  // work items (sequence, query block) of a full-attention layer
+  int items_l;  // ... of a sliding-window layer (128-query blocks)
+};
 
 int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t* ids_dev, const int32_t* cu_dev, int s0,
-                  int ns, int rows, int max_len, int total_tokens, int att_waves, int att_items, float* prune_out,
-                  float* rank_out) {
+                  int ns, int rows, int max_len, int total_tokens, const AttnPlan& plan, float* prune_out, float* rank_out,
+                  float* keep_prob) {
   const int H = h->H, I = h->I;
   // Row path: exactly the computed rows, rounded to the 128-row block -- no slack rows: a 131072-row batch is 1024
   // blocks = two full rounds of 2 blocks per CU; two extra (empty) blocks would cost a third round.  The tiled path
@@ -320,12 +298,25 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   const int r_pad = fp_layout ? align_up(rows, ROW_BM) : align_up(rows + 64, 256);
   const int m_tiles = r_pad / GEMM_BM;
   const unsigned row_blocks = (unsigned)((r_pad + 3) / 4);
-  const bool split = h->split;
   hipStream_t st = L.stream;
+
+  // Evaluated policy E, instantiated kernel set V (V has every term of E).  Where V multiplies by a lo operand that
+  // E does not have, that operand is cleared: weights at load time (op_load_weight), activations right here.
+  const Policy E = h->eff, V = opl::kPolicies[h->pi];
+  auto extra = [](int v, int e, int bit) { return (v & bit) != 0 && (e & bit) == 0; };
+  const bool clr_q = extra(V.qk, E.qk, 1), clr_k = extra(V.qk, E.qk, 2), clr_v = extra(V.pv, E.pv, 2);
+  const bool clr_o = extra(V.attn_out, E.attn_out, 1), clr_h = extra(V.mlp_out, E.mlp_out, 1);
+  const bool clr_ln_attn = extra(V.wqkv, E.wqkv, 1), clr_ln_mlp = extra(V.wi, E.wi, 1);
+  const bool zero_p_lo = extra(V.pv, E.pv, 1);
+  // tiled path: two kernel sets only (single pass / all terms)
+  const bool split = (E.wqkv | E.qk | E.pv | E.attn_out | E.wi | E.mlp_out) != 0;
 
   OP_TRY(L.begin(PK_ROWMAP));
   hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, ROW_ALIGN, ROW_ALIGN, ws.roff);
-  if (fp_layout) hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, att_waves * 32, 1, ws.qboff);
+  if (fp_layout) {
+    hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, plan.waves_g * 32, 1, ws.qboff);
+    hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, 128, 1, ws.qboff_l);
+  }
   hipLaunchKernelGGL(row_map_kernel, dim3((unsigned)((r_pad + 255) / 256)), dim3(256), 0, st, cu_dev, s0, ns, ws.roff,
                      r_pad, ws.row_seq, ws.row_pos, ws.row_tok);
   OP_TRY(L.end());
@@ -358,27 +349,16 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
                        h->capture + (size_t)index * total_tokens * H);
     return L.end();
   };
-  auto layer_norm = [&](const float* w) -> int {
-    OP_TRY(L.begin(PK_LN));
-    if (split)
-      hipLaunchKernelGGL((ln_kernel<true>), dim3(row_blocks), dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
-                         ws.ln_hi, ws.ln_lo);
-    else
-      hipLaunchKernelGGL((ln_kernel<false>), dim3(row_blocks), dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
-                         ws.ln_hi, ws.ln_lo);
-    return L.end();
-  };
 
+  const size_t plane_bytes = (size_t)r_pad * H * sizeof(u16);  // one row-major plane (tiled path)
   const int q_tiles = (max_len + ATT_BQ - 1) / ATT_BQ;
-
-  const bool fuse = getenv("OPEN_PROVENCE_NO_FUSE") == nullptr;
 
   auto attention = [&](bool is_global) -> int {
     OP_TRY(L.begin(is_global ? PK_ATTN_GLOBAL : PK_ATTN_LOCAL));
-    // fragment-packed attention: one block per (sequence, block of att_waves * 32 queries, head) work item
-    const dim3 grid(fp_layout ? (unsigned)att_items : (unsigned)q_tiles, (unsigned)h->nh, fp_layout ? 1u : (unsigned)ns);
     const int window = is_global ? -1 : h->cfg.local_attention / 2;
     if (fp_layout) {
+      // one block per (sequence, query block, head) work item: 256- or 128-query blocks on 64-key tiles for the
+      // full-attention layers, 128-query blocks on 32-key tiles for the sliding-window layers
       AttnFpParams ap;  // q_hi/q_lo (k, vt, o likewise) are adjacent: together they hold the fragment-packed tensor
       ap.q_fp = ws.q_hi;
       ap.k_fp = ws.k_hi;
@@ -387,20 +367,16 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.cu = cu_dev;
       ap.s0 = s0;
       ap.roff = ws.roff;
-      ap.qboff = ws.qboff;
+      ap.qboff = is_global ? ws.qboff : ws.qboff_l;
       ap.ns = ns;
       ap.H = H;
       ap.r_pad = r_pad;
       ap.window = window;
-      if (split && att_waves == 8)
-        hipLaunchKernelGGL((attn_fp_kernel<true, 8>), grid, dim3(512), 0, st, ap);
-      else if (split)
-        hipLaunchKernelGGL((attn_fp_kernel<true, 4>), grid, dim3(256), 0, st, ap);
-      else if (att_waves == 8)
-        hipLaunchKernelGGL((attn_fp_kernel<false, 8>), grid, dim3(512), 0, st, ap);
-      else
-        hipLaunchKernelGGL((attn_fp_kernel<false, 4>), grid, dim3(256), 0, st, ap);
+      const dim3 grid((unsigned)(is_global ? plan.items_g : plan.items_l), (unsigned)h->nh);
+      if (!opl::launch_attn(st, ap, is_global ? plan.waves_g : 4, is_global ? 2 : 1, h->pi, zero_p_lo, grid))
+        return fail(h, OP_ERR_UNSUPPORTED, "internal: no attention kernel for this configuration");
     } else {
+      const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
       AttnParams ap;
       ap.q_hi = ws.q_hi;
       ap.q_lo = ws.q_lo;
@@ -416,12 +392,27 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.H = H;
       ap.r_pad = r_pad;
       ap.window = window;
+      ap.zero_p_lo = (E.pv & 1) ? 0 : 1;
       if (split)
         hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(256), 0, st, ap);
       else
         hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(256), 0, st, ap);
     }
-    return L.end();
+    OP_TRY(L.end());
+    if (fp_layout && clr_o) OP_TRY(clear_lo(L, ws.o_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
+    if (!fp_layout && split && !(E.attn_out & 1)) OP_HIP(h, hipMemsetAsync(ws.o_lo, 0, plane_bytes, st));
+    return OP_OK;
+  };
+  // fragment-packed q / k / v^T just written by a q/k/v projection: clear what the policy does not carry
+  auto clear_qkv = [&]() -> int {
+    if (clr_q) OP_TRY(clear_lo(L, ws.q_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
+    if (clr_k) OP_TRY(clear_lo(L, ws.k_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
+    if (clr_v) OP_TRY(clear_lo(L, ws.vt_hi, 2048, (size_t)h->nh * (r_pad / 32)));
+    return OP_OK;
+  };
+  auto clear_h = [&]() -> int {
+    if (clr_h) OP_TRY(clear_lo(L, ws.h_hi, 512, (size_t)(r_pad / 16) * (I / 32)));
+    return OP_OK;
   };
 
   // parameters of a q/k/v projection of layer `li` (row-stationary kernels)
@@ -446,8 +437,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     rp.o1_hi = ws.k_hi;
     rp.o2_hi = ws.vt_hi;
     rp.ld_out = H;
+    rp.zero_a_lo = clr_ln_attn ? 1 : 0;
     return rp;
   };
+  // 4 waves x 32 rows = 128-row blocks, two per CU.  Small batches (at most one such block per CU) use 4 waves x
+  // 16 rows = 64-row blocks instead: twice the blocks, so a latency-bound request spreads over twice the CUs.
+  const bool small_blocks = (r_pad / ROW_BM) <= h->n_cus && !(h->cfg.flags & OP_FLAG_NO_SMALL_BLOCKS);
+  const unsigned row_grid = (unsigned)(r_pad / (small_blocks ? 64 : ROW_BM));
+  const char* no_kernel = "internal: no row-stationary kernel for hidden %d";
 
   for (int li = 0; li < h->N; ++li) {
     const LayerWeights& lw = h->layers[li];
@@ -455,16 +452,17 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     OP_TRY(capture(li));
 
     if (h->row_path) {
-      // ---- row-stationary path (hidden <= 256) --------------------------------------------------------
+      // ---- row-stationary path (hidden <= 256): three launches per layer ------------------------------
       if (li == 0) {  // layer 0 has no attn_norm: split x0 directly
         RowGemmParams rp = qkv_params(0);
-        OP_TRY((launch_rowgemm<RE_QKV, RP_SPLIT>(L, PK_ROW_QKV, rp, H, r_pad, split)));
-      } else if (!fuse) {
-        RowGemmParams rp = qkv_params(li);
-        OP_TRY((launch_rowgemm<RE_QKV, RP_LN>(L, PK_ROW_QKV, rp, H, r_pad, split)));
+        OP_TRY(L.begin(PK_ROW_QKV));
+        if (!opl::launch_row_qkv0(st, rp, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+        OP_TRY(L.end());
+        OP_TRY(clear_qkv());
       }  // else: q/k/v of this layer were produced by the fused kernel that closed layer li-1
       OP_TRY(attention(is_global));
 
+      // x += o Wo^T ; h = GeGLU(LN(x) Wi^T)   -- one kernel, the hidden state stays in registers in between
       RowGemmParams rp;
       memset(&rp, 0, sizeof(rp));
       rp.eps = h->cfg.norm_eps;
@@ -475,43 +473,36 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       rp.n_chunks = 2 * I / ROW_CHUNK;
       rp.o0_hi = ws.h_hi;  // fragment-packed h (h_hi + h_lo are one buffer)
       rp.ld_out = I;
-      if (fuse) {
-        // x += o Wo^T ; h = GeGLU(LN(x) Wi^T)   -- one kernel, the hidden state stays in registers in between
-        rp.a1_fp = ws.o_hi;
-        rp.w1p = lw.wo_ks;
-        rp.k1_steps = H / 32;
-        rp.x_io = ws.x;
-        OP_TRY((launch_rowgemm<RE_GEGLU, RP_KSTREAM>(L, PK_FUSED_ATTN_OUT_WI, rp, H, r_pad, split)));
-      } else {
-        RowGemmParams ro;
-        memset(&ro, 0, sizeof(ro));
-        ro.hidden = H;
-        ro.r_pad = r_pad;
-        ro.a_hi = ws.o_hi;
-        ro.wp = lw.wo_pk;
-        ro.n_chunks = H / ROW_CHUNK;
-        ro.x = ws.x;
-        ro.ld_out = H;
-        OP_TRY((launch_rowgemm<RE_RESIDUAL, RP_PLANES>(L, PK_ROW_ATTN_OUT, ro, H, r_pad, split)));
-        rp.x_in = ws.x;
-        OP_TRY((launch_rowgemm<RE_GEGLU, RP_LN>(L, PK_ROW_WI_GEGLU, rp, H, r_pad, split)));
-      }
+      rp.a1_fp = ws.o_hi;
+      rp.w1p = lw.wo_ks;
+      rp.k1_steps = H / 32;
+      rp.x_io = ws.x;
+      rp.zero_a_lo = clr_ln_mlp ? 1 : 0;
+      OP_TRY(L.begin(PK_FUSED_ATTN_OUT_WI));
+      if (!opl::launch_row_geglu_fused(st, rp, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+      OP_TRY(L.end());
+      OP_TRY(clear_h());
 
-      if (fuse && li + 1 < h->N) {
+      if (li + 1 < h->N) {
         // x += h Wo^T ; q, k, v^T of the NEXT layer = RoPE / transpose of LN(x) Wqkv^T
         RowGemmParams rq = qkv_params(li + 1);
         rq.a1_fp = ws.h_hi;
         rq.w1p = lw.wo2_pk;
         rq.k1_steps = I / 32;
         rq.x_io = ws.x;
-        OP_TRY((launch_rowgemm<RE_QKV, RP_KSTREAM>(L, PK_FUSED_MLP_OUT_QKV, rq, H, r_pad, split)));
+        OP_TRY(L.begin(PK_FUSED_MLP_OUT_QKV));
+        if (!opl::launch_row_qkv_fused(st, rq, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+        OP_TRY(L.end());
+        OP_TRY(clear_qkv());
       } else {
         KStreamParams kp;
         kp.a_fp = ws.h_hi;
         kp.wp = lw.wo2_pk;
         kp.n_ksteps = I / 32;
         kp.x = ws.x;
-        OP_TRY(launch_kstream(L, PK_KSTREAM_MLP_OUT, kp, H, r_pad, split));
+        OP_TRY(L.begin(PK_KSTREAM_MLP_OUT));
+        if (!opl::launch_kstream(st, kp, H / 16, h->pi, (unsigned)(r_pad / ROW_BM))) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+        OP_TRY(L.end());
       }
       continue;
     }
@@ -519,34 +510,26 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     if (h->panel_path) {
       // ---- panel path (hidden % 256 == 0): LayerNorm -> fragment-packed planes, k-streamed panel GEMMs ----
       const dim3 ln_grid((unsigned)(r_pad / 16));
-      auto layer_norm_fp = [&](const float* w) -> int {
+      auto layer_norm_fp = [&](const float* w, bool with_lo, bool clear) -> int {
         OP_TRY(L.begin(PK_LN));
-        if (split)
+        if (with_lo)
           hipLaunchKernelGGL((ln_fp_kernel<true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
                              w ? 1 : 0, ws.ln_hi);
         else
           hipLaunchKernelGGL((ln_fp_kernel<false>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
                              w ? 1 : 0, ws.ln_hi);
-        return L.end();
+        OP_TRY(L.end());
+        if (clear) OP_TRY(clear_lo(L, ws.ln_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
+        return OP_OK;
       };
       auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles) -> int {
         OP_TRY(L.begin(kind));
         const dim3 grid((unsigned)(r_pad / ROW_BM), (unsigned)n_tiles);
-#define OPK_PANEL(EPI_)                                                                         \
-  do {                                                                                          \
-    if (split)                                                                                  \
-      hipLaunchKernelGGL((panel_gemm_kernel<EPI_, true>), grid, dim3(256), 0, st, pp);          \
-    else                                                                                        \
-      hipLaunchKernelGGL((panel_gemm_kernel<EPI_, false>), grid, dim3(256), 0, st, pp);         \
-  } while (0)
-        if (epi == PE_RESIDUAL) OPK_PANEL(PE_RESIDUAL);
-        else if (epi == PE_QK) OPK_PANEL(PE_QK);
-        else if (epi == PE_V) OPK_PANEL(PE_V);
-        else OPK_PANEL(PE_GEGLU);
-#undef OPK_PANEL
+        if (!opl::launch_panel(st, pp, epi, h->pi, grid)) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
         return L.end();
       };
-      OP_TRY(layer_norm_fp(li != 0 ? lw.attn_norm : nullptr));  // layer 0: attn_norm is Identity -> plain split
+      // layer 0: attn_norm is Identity -> plain split
+      OP_TRY(layer_norm_fp(li != 0 ? lw.attn_norm : nullptr, (V.wqkv & 1) != 0, clr_ln_attn));
       PanelParams pp;
       memset(&pp, 0, sizeof(pp));
       pp.r_pad = r_pad;
@@ -564,28 +547,45 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       pp.wp = lw.wqkv_pk + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
       pp.o0 = ws.vt_hi;
       OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
+      OP_TRY(clear_qkv());
       OP_TRY(attention(is_global));
       pp.a_fp = ws.o_hi;
       pp.wp = lw.wo_ks;
       pp.x = ws.x;
       pp.ld_out = H;
-      OP_TRY(panel(PK_GEMM_ATTN_OUT, PE_RESIDUAL, pp, H / 256));
-      OP_TRY(layer_norm_fp(lw.mlp_norm));
+      OP_TRY(panel(PK_GEMM_ATTN_OUT, 100, pp, H / 256));
+      OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp));
       pp.a_fp = ws.ln_hi;
       pp.wp = lw.wi_pk;
       pp.o0 = ws.h_hi;
       pp.ld_out = I;
       OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128));
+      OP_TRY(clear_h());
       pp.a_fp = ws.h_hi;
       pp.n_ksteps = I / 32;
       pp.wp = lw.wo2_pk;
       pp.ld_out = H;
-      OP_TRY(panel(PK_GEMM_MLP_OUT, PE_RESIDUAL, pp, H / 256));
+      OP_TRY(panel(PK_GEMM_MLP_OUT, 101, pp, H / 256));
       continue;
     }
 
-    // ---- tiled path (any hidden % 128 == 0): separate LayerNorm kernels, 128 x 128 x 32 tiles, row-major planes ----
-    if (li != 0) OP_TRY(layer_norm(lw.attn_norm));
+    // ---- tiled path (any hidden % 128 == 0): separate LayerNorm kernels, 128 x 128 x 32 tiles, row-major planes.
+    // Two kernel sets (single pass / all terms); a narrower policy clears the lo planes it does not carry. ----
+    auto layer_norm = [&](const float* w, int term_mask) -> int {
+      if (w) {
+        OP_TRY(L.begin(PK_LN));
+        if (split)
+          hipLaunchKernelGGL((ln_kernel<true>), dim3(row_blocks), dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                             ws.ln_hi, ws.ln_lo);
+        else
+          hipLaunchKernelGGL((ln_kernel<false>), dim3(row_blocks), dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                             ws.ln_hi, ws.ln_lo);
+        OP_TRY(L.end());
+      }
+      if (split && !(term_mask & 1)) OP_HIP(h, hipMemsetAsync(ws.ln_lo, 0, plane_bytes, st));
+      return OP_OK;
+    };
+    OP_TRY(layer_norm(li != 0 ? lw.attn_norm : nullptr, E.wqkv));  // layer 0: embed_ln wrote the planes
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.a_hi = ws.ln_hi;
@@ -615,6 +615,9 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     p.o0_lo = ws.vt_lo;
     p.ld_out = r_pad;
     OP_TRY(launch_gemm<EPI_V_T>(L, PK_GEMM_V_T, p, split));
+    if (split && !(E.qk & 1)) OP_HIP(h, hipMemsetAsync(ws.q_lo, 0, plane_bytes, st));
+    if (split && !(E.qk & 2)) OP_HIP(h, hipMemsetAsync(ws.k_lo, 0, plane_bytes, st));
+    if (split && !(E.pv & 2)) OP_HIP(h, hipMemsetAsync(ws.vt_lo, 0, plane_bytes, st));
 
     OP_TRY(attention(is_global));
 
@@ -629,7 +632,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     p.ld_out = H;
     OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_ATTN_OUT, p, split));
     // x += (gelu(a) * g) Wo^T,  (a, g) = LN(x) Wi^T
-    OP_TRY(layer_norm(lw.mlp_norm));
+    OP_TRY(layer_norm(lw.mlp_norm, E.wi));
     p.a_hi = ws.ln_hi;
     p.a_lo = ws.ln_lo;
     p.w_hi = lw.wi_hi;
@@ -640,6 +643,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     p.o0_lo = ws.h_lo;
     p.ld_out = I;
     OP_TRY(launch_gemm<EPI_GEGLU>(L, PK_GEMM_WI_GEGLU, p, split));
+    if (split && !(E.mlp_out & 1)) OP_HIP(h, hipMemsetAsync(ws.h_lo, 0, (size_t)r_pad * I * sizeof(u16), st));
     p.a_hi = ws.h_hi;
     p.a_lo = ws.h_lo;
     p.w_hi = lw.wo2_hi;
@@ -654,7 +658,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   const int mean_pool = h->cfg.pooling == OP_POOL_MEAN ? 1 : 0;
   OP_TRY(L.begin(PK_FINAL_LN_PRUNE));
   hipLaunchKernelGGL(final_ln_prune_kernel, dim3(row_blocks), dim3(256), 0, st, ws.x, h->final_norm, h->cfg.norm_eps, H,
-                     r_pad, ws.row_tok, ws.row_seq, ws.row_pos, h->prune_w, h->prune_b, prune_out, mean_pool, ws.cls,
+                     r_pad, ws.row_tok, ws.row_seq, ws.row_pos, h->prune_w, h->prune_b, prune_out, keep_prob,
+                     h->cfg.prune_pre_final_norm ? 1 : 0, mean_pool, ws.cls,
                      h->capture ? h->capture + (size_t)h->N * total_tokens * H : nullptr);
   OP_TRY(L.end());
   OP_TRY(L.begin(PK_RANK_HEAD));
@@ -702,8 +707,19 @@ int op_create(const op_config* cfg, op_handle** out) {
     return fail(nullptr, OP_ERR_UNSUPPORTED, "hidden_size %d must be a multiple of 128 and <= 1024", H);
   if (I % 64 != 0) return fail(nullptr, OP_ERR_UNSUPPORTED, "intermediate_size %d must be a multiple of 64", I);
   if (cfg->num_labels > 64) return fail(nullptr, OP_ERR_UNSUPPORTED, "num_labels %d > 64", cfg->num_labels);
-  if (cfg->precision != OP_PRECISION_BF16X3 && cfg->precision != OP_PRECISION_BF16)
-    return fail(nullptr, OP_ERR_INVALID, "unknown precision %d", cfg->precision);
+  Policy req;
+  switch (cfg->precision) {
+    case OP_PRECISION_BF16X3: req = opl::kPolicies[0]; break;
+    case OP_PRECISION_BF16X2: req = opl::kPolicies[1]; break;
+    case OP_PRECISION_BF16: req = opl::kPolicies[2]; break;
+    case OP_PRECISION_CUSTOM:
+      for (int f = 0; f < OP_FAM_COUNT; ++f)
+        if (cfg->terms[f] > 3) return fail(nullptr, OP_ERR_INVALID, "terms[%d] = %d is not a term mask (0..3)", f, cfg->terms[f]);
+      req = Policy{cfg->terms[OP_FAM_WQKV], cfg->terms[OP_FAM_QK], cfg->terms[OP_FAM_PV], cfg->terms[OP_FAM_ATTN_OUT],
+                   cfg->terms[OP_FAM_WI], cfg->terms[OP_FAM_MLP_OUT]};
+      break;
+    default: return fail(nullptr, OP_ERR_INVALID, "unknown precision %d", cfg->precision);
+  }
   if (cfg->pooling != OP_POOL_CLS && cfg->pooling != OP_POOL_MEAN)
     return fail(nullptr, OP_ERR_INVALID, "unknown pooling %d", cfg->pooling);
   if (cfg->local_attention < 0 || cfg->max_position_embeddings <= 0)
@@ -727,13 +743,13 @@ int op_create(const op_config* cfg, op_handle** out) {
   h->V = cfg->vocab_size;
   h->nl = cfg->num_labels;
   h->max_pos = cfg->max_position_embeddings;
-  h->split = cfg->precision == OP_PRECISION_BF16X3;
+  h->req = h->eff = req;
   h->chunk_rows = cfg->chunk_rows > 0 ? align_up(cfg->chunk_rows, ROW_ALIGN) : 262144;  // grids must cover the chip several times over
   h->layers.resize(N);
   // H % 64 and I % 32: every row-GEMM streams an EVEN number of 32-feature chunks on each side of the q/k -> v
   // boundary (H/16 q/k chunks, H/32 v chunks, H/32 out-projection chunks, I/16 Wi chunks) -- rowgemm_kernel's
   // two-stage loop is unrolled by two.
-  const bool force_tiled = getenv("OPEN_PROVENCE_FORCE_TILED") != nullptr;
+  const bool force_tiled = (cfg->flags & OP_FLAG_FORCE_TILED) != 0;
   h->row_path = (H <= 256) && (H % 64 == 0) && (I % 32 == 0) && !force_tiled;
   // panels of 256 output features (4 heads; 128 GeGLU input + 128 gate columns), an even number of k-steps
   h->panel_path = !h->row_path && (H % 256 == 0) && (I % 128 == 0) && !force_tiled;
@@ -764,6 +780,8 @@ int op_create(const op_config* cfg, op_handle** out) {
       h->n_cus = prop.multiProcessorCount;
   }
   const size_t HH = (size_t)H * H;
+  OP_CREATE_TRY(dev_alloc(h, &h->any_lo_dev, OP_FAM_COUNT));
+  OP_CREATE_HIP(hipMemset(h->any_lo_dev, 0, OP_FAM_COUNT * sizeof(int)));
   OP_CREATE_TRY(dev_alloc(h, &h->emb, (size_t)h->V * H));
   OP_CREATE_TRY(dev_alloc(h, &h->emb_norm, H));
   OP_CREATE_TRY(dev_alloc(h, &h->final_norm, H));
@@ -844,6 +862,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   u16* dst_pk = nullptr;
   u16* dst_ks = nullptr;  // additional k-streamed packing (attention Wo)
   int pk_mode = -1;
+  int family = -1;        // op_gemm_family of a GEMM weight
   Kind kind = F32_COPY;
   float* dst_f32 = nullptr;
   u16 *dst_hi = nullptr, *dst_lo = nullptr;
@@ -884,16 +903,16 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       dst_f32 = lw.mlp_norm; expect(H, 1);
     } else if (t == "attn.Wqkv.weight") {
       kind = PLANES; dst_hi = lw.wqkv_hi; dst_lo = lw.wqkv_lo; expect(3 * H, H);
-      dst_pk = lw.wqkv_pk; pk_mode = RE_QKV;
+      dst_pk = lw.wqkv_pk; pk_mode = RE_QKV; family = OP_FAM_WQKV;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
-      dst_pk = lw.wo_pk; pk_mode = RE_RESIDUAL; dst_ks = lw.wo_ks;
+      dst_pk = lw.wo_pk; pk_mode = RE_RESIDUAL; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
-      dst_pk = lw.wi_pk; pk_mode = RE_GEGLU;
+      dst_pk = lw.wi_pk; pk_mode = RE_GEGLU; family = OP_FAM_WI;
     } else if (t == "mlp.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo2_hi; dst_lo = lw.wo2_lo; expect(H, I);
-      dst_pk = lw.wo2_pk; pk_mode = 100;  // k-streamed
+      dst_pk = lw.wo2_pk; pk_mode = 100; family = OP_FAM_MLP_OUT;  // k-streamed
     } else {
       return fail(h, OP_ERR_INVALID, "op_load_weight: unknown tensor name '%s'", name_c);
     }
@@ -916,6 +935,16 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   }
   const unsigned blocks = (unsigned)((count + 255) / 256);
   hipLaunchKernelGGL(convert_to_f32_kernel, dim3(blocks), dim3(256), 0, 0, raw, dtype, count, f32);
+  // A requested policy without the hi x lo(weight) term stores zeros in the lo plane (so that any kernel set gives
+  // that policy's numerics); `any_lo` records whether the tensor had a non-zero lo element at all.
+  int zero_lo = 0;
+  int* any_lo = h->any_lo_dev;
+  if (family >= 0) {
+    const int req_mask[OP_FAM_COUNT] = {h->req.wqkv, h->req.qk, h->req.pv, h->req.attn_out, h->req.wi, h->req.mlp_out};
+    zero_lo = (req_mask[family] & OP_TERM_RIGHT_LO) ? 0 : 1;
+    any_lo = h->any_lo_dev + family;
+    h->resolved = false;
+  }
   switch (kind) {
     case F32_COPY:
       e = hipMemcpyAsync(dst_f32, f32, count * sizeof(float), hipMemcpyDeviceToDevice, 0);
@@ -925,11 +954,13 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       break;
     case PLANES:
       if (dst_hi)
-        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 0, dst_hi, dst_lo);
+        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 0, dst_hi, dst_lo,
+                           zero_lo, any_lo);
       break;
     case PLANES_GEGLU:
       if (dst_hi)
-        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, I, dst_hi, dst_lo);
+        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, I, dst_hi, dst_lo,
+                           zero_lo, any_lo);
       break;
   }
   if (h->panel_path && (dst_pk || dst_ks)) {
@@ -938,7 +969,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     auto pack = [&](int n_tiles, int mode, u16* dst) {
       const size_t total = (size_t)n_tiles * 256 * K;
       hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, f32, n_tiles, K, mode,
-                         H, I, dst);
+                         H, I, dst, zero_lo, any_lo);
     };
     if (pk_mode == RE_QKV) {
       pack(2 * H / 256, PE_QK, dst_pk);
@@ -953,11 +984,12 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   }
   if (dst_pk && h->row_path) {
     if (pk_mode == 100)
-      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_pk);
+      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_pk, zero_lo, any_lo);
     else
-      hipLaunchKernelGGL(pack_rowgemm_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_pk);
+      hipLaunchKernelGGL(pack_rowgemm_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_pk,
+                         zero_lo, any_lo);
     if (dst_ks)
-      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_ks);
+      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_ks, zero_lo, any_lo);
   }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(0);
@@ -968,9 +1000,45 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   return OP_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// Evaluated policy = requested policy minus the hi x lo(weight) terms whose lo planes are identically zero for this
+// checkpoint (bf16 weights: dropping the term changes no bit of the result), then the curated kernel set that has
+// exactly those terms -- or kernel set 0 with the unused lo operands cleared.
+int resolve_policy(op_handle* h) {
+  if (h->resolved) return OP_OK;
+  int any_lo[OP_FAM_COUNT] = {0};
+  OP_HIP(h, hipSetDevice(h->cfg.device_id));
+  OP_HIP(h, hipMemcpy(any_lo, h->any_lo_dev, sizeof(any_lo), hipMemcpyDeviceToHost));
+  Policy e = h->req;
+  if (!any_lo[OP_FAM_WQKV]) e.wqkv &= ~OP_TERM_RIGHT_LO;
+  if (!any_lo[OP_FAM_ATTN_OUT]) e.attn_out &= ~OP_TERM_RIGHT_LO;
+  if (!any_lo[OP_FAM_WI]) e.wi &= ~OP_TERM_RIGHT_LO;
+  if (!any_lo[OP_FAM_MLP_OUT]) e.mlp_out &= ~OP_TERM_RIGHT_LO;
+  h->eff = e;
+  h->pi = 0;
+  h->emulate = true;
+  if (!(h->cfg.flags & OP_FLAG_NO_POLICY_KERNELS)) {
+    for (int i = 0; i < opl::N_POLICIES; ++i)
+      if (opl::kPolicies[i] == e) {
+        h->pi = i;
+        h->emulate = false;
+        break;
+      }
+  } else if (opl::kPolicies[0] == e) {
+    h->emulate = false;
+  }
+  h->resolved = true;
+  return OP_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int op_weights_ready(op_handle* h) {
   if (!h) return fail(nullptr, OP_ERR_INVALID, "op_weights_ready: NULL handle");
-  if (h->missing.empty()) return OP_OK;
+  if (h->missing.empty()) return resolve_policy(h);
   std::string msg = "missing weights:";
   size_t shown = 0;
   for (const auto& m : h->missing) {
@@ -982,6 +1050,20 @@ int op_weights_ready(op_handle* h) {
   }
   msg += " (" + std::to_string(h->missing.size()) + " total)";
   return fail(h, OP_ERR_STATE, "%s", msg.c_str());
+}
+
+int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set) {
+  if (!h || !terms_out || !kernel_set) return fail(h, OP_ERR_INVALID, "op_effective_policy: NULL argument");
+  int rc = op_weights_ready(h);
+  if (rc != OP_OK) return rc;
+  terms_out[OP_FAM_WQKV] = (uint8_t)h->eff.wqkv;
+  terms_out[OP_FAM_QK] = (uint8_t)h->eff.qk;
+  terms_out[OP_FAM_PV] = (uint8_t)h->eff.pv;
+  terms_out[OP_FAM_ATTN_OUT] = (uint8_t)h->eff.attn_out;
+  terms_out[OP_FAM_WI] = (uint8_t)h->eff.wi;
+  terms_out[OP_FAM_MLP_OUT] = (uint8_t)h->eff.mlp_out;
+  *kernel_set = h->emulate ? -1 : h->pi;
+  return OP_OK;
 }
 
 size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int max_seqlen) {
@@ -1031,8 +1113,8 @@ int op_profile_read(op_handle* h, op_profile_entry* entries, int max_entries) {
 }
 
 int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_dev, const int32_t* cu_host_in, int n_seqs,
-                      int total_tokens, int max_seqlen, float* prune_out, float* rank_out, void* workspace,
-                      size_t workspace_bytes, void* hip_stream) {
+                      int total_tokens, int max_seqlen, float* prune_out, float* rank_out, float* keep_prob,
+                      void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (!h) return fail(nullptr, OP_ERR_INVALID, "op_forward_packed: NULL handle");
   if (n_seqs < 0 || total_tokens < 0 || max_seqlen < 0) return fail(h, OP_ERR_INVALID, "negative size");
   if (n_seqs == 0 || total_tokens == 0) {
@@ -1091,23 +1173,26 @@ int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_de
       ++s1;
     }
     if (rows > cap) return fail(h, OP_ERR_WORKSPACE, "internal: chunk of %d rows exceeds capacity %d", rows, cap);
-    // attention work items: 256-query blocks (8 waves) once a sequence is longer than 128 tokens, else 128
-    // -- unless that leaves CUs idle (small request): then 128-query blocks, twice as many work items
-    const char* aw = getenv("OPEN_PROVENCE_ATT_WAVES");
+    // attention work items of the full-attention layers: 256-query blocks (8 waves) once a sequence is longer than
+    // 128 tokens, else 128 -- unless that leaves CUs idle (small request): then 128-query blocks, twice as many work
+    // items.  Sliding-window layers always use 128-query blocks.
     auto count_items = [&](int waves) {
       int items = 0;
       for (int s = s0; s < s1; ++s) items += (cu[s + 1] - cu[s] + waves * 32 - 1) / (waves * 32);
       return items;
     };
-    int att_waves = aw ? (atoi(aw) == 4 ? 4 : 8) : (max_len > 128 ? 8 : 4);
-    int att_items = count_items(att_waves);
-    if (!aw && att_waves == 8 && (long)att_items * h->nh <= h->n_cus) {
-      att_waves = 4;
-      att_items = count_items(4);
+    const bool forced = (h->cfg.flags & (OP_FLAG_ATT_WAVES_4 | OP_FLAG_ATT_WAVES_8)) != 0;
+    AttnPlan plan;
+    plan.waves_g = forced ? ((h->cfg.flags & OP_FLAG_ATT_WAVES_4) ? 4 : 8) : (max_len > 128 ? 8 : 4);
+    plan.items_g = count_items(plan.waves_g);
+    if (!forced && plan.waves_g == 8 && (long)plan.items_g * h->nh <= h->n_cus) {
+      plan.waves_g = 4;
+      plan.items_g = count_items(4);
     }
+    plan.items_l = count_items(4);
     if (rows > 0) {
-      OP_TRY(forward_chunk(h, L, ws, ids_dev, cu_dev, s0, s1 - s0, rows, max_len, total_tokens, att_waves, att_items,
-                           prune_out, rank_out));
+      OP_TRY(forward_chunk(h, L, ws, ids_dev, cu_dev, s0, s1 - s0, rows, max_len, total_tokens, plan, prune_out, rank_out,
+                           keep_prob));
     } else {
       // only empty sequences in this chunk
       OP_HIP(h, hipMemsetAsync(rank_out + (size_t)s0 * h->nl, 0, (size_t)(s1 - s0) * h->nl * sizeof(float), stream));

@@ -1,0 +1,55 @@
+// op_internal.h -- host-side declarations shared by op_api.hip and the kernel-launch translation units
+// (op_launch_*.hip).  The library is built from several translation units so that the large kernel templates
+// compile in parallel; each launch unit instantiates one kernel family for every curated precision policy.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "opk_attn.hip.h"
+#include "opk_common.hip.h"
+#include "opk_panel.hip.h"
+#include "opk_rowgemm.hip.h"
+
+namespace opl {
+
+// Precision policy = one term mask per contraction family (opk::T_LEFT_LO / T_RIGHT_LO; see op_gemm_family in
+// include/open_provence_hip.h for the order).  "left" is always the activation-side operand:
+//   wqkv: LN(x) x Wqkv    qk: q x k    pv: p x v    attn_out: o x Wo    wi: LN(x) x Wi    mlp_out: h x Wo
+struct Policy {
+  int wqkv, qk, pv, attn_out, wi, mlp_out;
+  constexpr bool operator==(const Policy& o) const {
+    return wqkv == o.wqkv && qk == o.qk && pv == o.pv && attn_out == o.attn_out && wi == o.wi && mlp_out == o.mlp_out;
+  }
+};
+
+// Curated policies: every kernel family is instantiated with exactly the product terms (and output lo planes) each
+// of these needs.  Any other policy runs on the kernels of kPolicies[0] (all terms) with the unused lo operands
+// cleared -- bit-identical numerics, no speed-up.
+//   0  bf16x3                 every operand (hi, lo)
+//   1  bf16 weights           weight lo planes are zero (bf16 checkpoint, or OP_PRECISION_BF16X2): 2 passes in the four
+//                             weight GEMMs, 3 in attention (q, k, p, v are all activations)
+//   2  bf16                   single pass everywhere
+constexpr Policy kPolicies[] = {
+    {3, 3, 3, 3, 3, 3},
+    {1, 3, 3, 1, 1, 1},
+    {0, 0, 0, 0, 0, 0},
+};
+constexpr int N_POLICIES = (int)(sizeof(kPolicies) / sizeof(kPolicies[0]));
+
+// template arguments each kernel family derives from a policy
+constexpr int qkv_olo(const Policy& p) { return (p.qk & 1) | (p.qk & 2) | ((p.pv & 2) ? 4 : 0); }  // q_lo, k_lo, v_lo
+constexpr int h_olo(const Policy& p) { return p.mlp_out & 1; }
+constexpr bool o_lo(const Policy& p) { return (p.attn_out & 1) != 0; }
+
+// Launchers.  `pi` indexes kPolicies.  Each returns false when the shape has no instantiation.
+bool launch_row_qkv0(hipStream_t st, const opk::RowGemmParams& p, int ks, bool small, int pi, unsigned grid);
+bool launch_row_geglu_fused(hipStream_t st, const opk::RowGemmParams& p, int ks, bool small, int pi, unsigned grid);
+bool launch_row_qkv_fused(hipStream_t st, const opk::RowGemmParams& p, int ks, bool small, int pi, unsigned grid);
+bool launch_kstream(hipStream_t st, const opk::KStreamParams& p, int nf, int pi, unsigned grid);
+// waves x kt: (8, 2) and (4, 2) full attention / long and short sequences, (4, 1) sliding window.
+// zero_p_lo (pi == 0 only): the policy has no lo(p) x hi(v) term.
+bool launch_attn(hipStream_t st, const opk::AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid);
+bool launch_panel(hipStream_t st, const opk::PanelParams& p, int epi, int pi, dim3 grid);
+
+}  // namespace opl

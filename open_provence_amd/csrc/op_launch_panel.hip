@@ -1,0 +1,41 @@
+// op_launch_panel.hip -- instantiations of panel_gemm_kernel (hidden % 256 == 0: base / large / en-gte) for every
+// curated precision policy.
+#include "op_internal.h"
+
+namespace opl {
+using namespace opk;
+
+namespace {
+
+template <int PI>
+bool launch_pi(hipStream_t st, const PanelParams& p, int epi, dim3 grid) {
+  constexpr Policy P = kPolicies[PI];
+  const dim3 block(256);
+  if (epi == PE_QK)
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_QK, P.wqkv, (P.qk & 3)>), grid, block, 0, st, p);
+  else if (epi == PE_V)
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_V, P.wqkv, ((P.pv & 2) ? 1 : 0)>), grid, block, 0, st, p);
+  else if (epi == PE_GEGLU)
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_GEGLU, P.wi, h_olo(P)>), grid, block, 0, st, p);
+  else if (epi == 100)  // attention output projection
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_RESIDUAL, P.attn_out, 0>), grid, block, 0, st, p);
+  else if (epi == 101)  // MLP output projection
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_RESIDUAL, P.mlp_out, 0>), grid, block, 0, st, p);
+  else
+    return false;
+  return true;
+}
+
+}  // namespace
+
+bool launch_panel(hipStream_t st, const PanelParams& p, int epi, int pi, dim3 grid) {
+  static_assert(N_POLICIES == 3, "extend the switch below");
+  switch (pi) {
+    case 0: return launch_pi<0>(st, p, epi, grid);
+    case 1: return launch_pi<1>(st, p, epi, grid);
+    case 2: return launch_pi<2>(st, p, epi, grid);
+    default: return false;
+  }
+}
+
+}  // namespace opl

@@ -1,0 +1,80 @@
+// op_launch_row.hip -- instantiations of the row-stationary GEMM kernels (hidden 128 / 256) for every curated
+// precision policy: layer-0 q/k/v projection, the two fused per-layer kernels and the last layer's k-streamed
+// MLP output projection.  OPL_ROW_PART selects a subset so that the build can compile the parts in parallel.
+#include "op_internal.h"
+
+namespace opl {
+using namespace opk;
+
+namespace {
+
+template <int KS, int EPI, int PRO, int T1, int T2, int OLO>
+void launch_shape(hipStream_t st, const RowGemmParams& p, bool small, unsigned grid) {
+  // 4 waves x 32 rows = 128-row blocks, two per CU.  Small batches (at most one such block per CU) use 4 waves x
+  // 16 rows = 64-row blocks instead: twice the blocks, so a latency-bound request spreads over twice the CUs.
+  if (small)
+    hipLaunchKernelGGL((rowgemm_kernel<KS, EPI, PRO, T1, T2, OLO, 4, 1>), dim3(grid), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((rowgemm_kernel<KS, EPI, PRO, T1, T2, OLO, 4, 2>), dim3(grid), dim3(256), 0, st, p);
+}
+
+template <int EPI, int PRO, int T1, int T2, int OLO>
+bool launch_ks(hipStream_t st, const RowGemmParams& p, int ks, bool small, unsigned grid) {
+  if (ks == 8) launch_shape<8, EPI, PRO, T1, T2, OLO>(st, p, small, grid);
+  else if (ks == 4) launch_shape<4, EPI, PRO, T1, T2, OLO>(st, p, small, grid);
+  else return false;
+  return true;
+}
+
+}  // namespace
+
+#define OPL_SWITCH(CALL)                              \
+  static_assert(N_POLICIES == 3, "extend the switch"); \
+  switch (pi) {                                       \
+    case 0: return CALL(0);                           \
+    case 1: return CALL(1);                           \
+    case 2: return CALL(2);                           \
+    default: return false;                            \
+  }
+
+#if OPL_ROW_PART == 0
+bool launch_row_geglu_fused(hipStream_t st, const RowGemmParams& p, int ks, bool small, int pi, unsigned grid) {
+#define OPL_CALL(PI) (launch_ks<RE_GEGLU, RP_KSTREAM, kPolicies[PI].attn_out, kPolicies[PI].wi, h_olo(kPolicies[PI])>(st, p, ks, small, grid))
+  OPL_SWITCH(OPL_CALL)
+#undef OPL_CALL
+}
+#endif
+
+#if OPL_ROW_PART == 1
+bool launch_row_qkv_fused(hipStream_t st, const RowGemmParams& p, int ks, bool small, int pi, unsigned grid) {
+#define OPL_CALL(PI) (launch_ks<RE_QKV, RP_KSTREAM, kPolicies[PI].mlp_out, kPolicies[PI].wqkv, qkv_olo(kPolicies[PI])>(st, p, ks, small, grid))
+  OPL_SWITCH(OPL_CALL)
+#undef OPL_CALL
+}
+#endif
+
+#if OPL_ROW_PART == 2
+bool launch_row_qkv0(hipStream_t st, const RowGemmParams& p, int ks, bool small, int pi, unsigned grid) {
+#define OPL_CALL(PI) (launch_ks<RE_QKV, RP_SPLIT, 0, kPolicies[PI].wqkv, qkv_olo(kPolicies[PI])>(st, p, ks, small, grid))
+  OPL_SWITCH(OPL_CALL)
+#undef OPL_CALL
+}
+
+namespace {
+template <int T>
+bool launch_kstream_t(hipStream_t st, const KStreamParams& p, int nf, unsigned grid) {
+  if (nf == 16) hipLaunchKernelGGL((kstream_gemm_kernel<16, T, 4>), dim3(grid), dim3(256), 0, st, p);
+  else if (nf == 8) hipLaunchKernelGGL((kstream_gemm_kernel<8, T, 4>), dim3(grid), dim3(256), 0, st, p);
+  else return false;
+  return true;
+}
+}  // namespace
+
+bool launch_kstream(hipStream_t st, const KStreamParams& p, int nf, int pi, unsigned grid) {
+#define OPL_CALL(PI) (launch_kstream_t<kPolicies[PI].mlp_out>(st, p, nf, grid))
+  OPL_SWITCH(OPL_CALL)
+#undef OPL_CALL
+}
+#endif
+
+}  // namespace opl

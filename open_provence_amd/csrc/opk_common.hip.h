@@ -1,0 +1,139 @@
+// opk_common.hip.h -- CDNA4 (gfx950) device code of the OpenProvence forward path: types, constants and helpers
+// shared by every kernel family (opk_small / opk_tiled / opk_rowgemm / opk_panel / opk_attn .hip.h).
+//
+// Packed ("unpadded") row layout: the tokens of a chunk of sequences are laid end to end, each
+// sequence starting at a multiple of ROW_ALIGN rows; `row_pos[r] < 0` marks an alignment row.  All
+// activations are [rows, features] row-major.  The fp32 residual stream `x` is the only fp32
+// activation; every MFMA operand is stored as bf16 planes: `*_hi` = RNE(bf16(v)) and (BF16X3 mode)
+// `*_lo` = RNE(bf16(v - hi)), so that  a*b ~= a_hi*b_hi + a_lo*b_hi + a_hi*b_lo  on the bf16 MFMA pipe
+// with fp32 accumulation (~2^-16 relative) -- what the 1e-3 parity bar against the fp32 CPU
+// reference needs (single-pass bf16 is ~1e-2, SURVEY.md headline fact 5).
+//
+// Arithmetic restated from (third-party) HF ModernBERT, transformers 5.15.0:
+//   embeddings+LN  modeling_modernbert.py:52-71     GeGLU MLP  :74-91      RoPE :94-219
+//   attention      :166-185, :222-301               layer      :304-333    heads :481-490, :569-622
+// and the reference's OpenProvenceHead (open_provence/modeling_open_provence_standalone.py:434-448).
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+namespace opk {
+
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t u16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte staging register (stays in VGPRs)
+
+constexpr int ROW_ALIGN = 32;   // sequence starts are multiples of this many rows (= one wave's row group)
+constexpr int GEMM_BM = 128;    // rows (tokens) per GEMM tile
+constexpr int GEMM_BN = 128;    // output features per GEMM tile
+constexpr int GEMM_BK = 32;     // one 16x16x32 MFMA step
+constexpr int GEMM_LDS = 48;    // LDS row stride in bf16 elements (32 + 16 pad: conflict-free b128 reads)
+constexpr int ATT_BQ = 64;      // queries per attention block (4 waves x 16)
+constexpr int ATT_BK = 64;      // keys per tile
+constexpr int ATT_LDS = 80;     // LDS row stride in bf16 elements (64 + 16 pad)
+constexpr int HEAD_DIM = 64;
+constexpr int ROPE_HALF = 32;
+
+// ----------------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ u16 f2bf(float x) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs only)
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// two fp32 -> one dword of two bf16 (round to nearest even): a single v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// (hi, lo) bf16 split of a pair: hi = RNE(v), lo = RNE(v - hi); 5 VALU instructions per pair
+template <bool SPLIT>
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = SPLIT ? pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)) : 0u;
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
+  split2<SPLIT>(v[0], v[1], hi.x, lo.x);
+  split2<SPLIT>(v[2], v[3], hi.y, lo.y);
+}
+
+union FragU {
+  uint4 u;
+  bf16x8 v;
+};
+__device__ __forceinline__ bf16x8 as_frag(uint4 u) {
+  FragU f;
+  f.u = u;
+  return f.v;
+}
+// Load the fragment as an ext-vector type: an LDS load typed as HIP's uint4 class makes hipcc (ROCm 7.2) treat it
+// as possibly aliasing an in-flight global_load_lds DMA and drain the DMA (s_waitcnt vmcnt(0)) in front of it.
+__device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// D = X * Y + C on one wave.  X fragment: row (lane & 15), k-group (lane >> 4) holds 8 consecutive k.
+// Y fragment: column (lane & 15), same k-group.  D: column (lane & 15), rows 4*(lane >> 4) + r.
+__device__ __forceinline__ f32x4 mfma16(bf16x8 x, bf16x8 y, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// GELU (exact-erf form) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |x| he(|x|),  he(a) = erfc(a / sqrt 2) / 2,
+// with he(a) = 2^q(a), q a degree-5 polynomial (weighted minimax fit of log2 he on [0, 10], weight a he(a); leading
+// coefficient negative, so q -> -inf and he -> 0 for large |x|).  Eight instructions: five FMAs, one v_exp_f32, one
+// FMA, one med3 -- the VALU work next to the MFMAs is what these epilogues cost, instruction for instruction.  No
+// cancellation on either side of zero.  Max |gelu - exact| = 6.4e-7 over [-12, 12] evaluated in fp32 (offline, against
+// fp64 erf); the library erff costs ~3x the instructions.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x);
+  float q = fmaf(-4.7330930829e-04f, ax, 7.0845573209e-03f);
+  q = fmaf(q, ax, -5.1827382296e-02f);
+  q = fmaf(q, ax, -4.5999243855e-01f);
+  q = fmaf(q, ax, -1.1507878304e+00f);
+  q = fmaf(q, ax, -1.0000376701e+00f);
+  const float he = __builtin_amdgcn_exp2f(q);
+  // max(x, 0) as med3(x, 0, +inf): one instruction (fmaxf adds a NaN-quieting v_max x,x in front)
+  return fmaf(-he, ax, __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()));
+}
+
+enum RowEpilogue { RE_QKV = 0, RE_RESIDUAL = 1, RE_GEGLU = 2 };
+enum RowPrologue { RP_LN = 0, RP_SPLIT = 1, RP_PLANES = 2, RP_KSTREAM = 3 };
+constexpr int ROW_BM = 128;
+constexpr int ROW_CHUNK = 32;  // output features per streamed chunk
+enum PanelEpi { PE_RESIDUAL = 0, PE_QK = 1, PE_V = 2, PE_GEGLU = 3 };
+
+template <bool SPLIT>
+__device__ __forceinline__ void pack8(const float v[8], bf16x8& hi, bf16x8& lo) {
+  uint2 h0, l0, h1, l1;
+  split4<SPLIT>(v, h0, l0);
+  split4<SPLIT>(v + 4, h1, l1);
+  hi = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
+  lo = as_frag(make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+
+// Term mask of a contraction  left x right  (left = activation / q / p, right = weight / k / v): the hi x hi product is
+// always computed; bit 0 adds lo(left) x hi(right), bit 1 adds hi(left) x lo(right).  3 = "bf16x3", 0 = single pass.
+constexpr int T_LEFT_LO = 1;
+constexpr int T_RIGHT_LO = 2;
+__host__ __device__ constexpr int term_count(int t) { return 1 + (t & 1) + ((t >> 1) & 1); }
+
+
+}  // namespace opk

@@ -1,0 +1,776 @@
+// opk_rowgemm.hip.h -- row-stationary GEMMs (hidden <= 256) and the k-streamed output projection
+#pragma once
+
+#include <type_traits>
+
+#include "opk_common.hip.h"
+
+namespace opk {
+
+// ----------------------------------------------------------------------------------------------
+// Row-stationary GEMM for K = hidden <= 256 (the three projections whose input is the hidden state):
+//   C[m, n] = sum_k A[m, k] W[n, k],  A = 128 rows per block kept IN REGISTERS as MFMA fragments
+//   (each wave owns 32 rows = 2 fragments x K/32 k-steps x hi/lo), W streamed through LDS in chunks of
+//   32 output features, double-buffered, one barrier per chunk (96 MFMAs per wave between barriers).
+// Why: the activations are the big operand (read exactly once, never staged through LDS); the weights
+// are small, L2-resident and STATIC, so they are pre-packed at load time in exactly the order the MFMA
+// X/Y fragments want them ([chunk][k-step][plane][frag][k-group][row][8]) -- every LDS fragment read
+// is a lane-linear, conflict-free 1 KiB ds_read_b128, every global->LDS copy a linear memcpy.
+// Prologues fuse what used to be separate kernels: LayerNorm (+ hi/lo split) of the fp32 residual
+// stream is computed in registers directly in fragment layout (a row lives in 4 lanes).
+// ----------------------------------------------------------------------------------------------
+
+struct RowGemmParams {
+  const float* x_in;  // RP_LN / RP_SPLIT: fp32 [r_pad][K]
+  const float* ln_w;  // RP_LN
+  float eps;
+  const u16* a_hi;  // RP_PLANES: planes [r_pad][K]
+  const u16* a_lo;
+  const u16* wp;  // packed weights, n_chunks x (K/32) x 2 planes x 2 frags x 512 elements
+  int n_chunks;
+  int n_swapped;  // RE_QKV: chunks [0, n_swapped) are q/k (RoPE), the rest v (transposed store)
+  float* x;       // RE_RESIDUAL: fp32 [r_pad][ld_out], updated in place
+  u16* o0_hi;     // RE_QKV: q   RE_GEGLU: h
+  u16* o0_lo;
+  u16* o1_hi;  // RE_QKV: k
+  u16* o1_lo;
+  u16* o2_hi;  // RE_QKV: v^T [H][r_pad]
+  u16* o2_lo;
+  int ld_out;  // RE_RESIDUAL: H   RE_GEGLU: I   RE_QKV: H
+  int hidden;
+  int r_pad;
+  const int32_t* row_pos;
+  const float* rope_cos;
+  const float* rope_sin;
+  int max_pos;
+  // RP_KSTREAM (fused block): x_new = x + A1 W1^T first, A1 fragment-packed [r_pad/16][k1_steps][2][512], W1 packed
+  // by pack_kstream_kernel with permuted output features; then LayerNorm(x_new) feeds the chunk loop.
+  const u16* a1_fp;
+  const u16* w1p;
+  int k1_steps;
+  float* x_io;
+  int zero_a_lo;  // clear the lo fragments of the in-register (LayerNorm / split) operand: see rowgemm_kernel
+};
+
+// source row of packed row `pr` (0..31) of chunk `c`
+__device__ __forceinline__ int rowgemm_source_row(int mode, int c, int pr, int H, int I) {
+  const int nf = pr >> 4, i = pr & 15;
+  if (mode == RE_QKV) {
+    const int per_block = H / ROW_CHUNK;  // chunks in each of q, k, v
+    const int blk = c / per_block, cc = c % per_block;
+    const int head = cc >> 1, j = cc & 1;
+    // q / k: the chunk pair (j = 0, 1) of a head leaves lane slot i = 4g + r with d = 8g + 4j + r (fragment 0)
+    // and its RoPE partner d + 32 (fragment 1): after the pair a lane owns 8 consecutive d of both k-steps.
+    if (blk < 2) return blk * H + head * HEAD_DIM + 32 * nf + 8 * (i >> 2) + 4 * j + (i & 3);
+    // v: fragment nf of chunk j becomes piece n = 2j + nf of the transposed layout, whose row i is
+    // d = 32j + 8(i>>2) + 4nf + (i&3) -- the order that makes the attention output lane-contiguous.
+    return 2 * H + head * HEAD_DIM + 32 * j + 8 * (i >> 2) + 4 * nf + (i & 3);
+  }
+  if (mode == RE_GEGLU) {  // chunk pair (2t, 2t+1): lane slot i = 4g + r -> h-column 32t + 8g + 4u + r
+    const int col = 32 * (c >> 1) + 8 * (i >> 2) + 4 * (c & 1) + (i & 3);
+    return nf == 0 ? col : I + col;  // input column | matching gate column
+  }
+  return c * ROW_CHUNK + pr;
+}
+
+#ifdef OPK_PACK_KERNELS  // weight re-packing runs in op_api.hip only
+// dst[chunk][ks][plane][nf][g][i][e] <- src[source_row(chunk, nf*16+i)][ks*32 + g*8 + e]
+__global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, int K, int mode, int H, int I,
+                                    u16* __restrict__ dst, int zero_lo, int* __restrict__ any_lo) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_rows * K;
+  if (idx >= total) return;
+  const int KS = K / 32;
+  size_t t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int i = (int)(t & 15); t >>= 4;
+  const int g = (int)(t & 3); t >>= 2;
+  const int nf = (int)(t & 1); t >>= 1;
+  const int ks = (int)(t % KS);
+  const int c = (int)(t / KS);
+  const int srow = rowgemm_source_row(mode, c, nf * 16 + i, H, I);
+  const float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
+  const u16 h = f2bf(v);
+  const size_t base = (((size_t)c * KS + ks) * 2) * 1024 + (size_t)nf * 512 + (size_t)g * 128 + i * 8 + e;
+  const u16 l = f2bf(v - bf2f(h));
+  if ((l & 0x7fffu) != 0) *any_lo = 1;
+  dst[base] = h;
+  dst[base + 1024] = zero_lo ? (u16)0 : l;
+}
+#endif
+
+// One weight chunk (32 output features x K) against this wave's 32 rows: 2 x 2 accumulators, K/32 k-steps of
+// 4 MFMAs per product term.  (hipcc hoists the fragment reads one k-step ahead of their MFMAs by itself; an explicit
+// register double buffer only cost 16 VGPRs.)
+template <int KS, int MF, int T, bool SWAPPED>
+__device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const bf16x8 (&a_hi)[MF][KS],
+                                                   const bf16x8 (&a_lo)[MF][KS], f32x4 (&acc)[2][MF]) {
+  constexpr bool W_LO = (T & T_RIGHT_LO) != 0, A_LO = (T & T_LEFT_LO) != 0;
+  constexpr int PLANES = W_LO ? 2 : 1;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 wh[2], wl[2];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+      wh[nf] = lds_frag(stage_lane + (ks * PLANES) * 1024 + nf * 512);
+      wl[nf] = W_LO ? lds_frag(stage_lane + (ks * PLANES + 1) * 1024 + nf * 512) : wh[nf];
+    }
+    // The product terms are issued term-major over the four accumulators: an accumulator is touched every
+    // fourth MFMA, so no MFMA waits for the result of the previous one (back-to-back MFMAs on one accumulator
+    // stall on the read-after-write).  (A unit-major software pipeline that prefetches the next (k-step, 16-feature)
+    // fragment pair during six MFMAs measured the same: the fragment-read latency is already covered by the
+    // partner wave on the SIMD.)
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      if ((term == 0 && !W_LO) || (term == 1 && !A_LO)) continue;
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const bf16x8 w = term == 0 ? wl[nf] : wh[nf];
+          const bf16x8 a = term == 1 ? a_lo[mf][ks] : a_hi[mf][ks];
+          acc[nf][mf] = SWAPPED ? mfma16(w, a, acc[nf][mf]) : mfma16(a, w, acc[nf][mf]);
+        }
+      }
+    }
+  }
+}
+
+// T2 = term mask of the chunk loop's GEMM (left = this block's rows, right = the streamed weight), T1 = term mask of
+// the fused phase-1 GEMM (RP_KSTREAM only), OLO = which outputs also get a lo plane (bit 0: o0 = q / h, bit 1: o1 = k,
+// bit 2: o2 = v^T).
+template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2>
+__global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void rowgemm_kernel(RowGemmParams p) {
+  // A block is WAVES x MF x 16 rows; the library launches 4 waves x 2 fragments = 128 rows, two blocks per CU, and
+  // 4 waves x 1 fragment = 64 rows for small batches (fewer than one 128-row block per CU-slot: twice the blocks, so
+  // twice the CUs work on a latency-bound request).
+  // Measured alternatives on MI355X (xsmall, 256 x 512): 8 waves x 2 (256 rows, one block per CU, half the DMA
+  // instructions and L2 -> LDS traffic per row) is within +-2 % on both fused kernels; 8 waves x 1 (16 rows per wave,
+  // <= 128 VGPRs, 4 waves per SIMD, twice the fragment reads per MFMA) is equal on q/k/v and 10 % slower on GeGLU.
+  static_assert(MF == 1 || MF == 2, "one or two 16-row fragments per wave");
+  constexpr bool W_LO = (T2 & T_RIGHT_LO) != 0, A_LO = (T2 & T_LEFT_LO) != 0;
+  constexpr bool W_LO1 = PRO == RP_KSTREAM && (T1 & T_RIGHT_LO) != 0, A_LO1 = PRO == RP_KSTREAM && (T1 & T_LEFT_LO) != 0;
+  constexpr int PLANES = W_LO ? 2 : 1;
+  constexpr int PLANES1 = W_LO1 ? 2 : 1;
+  constexpr int K = KS * 32;
+  constexpr int CHUNK_SRC = KS * 2 * 1024;        // elements per packed chunk in global memory
+  constexpr int STAGE = KS * PLANES * 1024;       // elements per LDS stage
+  constexpr int STAGE_ALLOC = KS * (PLANES > PLANES1 ? PLANES : PLANES1) * 1024;  // phase 1 slabs: 2 KS fragments per plane
+  static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
+  __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE_ALLOC];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+  const int m0 = blockIdx.x * (WAVES * 16 * MF) + wave * (16 * MF);
+
+  // ---- weight streaming: global -> LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction) --
+  // Stage layout = [ks][plane][frag][512] = a sequence of 1 KiB pieces; wave w copies pieces w, w+4, ...
+  // The copy is linear (the packing kernel already wrote fragment order), so the lane-linear LDS
+  // destination the DMA imposes is exactly the layout the fragment reads want.  No staging VGPRs, and
+  // the request is in flight while the MFMAs of the current chunk run.
+  constexpr int WAVE_PIECES = STAGE / (WAVES * 512);
+  auto stage_chunk = [&](int chunk, int stage) {
+    const u16* src = p.wp + (size_t)chunk * CHUNK_SRC;
+#pragma unroll
+    for (int u = 0; u < WAVE_PIECES; ++u) {
+      const int piece = wave + WAVES * u;              // wave-uniform
+      const int elem = piece * 512;                    // position inside the LDS stage
+      const int ks = elem / (PLANES * 1024);
+      const int rem = elem % (PLANES * 1024);
+      const int src_elem = ks * 2048 + rem;            // source keeps both planes per k-step
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + src_elem + lane * 8),
+          (__attribute__((address_space(3))) void*)(&sW[stage][elem]), 16, 0, 0);
+    }
+  };
+  bf16x8 a_hi[MF][KS], a_lo[MF][KS];
+  if (PRO == RP_KSTREAM) {
+    // ---- fused phase 1: x_new[32 rows, H] = x + A1[32 rows, K1] W1[H, K1]^T, K1 streamed ----------------
+    // Same structure as kstream_gemm_kernel (one [H x 32] weight slab per k-step by DMA, A1 fragments straight
+    // from the fragment-packed activation, prefetched one k-step ahead), all H outputs of the 32 rows in
+    // accumulators.  W1's output features were permuted at load time so that accumulator fragments (2s, 2s+1)
+    // are exactly lane slot g of k-step s of THIS kernel's chunk loop: residual add, LayerNorm and the hi/lo
+    // split happen in registers and the hidden state makes one fp32 round trip (read + write) per block.
+    constexpr int NF1 = 2 * KS;
+    constexpr int SLAB_SRC = NF1 * 2 * 512;
+    constexpr int SLAB_PIECES = (NF1 * PLANES1) / WAVES;
+    static_assert((NF1 * PLANES1) % WAVES == 0, "slab must split evenly over the waves");
+    auto stage_slab = [&](int ks1, int stage) {
+      const u16* src = p.w1p + (size_t)ks1 * SLAB_SRC;
+#pragma unroll
+      for (int u = 0; u < SLAB_PIECES; ++u) {
+        const int piece = wave + WAVES * u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+      }
+    };
+    const int nks1 = p.k1_steps;
+    const u16* a_base0 = p.a1_fp + ((size_t)(m0 >> 4) * nks1 * 2) * 512 + lane * 8;
+    const size_t a_block = (size_t)nks1 * 2 * 512;  // elements per 16-row block of A1
+    bf16x8 an_hi[MF], an_lo[MF];
+    auto load_a1 = [&](int ks1) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        an_hi[mf] = *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks1 * 1024);
+        an_lo[mf] = A_LO1 ? *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks1 * 1024 + 512) : an_hi[mf];
+      }
+    };
+    f32x4 acc1[NF1][MF];
+#pragma unroll
+    for (int nf = 0; nf < NF1; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_slab(0, 0);
+    load_a1(0);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      asm volatile("" : "+v"(an_hi[mf]));
+      asm volatile("" : "+v"(an_lo[mf]));
+    }
+    __syncthreads();
+    auto slab_step = [&](int ks1, auto cur_tag) {
+      constexpr int cur = decltype(cur_tag)::value;
+      const int kn = ks1 + 1 < nks1 ? ks1 + 1 : ks1;
+      stage_slab(kn, cur ^ 1);
+      bf16x8 c_hi[MF], c_lo[MF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        c_hi[mf] = an_hi[mf];
+        c_lo[mf] = an_lo[mf];
+      }
+      load_a1(kn);
+      __builtin_amdgcn_sched_barrier(0);
+      // two weight fragments at a time, the three product terms issued term-major over their 2 x MF accumulators:
+      // no MFMA reads the accumulator the previous one wrote (a dependent pair stalls the pipe)
+#pragma unroll
+      for (int nf = 0; nf < NF1; nf += 2) {
+        bf16x8 wh[2], wl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
+          wl[j] = W_LO1 ? lds_frag(&sW[cur][(NF1 + nf + j) * 512 + lane * 8]) : wh[j];
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+          if ((term == 0 && !W_LO1) || (term == 1 && !A_LO1)) continue;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+              acc1[nf + j][mf] = mfma16(term == 0 ? wl[j] : wh[j], term == 1 ? c_lo[mf] : c_hi[mf], acc1[nf + j][mf]);
+        }
+      }
+      __syncthreads();
+    };
+    for (int k0 = 0; k0 < nks1; k0 += 2) {  // even number of k-steps (checked on the host)
+      slab_step(k0, std::integral_constant<int, 0>{});
+      slab_step(k0 + 1, std::integral_constant<int, 1>{});
+    }
+    stage_chunk(0, 0);  // first weight chunk of phase 2 flies while the LayerNorm below runs
+
+    // ---- transition: residual add, store the new hidden state, LayerNorm, split -> fragments --------------
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      float* xrow = p.x_io + (size_t)(m0 + mf * 16 + l15) * K + g * 8;
+      float sum = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < NF1; ++nf) {
+        float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
+        float4 r4 = *px;
+        r4.x += acc1[nf][mf][0];
+        r4.y += acc1[nf][mf][1];
+        r4.z += acc1[nf][mf][2];
+        r4.w += acc1[nf][mf][3];
+        *px = r4;
+        acc1[nf][mf] = f32x4{r4.x, r4.y, r4.z, r4.w};
+        sum += (r4.x + r4.y) + (r4.z + r4.w);
+        // keep the scheduler from hoisting all 16 row loads (64 more registers) on top of the accumulators
+        if ((nf & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum / (float)K;
+      float q = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < NF1; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc1[nf][mf][r] - mean;
+          q += d * d;
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = 1.0f / sqrtf(q / (float)K + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8 + 4);
+        const float v[8] = {(acc1[2 * ks][mf][0] - mean) * rstd * w0.x,     (acc1[2 * ks][mf][1] - mean) * rstd * w0.y,
+                            (acc1[2 * ks][mf][2] - mean) * rstd * w0.z,     (acc1[2 * ks][mf][3] - mean) * rstd * w0.w,
+                            (acc1[2 * ks + 1][mf][0] - mean) * rstd * w1.x, (acc1[2 * ks + 1][mf][1] - mean) * rstd * w1.y,
+                            (acc1[2 * ks + 1][mf][2] - mean) * rstd * w1.z, (acc1[2 * ks + 1][mf][3] - mean) * rstd * w1.w};
+        pack8<A_LO>(v, a_hi[mf][ks], a_lo[mf][ks]);
+      }
+    }
+  } else {
+    stage_chunk(0, 0);
+  }
+
+  // ---- prologue: this wave's 32 rows as fragments ---------------------------------------------
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    if (PRO == RP_KSTREAM) break;
+    const size_t row = (size_t)(m0 + mf * 16 + l15);
+    if (PRO == RP_PLANES) {  // fragment-packed input: piece (row block, k-step, plane), 16 bytes per lane
+      const u16* base = p.a_hi + (((size_t)((m0 >> 4) + mf) * KS) * 2) * 512 + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a_hi[mf][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)ks * 1024);
+        if (A_LO) a_lo[mf][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)ks * 1024 + 512);
+      }
+      // Pin the fragment loads in front of the chunk loop: an empty asm that "rewrites" each register makes
+      // the compiler wait for the load HERE; otherwise it sinks the loads next to their first MFMA inside the
+      // loop and then drains the weight DMA (vmcnt(0)) at the top of every iteration.
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("" : "+v"(a_hi[mf][ks]));
+        if (A_LO) asm volatile("" : "+v"(a_lo[mf][ks]));
+      }
+    } else {
+      float v[KS][8];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 f0 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8);
+        const float4 f1 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8 + 4);
+        v[ks][0] = f0.x; v[ks][1] = f0.y; v[ks][2] = f0.z; v[ks][3] = f0.w;
+        v[ks][4] = f1.x; v[ks][5] = f1.y; v[ks][6] = f1.z; v[ks][7] = f1.w;
+      }
+      if (PRO == RP_LN) {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s += v[ks][e];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[ks][e] - mean;
+            q += d * d;
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)K + p.eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8 + 4);
+          const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[ks][e] = (v[ks][e] - mean) * rstd * ww[e];
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) pack8<A_LO>(v[ks], a_hi[mf][ks], a_lo[mf][ks]);
+    }
+  }
+  // Numerics of a narrower policy on this (wider) instantiation: the lo fragments of the in-register operand are
+  // cleared once, so their product term adds exact zeros (bit-identical to the kernel that omits the term).
+  if (A_LO && PRO != RP_PLANES && p.zero_a_lo) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a_lo[mf][ks] = as_frag(make_uint4(0u, 0u, 0u, 0u));
+  }
+
+  // RE_QKV: RoPE rows of this lane's tokens: cos/sin [pos][8g + 4j .. +3] for the half-head j of the chunk whose
+  // (deferred) epilogue runs in this iteration are fetched at the top of the iteration, before the DMA is issued.
+  const float* rope_c_row[MF];
+  const float* rope_s_row[MF];
+  f32x4 rope_c[MF], rope_s[MF];
+  if (EPI == RE_QKV) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int pos = p.row_pos[m0 + mf * 16 + l15];
+      pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+      rope_c_row[mf] = p.rope_cos + (size_t)pos * ROPE_HALF + g * 8;
+      rope_s_row[mf] = p.rope_sin + (size_t)pos * ROPE_HALF + g * 8;
+      rope_c[mf] = rope_s[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
+
+  // ---- stream the weight chunks ---------------------------------------------------------------
+  uint2 hold_hi[MF], hold_lo[MF];  // RE_GEGLU: first half of a chunk pair
+  uint2 qk_hold[MF][4];            // RE_QKV: first half-head of a q/k chunk pair: [mf][d<32 hi, lo, d>=32 hi, lo]
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qk_hold[mf][t] = make_uint2(0u, 0u);
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
+  // Epilogue of chunk `cc` (compile-time parity PP = cc & 1) from accumulators `av`.  It runs one iteration late,
+  // inside the iteration that computes chunk cc+1, its VALU instructions scheduled between that chunk's MFMAs
+  // (sched_group_barrier recipe below): vector instructions of all kinds share the SIMD's issue port, so the
+  // epilogue costs its instruction count either way, but interleaved it no longer adds a serial VALU-only phase.
+  constexpr bool O0_LO = (OLO & 1) != 0, O1_LO = (OLO & 2) != 0, O2_LO = (OLO & 4) != 0;
+  constexpr bool QK_LO = O0_LO || O1_LO;
+  auto epilogue = [&](int cc, auto parity_tag, auto sw_tag, const f32x4 (&av)[2][MF]) {
+    constexpr int PP = decltype(parity_tag)::value;
+    constexpr bool sw = decltype(sw_tag)::value;  // q/k chunk ("swapped" MFMA orientation) or v chunk
+    if (EPI == RE_RESIDUAL) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const size_t row = (size_t)(m0 + mf * 16 + l15);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          float4* px = reinterpret_cast<float4*>(p.x + row * p.ld_out + cc * ROW_CHUNK + nf * 16 + g * 4);
+          float4 r4 = *px;
+          r4.x += av[nf][mf][0];
+          r4.y += av[nf][mf][1];
+          r4.z += av[nf][mf][2];
+          r4.w += av[nf][mf][3];
+          *px = r4;
+        }
+      }
+    } else if (EPI == RE_GEGLU) {
+      // Output = "fragment-packed" h (see hfp_offset): chunk 2t gives this lane h-columns 32t + 8g + (0..3),
+      // chunk 2t+1 columns 32t + 8g + (4..7) (the Wi rows were permuted that way at load time), so after the
+      // pair the lane owns the 8 consecutive k-values of ITS OWN fragment slot for k-step t of the next GEMM
+      // and the wave stores one contiguous 1 KiB piece per (16-row block, plane).
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(av[0][mf][r]) * av[1][mf][r];
+        uint2 h2, l2;
+        split4<O0_LO>(v, h2, l2);
+        if (PP == 0) {
+          hold_hi[mf] = h2;
+          hold_lo[mf] = l2;
+        } else {
+          const size_t rb = (size_t)((m0 >> 4) + mf);
+          const size_t off = ((rb * (size_t)(p.ld_out >> 5) + (size_t)(cc >> 1)) * 2) * 512 + lane * 8;
+          *reinterpret_cast<uint4*>(p.o0_hi + off) = make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y);
+          if (O0_LO) *reinterpret_cast<uint4*>(p.o0_hi + off + 512) = make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y);
+        }
+      }
+    } else {  // RE_QKV: fragment-packed q, k (pieces [row/16][H/32][plane]) and v^T (pieces [head][row/32][plane][4])
+      const int per_block = p.hidden / ROW_CHUNK;
+      if (sw) {
+        const bool is_q = cc < per_block;
+        const int cq = is_q ? cc : cc - per_block;
+        u16* out = is_q ? p.o0_hi : p.o1_hi;
+        // head_dim^-0.5 * log2(e): the fragment-packed attention kernel exponentiates with exp2
+        const float qscale = is_q ? 0.125f * 1.44269504088896340736f : 1.0f;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          // half-head index j = cq & 1 equals the chunk parity PP (even number of chunks per block)
+          const f32x4 c4 = rope_c[mf];
+          const f32x4 s4 = rope_s[mf];
+          float lo_half[4], hi_half[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x1 = av[0][mf][r], x2 = av[1][mf][r];
+            lo_half[r] = (x1 * c4[r] - x2 * s4[r]) * qscale;
+            hi_half[r] = (x2 * c4[r] + x1 * s4[r]) * qscale;
+          }
+          uint2 h0, l0, h1, l1;
+          split4<QK_LO>(lo_half, h0, l0);
+          split4<QK_LO>(hi_half, h1, l1);
+          if (PP == 0) {
+            qk_hold[mf][0] = h0; qk_hold[mf][1] = l0; qk_hold[mf][2] = h1; qk_hold[mf][3] = l1;
+          } else {
+            const size_t rb = (size_t)((m0 >> 4) + mf);
+            const size_t kb = (size_t)(cq >> 1) * 2;  // k-step of d in [0, 32); d + 32 is the next one
+            const size_t off = ((rb * (size_t)(p.hidden >> 5) + kb) * 2) * 512 + lane * 8;
+            *reinterpret_cast<uint4*>(out + off) = make_uint4(qk_hold[mf][0].x, qk_hold[mf][0].y, h0.x, h0.y);
+            *reinterpret_cast<uint4*>(out + off + 1024) = make_uint4(qk_hold[mf][2].x, qk_hold[mf][2].y, h1.x, h1.y);
+            if (QK_LO && (O0_LO == O1_LO || (is_q ? O0_LO : O1_LO))) {  // q and k may differ: wave-uniform select
+              *reinterpret_cast<uint4*>(out + off + 512) = make_uint4(qk_hold[mf][1].x, qk_hold[mf][1].y, l0.x, l0.y);
+              *reinterpret_cast<uint4*>(out + off + 1536) = make_uint4(qk_hold[mf][3].x, qk_hold[mf][3].y, l1.x, l1.y);
+            }
+          }
+        }
+      } else {
+        // C rows = tokens 4g + r of block mf, column = feature slot l15: the two 16-row blocks of a 32-row
+        // group are the two halves of the 8 key slots of one v^T fragment lane.  With 32 rows per wave the lane
+        // stores all 16 bytes, with 16 rows per wave the 8 bytes of its half.
+        const int cv = cc - p.n_swapped;
+        const size_t head = (size_t)(cv >> 1);
+        const size_t tb = (size_t)(m0 >> 5);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const size_t n = (size_t)((cv & 1) * 2 + nf);
+          const size_t off = (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + n) * 512 + lane * 8;
+          const float v0[4] = {av[nf][0][0], av[nf][0][1], av[nf][0][2], av[nf][0][3]};
+          uint2 h0, l0;
+          split4<O2_LO>(v0, h0, l0);
+          if (MF == 2) {
+            const float v1[4] = {av[nf][MF - 1][0], av[nf][MF - 1][1], av[nf][MF - 1][2], av[nf][MF - 1][3]};
+            uint2 h1, l1;
+            split4<O2_LO>(v1, h1, l1);
+            *reinterpret_cast<uint4*>(p.o2_hi + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            if (O2_LO) *reinterpret_cast<uint4*>(p.o2_hi + off + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          } else {
+            const int half = ((m0 >> 4) & 1) * 4;
+            *reinterpret_cast<uint2*>(p.o2_hi + off + half) = h0;
+            if (O2_LO) *reinterpret_cast<uint2*>(p.o2_hi + off + 2048 + half) = l0;
+          }
+        }
+      }
+    }
+  };
+
+  f32x4 acc_prev[2][MF];
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Unrolled by two so that the LDS stage index is a compile-time constant in each copy: the compiler can
+  // then tell the DMA into stage cur^1 from the fragment reads of stage cur and does NOT drain the DMA
+  // (s_waitcnt vmcnt(0)) before the first ds_read -- the wait sits only in front of the barrier.
+  // Every iteration is ONE basic block: the MFMA orientation of the chunk (SW) and the kind of the deferred
+  // epilogue (SWP: q/k or v for RE_QKV) are compile-time tags, the chunk loop is split at the q/k -> v boundary.
+  auto iteration = [&](int c, auto cur_tag, auto first_tag, auto sw_tag, auto swp_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr bool SW = decltype(sw_tag)::value;
+    constexpr bool SWP = decltype(swp_tag)::value;
+    // every wave passed the barrier that ended iteration c-1, so nobody reads stage cur^1 any more.
+    // Unconditional (the last iteration harmlessly re-copies its own chunk into the idle stage): a DMA issued
+    // under a branch makes the compiler drain it at the join, in front of the first fragment read.
+    if (EPI == RE_QKV && SWP && !FIRST) {  // RoPE rows for the half-head (j = cur ^ 1) of the chunk finished last
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        rope_c[mf] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + (cur ^ 1) * 4);
+        rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + (cur ^ 1) * 4);
+      }
+    }
+    stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
+    if (EPI == RE_QKV) __builtin_amdgcn_sched_barrier(0);  // keep those loads up here, ahead of the DMA's wait
+    if (!FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag, acc_prev);
+
+    f32x4 acc[2][MF];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rowgemm_chunk_mfma<KS, MF, T2, SW>(&sW[cur][lane * 8], a_hi, a_lo, acc);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = acc[nf][mf];
+    if (!FIRST) {
+      // Scheduling recipe for this iteration: the first k-step's fragment reads, then per MFMA two (bf16x3) or five
+      // (bf16) VALU instructions of the deferred epilogue and the fragment reads for the k-step ahead, spread evenly.
+      // Measured (microbench/mfma_loop.hip and the GeLU rewrite): VALU work is NOT free beside MFMAs -- every vector
+      // instruction costs its issue slot -- so the gain of the interleave is only that no wave sits in a VALU-only
+      // phase while its partner waits for the same port; the lever that pays is fewer epilogue instructions.
+      constexpr int NT = term_count(T2);
+      constexpr int N_MFMA = KS * 2 * MF * NT;
+      constexpr int N_DS = KS * 2 * PLANES;
+      constexpr int DS_LATE = N_DS - 2 * PLANES;  // reads placed between the MFMAs, spread evenly
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * PLANES, 0);
+#pragma unroll
+      for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NT == 3 ? 2 : (NT == 2 ? 3 : 5), 0);
+        if (((i + 1) * DS_LATE) / N_MFMA - (i * DS_LATE) / N_MFMA == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (((i + 1) * DS_LATE) / N_MFMA - (i * DS_LATE) / N_MFMA == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    }
+    __syncthreads();
+  };
+  // Even chunk counts on both sides of the q/k -> v boundary (checked on the host).  The first pair is peeled so
+  // that the deferred epilogue is unconditional in the steady-state loops.
+  const std::integral_constant<int, 0> even{};
+  const std::integral_constant<int, 1> odd{};
+  const std::true_type yes{};
+  const std::false_type no{};
+  const int n_sw = (EPI == RE_QKV) ? p.n_swapped : p.n_chunks;
+  iteration(0, even, yes, yes, yes);
+  iteration(1, odd, no, yes, yes);
+  for (int c0 = 2; c0 < n_sw; c0 += 2) {
+    iteration(c0, even, no, yes, yes);
+    iteration(c0 + 1, odd, no, yes, yes);
+  }
+  if (EPI == RE_QKV) {
+    iteration(n_sw, even, no, no, yes);  // first v chunk; finishes the last k chunk
+    iteration(n_sw + 1, odd, no, no, no);
+    for (int c0 = n_sw + 2; c0 < p.n_chunks; c0 += 2) {
+      iteration(c0, even, no, no, no);
+      iteration(c0 + 1, odd, no, no, no);
+    }
+    epilogue(p.n_chunks - 1, odd, no, acc_prev);
+  } else {
+    epilogue(p.n_chunks - 1, odd, yes, acc_prev);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Fragment-packed activations.  An activation matrix [rows x C] that is consumed as the MFMA operand
+// of the next GEMM is stored as 1 KiB pieces  [row/16][C/32][plane][lane = 16*(k%32/8) + row%16][8 k]:
+// exactly one wave-instruction of 16-byte lanes, in lane order.  Producer epilogues store whole pieces
+// (one fully coalesced 1 KiB store per wave), consumers load their fragment with one fully coalesced
+// 1 KiB load straight into registers -- no LDS staging, no row-strided 8-byte accesses.
+// ----------------------------------------------------------------------------------------------
+
+#ifdef OPK_PACK_KERNELS  // weight re-packing runs in op_api.hip only
+// dst[ks][plane][nf][g][i][e] <- W[nf*16 + i][ks*32 + g*8 + e]   (W is [N][K]; chunk = one k-step of all N)
+__global__ void pack_kstream_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst,
+                                    int zero_lo, int* __restrict__ any_lo) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * K) return;
+  const int NF = N / 16;
+  size_t t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int i = (int)(t & 15); t >>= 4;
+  const int g = (int)(t & 3); t >>= 2;
+  const int nf = (int)(t % NF);
+  const int ks = (int)(t / NF);
+  // permute: accumulator slot (nf, i = 4g' + r) holds output feature 32(nf>>1) + 8g' + 4(nf&1) + r, so that the
+  // accumulators of fragments (2s, 2s+1) ARE the 8 k-values of lane slot g' of k-step s of the next GEMM.
+  const int row = permute ? (32 * (nf >> 1) + 8 * (i >> 2) + 4 * (nf & 1) + (i & 3)) : (nf * 16 + i);
+  const float v = src[(size_t)row * K + ks * 32 + g * 8 + e];
+  const u16 h = f2bf(v);
+  const size_t base = ((size_t)ks * 2 * NF + nf) * 512 + (size_t)g * 128 + i * 8 + e;
+  const u16 l = f2bf(v - bf2f(h));
+  if ((l & 0x7fffu) != 0) *any_lo = 1;
+  dst[base] = h;
+  dst[base + (size_t)NF * 512] = zero_lo ? (u16)0 : l;
+}
+#endif
+
+struct KStreamParams {
+  const u16* a_fp;  // fragment-packed activations [r_pad/16][n_ksteps][2 planes][512]
+  const u16* wp;    // packed weights [n_ksteps][2 planes][NF][512]
+  int n_ksteps;     // K / 32
+  float* x;         // fp32 [r_pad][N], x += A W^T
+};
+
+// x[128 or 256 rows, N = 16*NF] += A[rows, K] W[N, K]^T with K streamed: per k-step the block DMAs one
+// [N x 32] weight slab into LDS (double-buffered) while every wave pulls its own two A fragments straight
+// from the fragment-packed activation (prefetched one k-step ahead) and keeps all N outputs of its 32 rows
+// in accumulators (NF x 2 x 4 registers).
+template <int NF, int T, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void kstream_gemm_kernel(KStreamParams p) {
+  constexpr bool W_LO = (T & T_RIGHT_LO) != 0, A_LO = (T & T_LEFT_LO) != 0;
+  constexpr int PLANES = W_LO ? 2 : 1;
+  constexpr int STAGE = NF * PLANES * 512;        // elements per LDS stage
+  constexpr int CHUNK_SRC = NF * 2 * 512;         // elements per k-step in the packed weights
+  constexpr int WAVE_PIECES = STAGE / (WAVES * 512);
+  static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
+  __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+  const int m0 = blockIdx.x * (WAVES * 32) + wave * 32;
+  const int nks = p.n_ksteps;
+
+  auto stage_chunk = [&](int ks, int stage) {
+    const u16* src = p.wp + (size_t)ks * CHUNK_SRC;
+#pragma unroll
+    for (int u = 0; u < WAVE_PIECES; ++u) {
+      const int piece = wave + WAVES * u;  // stage = [plane][nf] pieces; source = same order (2 planes)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+    }
+  };
+  // A fragments of k-step ks: piece (rb, ks, plane) of the fragment-packed activation, 16 bytes per lane
+  const u16* a_base0 = p.a_fp + ((size_t)(m0 >> 4) * nks * 2) * 512 + lane * 8;
+  const u16* a_base1 = a_base0 + (size_t)nks * 2 * 512;
+  bf16x8 an_hi[2], an_lo[2];
+  auto load_a = [&](int ks) {
+    an_hi[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks * 1024);
+    an_hi[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks * 1024);
+    if (A_LO) {
+      an_lo[0] = *reinterpret_cast<const bf16x8*>(a_base0 + (size_t)ks * 1024 + 512);
+      an_lo[1] = *reinterpret_cast<const bf16x8*>(a_base1 + (size_t)ks * 1024 + 512);
+    }
+  };
+
+  f32x4 acc[NF][2];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_chunk(0, 0);
+  load_a(0);
+  // Retire the first fragment loads HERE (empty asm "rewrites" the registers): a load still pending at the loop
+  // header makes the compiler drain everything (vmcnt(0)) right after the loop body has issued its DMA.
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    asm volatile("" : "+v"(an_hi[mf]));
+    if (A_LO) asm volatile("" : "+v"(an_lo[mf]));
+  }
+  __syncthreads();
+
+  for (int k0 = 0; k0 < nks; k0 += 2) {
+#pragma unroll
+    for (int cur = 0; cur < 2; ++cur) {
+      const int ks = k0 + cur;
+      if (ks >= nks) break;
+      const int kn = ks + 1 < nks ? ks + 1 : ks;
+      stage_chunk(kn, cur ^ 1);
+      bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        a_hi[mf] = an_hi[mf];
+        a_lo[mf] = an_lo[mf];
+      }
+      load_a(kn);                              // prefetch the next k-step's fragments ...
+      __builtin_amdgcn_sched_barrier(0);       // ... and keep the loads up here, ahead of the MFMAs
+#pragma unroll
+      for (int nf = 0; nf < NF; nf += 2) {  // term-major over 2 fragments x 2 row blocks (see rowgemm_kernel phase 1)
+        bf16x8 wh[2], wl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
+          wl[j] = W_LO ? lds_frag(&sW[cur][(NF + nf + j) * 512 + lane * 8]) : wh[j];
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+          if ((term == 0 && !W_LO) || (term == 1 && !A_LO)) continue;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+              acc[nf + j][mf] = mfma16(term == 0 ? wl[j] : wh[j], term == 1 ? a_lo[mf] : a_hi[mf], acc[nf + j][mf]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // x += acc : the weights are packed with permuted output features (pack_kstream_kernel), accumulator slot
+  // (nf, g, r) is feature 32(nf>>1) + 8g + 4(nf&1) + r of token m0 + 16mf + l15
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    float* xrow = p.x + (size_t)(m0 + mf * 16 + l15) * (NF * 16) + g * 8;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
+      float4 r4 = *px;
+      r4.x += acc[nf][mf][0];
+      r4.y += acc[nf][mf][1];
+      r4.z += acc[nf][mf][2];
+      r4.w += acc[nf][mf][3];
+      *px = r4;
+    }
+  }
+}
+
+}  // namespace opk

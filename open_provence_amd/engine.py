@@ -8,6 +8,7 @@ path.  Everything numerical happens inside ``op_forward_packed`` (``include/open
 from __future__ import annotations
 
 import ctypes
+import os
 from contextlib import contextmanager
 from typing import Iterator, Mapping, Sequence
 
@@ -18,7 +19,37 @@ from . import _lib
 from .config import EncoderDims
 from .packing import pack_rows
 
-_PRECISIONS = {"bf16x3": _lib.OP_PRECISION_BF16X3, "bf16": _lib.OP_PRECISION_BF16}
+_PRECISIONS = {"bf16x3": _lib.OP_PRECISION_BF16X3, "bf16x2": _lib.OP_PRECISION_BF16X2, "bf16": _lib.OP_PRECISION_BF16}
+# measurement / test switches, read ONCE when an encoder is created (the C ABI keeps no process-global state)
+_ENV_FLAGS = {
+    "OPEN_PROVENCE_FORCE_TILED": _lib.OP_FLAG_FORCE_TILED,
+    "OPEN_PROVENCE_NO_SMALL_BLOCKS": _lib.OP_FLAG_NO_SMALL_BLOCKS,
+    "OPEN_PROVENCE_NO_POLICY_KERNELS": _lib.OP_FLAG_NO_POLICY_KERNELS,
+}
+
+
+def parse_precision(precision: "str | Mapping[str, int]") -> tuple[int, list[int]]:
+    """``"bf16x3" | "bf16x2" | "bf16"`` or a per-family term-mask mapping / ``"wqkv=1,qk=3,..."`` string
+    (families: ``_lib.OP_FAMILIES``; mask bit 0 = lo(activation) x hi, bit 1 = hi x lo(weight / key / value);
+    families left out keep all terms) -> (enum op_precision, terms[8])."""
+
+    terms = [3] * len(_lib.OP_FAMILIES) + [0] * (8 - len(_lib.OP_FAMILIES))
+    if isinstance(precision, str) and precision in _PRECISIONS:
+        return _PRECISIONS[precision], terms
+    if isinstance(precision, str):
+        try:
+            mapping = {k.strip(): int(v) for k, v in (item.split("=") for item in precision.split(",") if item.strip())}
+        except ValueError as exc:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)} or 'family=mask,...': {precision!r}") from exc
+    else:
+        mapping = dict(precision)
+    for name, mask in mapping.items():
+        if name not in _lib.OP_FAMILIES:
+            raise ValueError(f"unknown contraction family {name!r}; expected one of {_lib.OP_FAMILIES}")
+        if int(mask) not in (0, 1, 2, 3):
+            raise ValueError(f"term mask of {name!r} must be 0..3, got {mask!r}")
+        terms[_lib.OP_FAMILIES.index(name)] = int(mask)
+    return _lib.OP_PRECISION_CUSTOM, terms
 _DTYPES = {torch.float32: _lib.OP_DTYPE_F32, torch.bfloat16: _lib.OP_DTYPE_BF16, torch.float16: _lib.OP_DTYPE_F16}
 
 
@@ -48,11 +79,12 @@ class HipEncoder:
         dims: EncoderDims,
         *,
         device: torch.device | str | int | None = None,
-        precision: str = "bf16x3",
+        precision: "str | Mapping[str, int]" = "bf16x3",
         chunk_rows: int | None = None,
+        prune_pre_final_norm: bool = False,
+        flags: int | None = None,
     ) -> None:
-        if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        precision_code, terms = parse_precision(precision)
         self.lib = _lib.load_library()
         self.device = require_gpu(device)
         self.dims = dims
@@ -71,7 +103,20 @@ class HipEncoder:
         cfg.local_attention = dims.local_attention
         cfg.max_position_embeddings = dims.max_position_embeddings
         cfg.pooling = _lib.OP_POOL_MEAN if dims.classifier_pooling == "mean" else _lib.OP_POOL_CLS
-        cfg.precision = _PRECISIONS[precision]
+        cfg.precision = precision_code
+        for i, mask in enumerate(terms):
+            cfg.terms[i] = mask
+        if flags is None:
+            flags = 0
+            for name, bit in _ENV_FLAGS.items():
+                if os.environ.get(name):
+                    flags |= bit
+            waves = os.environ.get("OPEN_PROVENCE_ATT_WAVES")
+            if waves:
+                flags |= _lib.OP_FLAG_ATT_WAVES_4 if int(waves) == 4 else _lib.OP_FLAG_ATT_WAVES_8
+        cfg.flags = int(flags)
+        cfg.prune_pre_final_norm = 1 if prune_pre_final_norm else 0
+        self.prune_pre_final_norm = bool(prune_pre_final_norm)
         cfg.norm_eps = dims.norm_eps
         cfg.global_rope_theta = dims.global_rope_theta
         cfg.local_rope_theta = dims.local_rope_theta
@@ -122,6 +167,21 @@ class HipEncoder:
             self.load_weight(name, tensor)
         _lib.check(self.lib, self._handle, self.lib.op_weights_ready(self._handle), "op_weights_ready")
 
+    def effective_policy(self) -> dict:
+        """Term masks actually evaluated (the requested policy minus weight-lo terms that are identically zero
+        for the loaded checkpoint) and the kernel set running them: ``{"terms": {family: mask}, "kernel_set":
+        "bf16x3" | "bf16-weights" | "bf16" | "all-terms kernels, cleared lo operands"}``."""
+
+        terms = (ctypes.c_uint8 * 8)()
+        kernel_set = ctypes.c_int(0)
+        code = self.lib.op_effective_policy(self._handle, terms, ctypes.byref(kernel_set))
+        _lib.check(self.lib, self._handle, code, "op_effective_policy")
+        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", -1: "all-terms kernels, cleared lo operands"}
+        return {
+            "terms": {name: int(terms[i]) for i, name in enumerate(_lib.OP_FAMILIES)},
+            "kernel_set": names.get(int(kernel_set.value), str(kernel_set.value)),
+        }
+
     # -- forward ---------------------------------------------------------------------------------
     def _ensure_workspace(self, n_seqs: int, total_tokens: int, max_seqlen: int) -> torch.Tensor:
         need = int(self.lib.op_workspace_bytes(self._handle, n_seqs, total_tokens, max_seqlen))
@@ -140,8 +200,11 @@ class HipEncoder:
         cu_seqlens: torch.Tensor,
         cu_seqlens_host: np.ndarray,
         max_seqlen: int,
+        keep_prob: torch.Tensor | None = None,
     ) -> tuple[torch.Tensor, torch.Tensor]:
         """``ids[T]`` / ``cu_seqlens[B+1]`` int32 on this device -> (prune_logits[T, 2], rank_logits[B, nl]) fp32.
+        ``keep_prob`` (optional, fp32 ``[T]`` on this device) additionally receives
+        ``softmax(prune_logits, -1)[:, 1]``, evaluated in the head kernel.
 
         Asynchronous on the current torch stream of ``self.device``."""
 
@@ -156,6 +219,11 @@ class HipEncoder:
             raise ValueError("cu_seqlens_host length mismatch")
         prune = torch.empty((total, 2), dtype=torch.float32, device=self.device)
         rank = torch.empty((n_seqs, self.dims.num_labels), dtype=torch.float32, device=self.device)
+        if keep_prob is not None and (
+            keep_prob.dtype != torch.float32 or keep_prob.device != self.device or keep_prob.numel() != total
+            or not keep_prob.is_contiguous()
+        ):
+            raise ValueError("keep_prob must be a contiguous fp32 tensor of total_tokens elements on the encoder's device")
         if n_seqs == 0:
             return prune, rank
         ws = self._ensure_workspace(n_seqs, total, int(max_seqlen))
@@ -180,6 +248,7 @@ class HipEncoder:
                 int(max_seqlen),
                 ctypes.c_void_p(prune.data_ptr()),
                 ctypes.c_void_p(rank.data_ptr()),
+                ctypes.c_void_p(keep_prob.data_ptr()) if keep_prob is not None else None,
                 ctypes.c_void_p(aligned),
                 ctypes.c_size_t(ws.numel() - (aligned - base)),
                 ctypes.c_void_p(stream),
@@ -187,10 +256,21 @@ class HipEncoder:
         _lib.check(self.lib, self._handle, code, "op_forward_packed")
         return prune, rank
 
+    def check_ids(self, ids: np.ndarray) -> None:
+        """``nn.Embedding`` raises on out-of-range ids (the reference's behaviour); the kernel only clamps them as a
+        memory-safety net, so the host validates wherever ids are still in host memory."""
+
+        if ids.size and (int(ids.min()) < 0 or int(ids.max()) >= self.dims.vocab_size):
+            raise IndexError(
+                f"token id out of range for the embedding table: ids span [{int(ids.min())}, {int(ids.max())}], "
+                f"vocab_size is {self.dims.vocab_size}"
+            )
+
     def forward_rows(self, rows: Sequence[Sequence[int]]) -> tuple[torch.Tensor, torch.Tensor, np.ndarray]:
         """Convenience: host id rows -> one H2D copy -> forward.  Returns (prune[T,2], rank[B,nl], cu_host)."""
 
         ids_np, cu_np, max_len = pack_rows(rows)
+        self.check_ids(ids_np)
         ids = torch.from_numpy(ids_np).to(self.device, non_blocking=False)
         cu = torch.from_numpy(cu_np).to(self.device, non_blocking=False)
         prune, rank = self.forward_packed(ids, cu, cu_np, max_len)

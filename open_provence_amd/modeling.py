@@ -411,6 +411,7 @@ class OpenProvenceModel:
         if labels is not None:
             raise NotImplementedError("training losses are outside the MI355X inference path")
         ids_np, cu_np, max_len = pack_padded(input_ids, attention_mask)
+        self.encoder.check_ids(ids_np)
         width = int(input_ids.shape[1])
         dev = self._runtime_device
         ids = torch.from_numpy(ids_np).to(dev)
@@ -423,7 +424,8 @@ class OpenProvenceModel:
             loss=None, logits=rank, ranking_logits=rank, pruning_logits=pruning_logits, hidden_states=None, attentions=None
         )
 
-    __call__ = forward
+    def __call__(self, *args: Any, **kwargs: Any):
+        return self.forward(*args, **kwargs)
 
     def _forward_is_native(self) -> bool:
         """True unless ``forward`` was overridden / monkeypatched (the reference's tests do that, and the
@@ -445,11 +447,15 @@ class OpenProvenceModel:
 
         if self._forward_is_native():
             ids_np, cu_np, max_len = pack_rows(rows)
+            self.encoder.check_ids(ids_np)
             dev = self._runtime_device
-            prune, rank = self.encoder.forward_packed(
-                torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev), cu_np, max_len
+            # keep-probability = softmax(pruning_logits)[:, 1], evaluated by the head kernel itself (no ATen
+            # arithmetic on the product path; the D2H payload is 4 B per token)
+            keep_dev = torch.empty(int(cu_np[-1]), dtype=torch.float32, device=dev)
+            _, rank = self.encoder.forward_packed(
+                torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev), cu_np, max_len, keep_prob=keep_dev
             )
-            keep = torch.softmax(prune, dim=-1)[:, 1].contiguous().cpu().numpy()
+            keep = keep_dev.cpu().numpy()
             rank_cpu = rank.cpu()
             return rank_cpu, [keep[cu_np[i] : cu_np[i + 1]] for i in range(len(rows))]
 
@@ -1132,8 +1138,6 @@ class OpenProvenceForTokenClassification(OpenProvenceModel):
             hidden_states=None,
             attentions=None,
         )
-
-    __call__ = forward
 
 
 # module-level helpers under the reference's names (its tests import these: tests/test_modeling_open_provence.py:11-29)

@@ -107,6 +107,63 @@ def synth_state_dict(dims: EncoderDims, seed: int) -> dict[str, torch.Tensor]:
     return out
 
 
+def _truncated_normal(seed: int, tag: int, shape: Sequence[int], std: float, cutoff: float) -> torch.Tensor:
+    """N(0, std^2) truncated to +-cutoff * std (resampling, like ``nn.init.trunc_normal_``'s distribution), from the
+    same counter-based stream: Box-Muller on float64 uniforms, so the values depend on (seed, tag, index) only."""
+
+    count = int(np.prod(shape))
+    out = np.empty(count, dtype=np.float64)
+    todo = np.arange(count)
+    attempt = 0
+    while todo.size:
+        with np.errstate(over="ignore"):
+            base = _splitmix64(np.array([np.uint64(seed) * np.uint64(0x1000003) + np.uint64(tag) + (np.uint64(attempt) << np.uint64(40))], dtype=np.uint64))[0]
+            idx = todo.astype(np.uint64) * np.uint64(2) + base
+        b1 = _splitmix64(idx) >> np.uint64(11)
+        b2 = _splitmix64(idx + np.uint64(1)) >> np.uint64(11)
+        u1 = (b1.astype(np.float64) + 1.0) * (1.0 / (1 << 53))  # (0, 1]
+        u2 = b2.astype(np.float64) * (1.0 / (1 << 53))
+        z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+        ok = np.abs(z) <= cutoff
+        out[todo[ok]] = z[ok]
+        todo = todo[~ok]
+        attempt += 1
+    values = (out * std).astype(np.float32)
+    return torch.from_numpy(values.reshape(tuple(shape))).clone()
+
+
+def refinit_state_dict(dims: EncoderDims, seed: int, *, initializer_range: float = 0.02, cutoff_factor: float = 2.0) -> dict[str, torch.Tensor]:
+    """Checkpoint-shaped state dict drawn from the distributions the reference's OWN initialisation uses -- HF
+    ``ModernBertPreTrainedModel._init_weights`` (modeling_modernbert.py:353-400: truncated normal, std 0.02 for
+    embeddings / Wqkv / Wi, 0.02 / sqrt(2 N) for the output projections and the head's dense, H^-0.5 for the
+    classifier, norm weights 1, biases 0) and ``OpenProvenceHead._init_weights`` (standalone.py:427-432: Xavier-uniform
+    pruning classifier, zero bias) -- but regenerated from ``(dims, seed)`` so that full-depth fixtures need not store
+    10^7..10^8 weights.  The numerical regime (tiny residual branches, near-uniform attention, logits of order
+    0.1) is the one a freshly constructed reference model is in; :func:`synth_state_dict` is the hard regime."""
+
+    H, nl = dims.hidden_size, dims.num_labels
+    std_in = initializer_range
+    std_out = initializer_range / math.sqrt(2.0 * dims.num_layers)
+    out: dict[str, torch.Tensor] = {}
+    for tag, (name, shape) in enumerate(state_dict_keys(dims)):
+        if name.endswith("norm.weight"):
+            tensor = torch.ones(shape, dtype=torch.float32)
+        elif name.endswith("tok_embeddings.weight") or name.endswith("Wqkv.weight") or name.endswith("Wi.weight"):
+            tensor = _truncated_normal(seed, tag, shape, std_in, cutoff_factor)
+        elif name.endswith("attn.Wo.weight") or name.endswith("mlp.Wo.weight") or name.endswith("dense.weight"):
+            tensor = _truncated_normal(seed, tag, shape, std_out, cutoff_factor)
+        elif name == "ranking_model.classifier.weight":
+            tensor = _truncated_normal(seed, tag, shape, H ** -0.5, cutoff_factor)
+        elif name == "pruning_head.classifier.weight":
+            tensor = _filled(seed, tag, shape, math.sqrt(6.0 / (H + 2)))
+        elif name.endswith("classifier.bias"):
+            tensor = torch.zeros(shape, dtype=torch.float32)
+        else:  # pragma: no cover - key list and branches are kept in sync
+            raise KeyError(name)
+        out[name] = tensor
+    return out
+
+
 def synth_pair_batch(
     dims: EncoderDims,
     n_pairs: int,

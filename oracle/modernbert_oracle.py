@@ -82,6 +82,7 @@ def oracle_forward(
     dtype: torch.dtype = torch.float32,
     attn: str = "eager",
     return_hidden: bool = False,
+    prune_pre_final_norm: bool = False,
 ) -> OracleOutput:
     """Padded-batch forward: ``input_ids[B, L]`` int64, ``attention_mask[B, L]`` (1 = real token).
 
@@ -157,7 +158,10 @@ def oracle_forward(
 
     pw = state["pruning_head.classifier.weight"].to(dtype)
     pb = state["pruning_head.classifier.bias"].to(dtype)
-    pruning_logits = last @ pw.T + pb
+    # standalone.py:1695 feeds outputs.hidden_states[-1] to the head: the final_norm output under transformers >= 5
+    # (utils/output_capturing.py:269-277 ties it to last_hidden_state), the last layer's un-normalised output under
+    # the 4.x line the reference pins (its ModernBertModel.forward appended the tuple entry before final_norm).
+    pruning_logits = (x if prune_pre_final_norm else last) @ pw.T + pb
     return OracleOutput(ranking_logits=ranking_logits, pruning_logits=pruning_logits, hidden_states=hidden)
 
 

@@ -38,7 +38,7 @@ sys.path.insert(0, str(REPO / "tests"))
 from helpers import CharTokenizer, period_splitter  # noqa: E402
 
 from open_provence_amd.config import EncoderDims  # noqa: E402
-from open_provence_amd.synthetic import synth_state_dict  # noqa: E402
+from open_provence_amd.synthetic import refinit_state_dict, synth_state_dict  # noqa: E402
 
 REFERENCE_FILE = Path("/root/reference/open_provence/modeling_open_provence_standalone.py")
 
@@ -75,7 +75,7 @@ def versions() -> dict[str, str]:
     }
 
 
-def build_model(ref, base_cfg: dict[str, Any], *, max_length: int, seed: int, weight_seed: int | None):
+def build_model(ref, base_cfg: dict[str, Any], *, max_length: int, seed: int, weight_seed: int | None, weight_init: str = "synth"):
     torch.manual_seed(seed)
     cfg = ref.OpenProvenceConfig(
         base_model_config=dict(base_cfg),
@@ -87,12 +87,44 @@ def build_model(ref, base_cfg: dict[str, Any], *, max_length: int, seed: int, we
     model = ref.OpenProvenceModel(cfg)
     dims = EncoderDims.from_base_model_config(base_cfg, num_labels=1)
     if weight_seed is not None:
-        state = synth_state_dict(dims, weight_seed)
+        state = (refinit_state_dict if weight_init == "refinit" else synth_state_dict)(dims, weight_seed)
         missing, unexpected = model.load_state_dict(state, strict=False)
         bad = [k for k in missing if "inv_freq" not in k]
         assert not bad and not unexpected, (bad, unexpected)
     model.eval()
     return model, dims
+
+
+class emulate_transformers4_hidden_states:
+    """The reference takes ``outputs.hidden_states[-1]`` (standalone.py:1695).  transformers >= 5 ties that entry to
+    ``last_hidden_state`` (utils/output_capturing.py:269-277); the 4.x line the reference pins (uv.lock: 4.57.1)
+    appended the last layer's output BEFORE ``final_norm`` (source not available offline; recalled).
+    This context reproduces the 4.x tuple around the reference's unmodified forward: a pre-hook on ``final_norm``
+    records its input and the backbone's output tuple gets that tensor as its last entry."""
+
+    def __init__(self, model) -> None:
+        self.model = model
+        self.captured: list[torch.Tensor] = []
+
+    def __enter__(self):
+        backbone = self.model.ranking_model
+        self._hook = backbone.model.final_norm.register_forward_pre_hook(lambda _m, args: self.captured.append(args[0]))
+        self._orig = backbone.forward
+
+        def patched(*args, **kwargs):
+            self.captured.clear()
+            out = self._orig(*args, **kwargs)
+            if getattr(out, "hidden_states", None) is not None and self.captured:
+                out.hidden_states = tuple(out.hidden_states[:-1]) + (self.captured[-1],)
+            return out
+
+        backbone.forward = patched
+        return self
+
+    def __exit__(self, *exc):
+        self.model.ranking_model.forward = self._orig
+        self._hook.remove()
+        return False
 
 
 def make_rows(dims: EncoderDims, lengths: list[int], seed: int) -> tuple[torch.Tensor, torch.Tensor]:
@@ -129,12 +161,18 @@ def forward_fixture(
     hidden_stride: int | None,
     init_seed: int = 0,
     input_seed: int = 1234,
+    weight_init: str = "synth",
+    transformers4_hidden_states: bool = False,
 ) -> None:
     ref = load_reference()
-    model, dims = build_model(ref, cfg, max_length=max(lengths), seed=init_seed, weight_seed=weight_seed)
+    model, dims = build_model(ref, cfg, max_length=max(lengths), seed=init_seed, weight_seed=weight_seed, weight_init=weight_init)
     ids, mask = make_rows(dims, lengths, input_seed)
     with torch.no_grad():
-        out = model(input_ids=ids, attention_mask=mask)
+        if transformers4_hidden_states:
+            with emulate_transformers4_hidden_states(model):
+                out = model(input_ids=ids, attention_mask=mask)
+        else:
+            out = model(input_ids=ids, attention_mask=mask)
     arrays: dict[str, np.ndarray] = {
         "input_ids": ids.numpy(),
         "attention_mask": mask.numpy(),
@@ -165,6 +203,12 @@ def forward_fixture(
     }
     if weight_seed is not None:
         meta["weight_seed"] = weight_seed
+        meta["weight_init"] = weight_init
+    if transformers4_hidden_states:
+        meta["prune_pre_final_norm"] = True
+        meta["note"] = ("hidden_states[-1] patched to the final_norm INPUT (emulate_transformers4_hidden_states): what "
+                        "transformers 4.x ModernBertModel.forward returned, hence what the reference's pruning head "
+                        "sees under its own uv.lock pin (4.57.1); the reference's forward code is otherwise untouched")
     np.savez_compressed(HERE / f"{name}.npz", **arrays)
     (HERE / f"{name}.json").write_text(json.dumps(meta, indent=2, sort_keys=True))
     print(f"[golden] {name}: rank={arrays['ranking_logits'].ravel()[:4]} prune-absmax={np.abs(arrays['pruning_logits']).max():.3f}")
@@ -587,6 +631,31 @@ def main() -> None:
             [2048, 128, 1024, 384, 1536, 256],
             weight_seed=31,
             hidden_stride=None,
+        )
+    # G7 / G8: xsmall and base at FULL depth with weights drawn from the reference's own initialisation
+    # distributions (regenerated from the seed: open_provence_amd.synthetic.refinit_state_dict) -- the regime a freshly
+    # constructed reference model is in, beside the O(1) regime of G1 / G2.
+    if want("g7_xsmall_refinit"):
+        forward_fixture(
+            "g7_xsmall_refinit",
+            base_cfg(vocab_size=2048, hidden_size=256, intermediate_size=1024, num_hidden_layers=10, num_attention_heads=4),
+            [512, 300, 512, 129, 64, 411],
+            weight_seed=51, weight_init="refinit", hidden_stride=61,
+        )
+    if want("g8_base_refinit"):
+        forward_fixture(
+            "g8_base_refinit",
+            base_cfg(vocab_size=2048, hidden_size=512, intermediate_size=2048, num_hidden_layers=19, num_attention_heads=8),
+            [512, 200, 384, 77],
+            weight_seed=52, weight_init="refinit", hidden_stride=None,
+        )
+    # G12: the pruning head on the PRE-final_norm state (transformers 4.x hidden_states[-1]); xsmall shape, 4 layers.
+    if want("g12_prenorm_tf4"):
+        forward_fixture(
+            "g12_prenorm_tf4",
+            base_cfg(vocab_size=2048, hidden_size=256, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=4),
+            [256, 100, 192, 33],
+            weight_seed=61, hidden_stride=None, transformers4_hidden_states=True,
         )
     g3_cfg = base_cfg(vocab_size=256, hidden_size=128, intermediate_size=128, num_hidden_layers=4, num_attention_heads=2, local_attention=32)
     if want("g3_process_stub"):

@@ -135,9 +135,10 @@ def state_from_fixture(arrays: dict[str, np.ndarray], meta: dict[str, Any]) -> d
     """Stored weights (keys prefixed ``w::``) or regenerated from ``meta['weight_seed']``."""
 
     if "weight_seed" in meta:
-        from open_provence_amd.synthetic import synth_state_dict
+        from open_provence_amd.synthetic import refinit_state_dict, synth_state_dict
 
-        return synth_state_dict(dims_from_meta(meta), int(meta["weight_seed"]))
+        make = refinit_state_dict if meta.get("weight_init") == "refinit" else synth_state_dict
+        return make(dims_from_meta(meta), int(meta["weight_seed"]))
     return {k[3:]: torch.from_numpy(v.copy()) for k, v in arrays.items() if k.startswith("w::")}
 
 

@@ -10,7 +10,7 @@ import torch
 from helpers import dims_from_meta, load_golden, rows_from_fixture, state_from_fixture
 
 
-def run_fixture_on_gpu(name: str, precision: str = "bf16x3", chunk_rows: int | None = None, capture: bool = True):
+def run_fixture_on_gpu(name: str, precision="bf16x3", chunk_rows: int | None = None, capture: bool = True, flags=None, return_outputs: bool = False):
     """Returns dict with max-abs errors of the HIP path vs the reference outputs stored in the fixture."""
 
     from open_provence_amd.engine import HipEncoder
@@ -19,8 +19,10 @@ def run_fixture_on_gpu(name: str, precision: str = "bf16x3", chunk_rows: int | N
     dims = dims_from_meta(meta)
     state = state_from_fixture(arrays, meta)
     rows = rows_from_fixture(arrays)
-    enc = HipEncoder(dims, device="cuda:0", precision=precision, chunk_rows=chunk_rows)
+    enc = HipEncoder(dims, device="cuda:0", precision=precision, chunk_rows=chunk_rows, flags=flags,
+                     prune_pre_final_norm=bool(meta.get("prune_pre_final_norm", False)))
     enc.load_state_dict(state)
+    policy = enc.effective_policy()
     if capture:
         with enc.capture_hidden():
             prune, rank, cu = enc.forward_rows(rows)
@@ -40,6 +42,8 @@ def run_fixture_on_gpu(name: str, precision: str = "bf16x3", chunk_rows: int | N
     report: dict[str, Any] = {
         "name": name,
         "precision": precision,
+        "kernel_set": policy["kernel_set"],
+        "terms": policy["terms"],
         "finite": bool(np.isfinite(prune).all() and np.isfinite(rank).all()),
         "prune_max_err": float(np.abs(prune - ref_prune).max()),
         "rank_max_err": float(np.abs(rank - ref_rank).max()),
@@ -50,6 +54,9 @@ def run_fixture_on_gpu(name: str, precision: str = "bf16x3", chunk_rows: int | N
     report["sigmoid_rank_max_err"] = float(
         np.abs(1 / (1 + np.exp(-rank[:, 0].astype(np.float64))) - 1 / (1 + np.exp(-ref_rank[:, 0].astype(np.float64)))).max()
     )
+    if return_outputs:
+        report["prune"] = prune
+        report["rank"] = rank
     stride = meta.get("hidden_stride")
     if hidden is not None and stride:
         per_layer = []

@@ -13,7 +13,8 @@ from parity_utils import run_fixture_on_gpu
 
 pytestmark = pytest.mark.gpu
 
-FIXTURES = ["g0b_hd64_refinit", "g0c_hd64_synth", "g1m_meanpool", "g1_xsmall", "g2_gte_varlen"]
+FIXTURES = ["g0b_hd64_refinit", "g0c_hd64_synth", "g1m_meanpool", "g1_xsmall", "g2_gte_varlen",
+            "g7_xsmall_refinit", "g8_base_refinit", "g12_prenorm_tf4"]
 TOL = 1e-3
 
 
@@ -44,18 +45,22 @@ def test_chunking_does_not_change_results(chunk_rows):
     assert abs(a["prune_max_err"] - b["prune_max_err"]) < 1e-4
 
 
-@pytest.mark.parametrize("env", [{"OPEN_PROVENCE_FORCE_TILED": "1"}, {"OPEN_PROVENCE_NO_FUSE": "1"}])
-def test_alternative_kernel_paths_agree(env, monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x2", {"qk": 2, "pv": 1, "wi": 2}])
+def test_generic_tiled_kernels_agree(precision, monkeypatch):
     """Three GEMM families exist: row-stationary fused kernels (hidden <= 256, default), k-streamed panel kernels
     (hidden % 256 == 0: base / large / en-gte; the H=768 fixture takes them by default) and the generic 128x128
-    tiles (any other shape).  The tiled kernels and the unfused row-stationary kernels must give the same answers as
-    the defaults on the xsmall-shaped fixtures, and the tiled kernels on the H=768 ragged fixture."""
+    tiles (any other shape; forced here through OP_FLAG_FORCE_TILED).  The tiled kernels must give the same answers
+    as the defaults: within the bar for bf16x3, and for a narrower policy within 1e-4 of that policy's result on the
+    default kernels (same arithmetic, different accumulation order)."""
 
-    for key, value in env.items():
-        monkeypatch.setenv(key, value)
-    names = ["g1_xsmall", "g0c_hd64_synth"]
-    if "OPEN_PROVENCE_FORCE_TILED" in env:
-        names.append("g2_gte_varlen")
-    for name in names:
-        rep = run_fixture_on_gpu(name, "bf16x3")
-        assert rep["finite"] and rep["prune_max_err"] < TOL and rep["rank_max_err"] < TOL, rep
+    for name in ["g1_xsmall", "g0c_hd64_synth", "g2_gte_varlen"]:
+        tiled = run_fixture_on_gpu(name, precision, flags=1, capture=False, return_outputs=True)
+        assert tiled["finite"]
+        if precision == "bf16x3":
+            assert tiled["prune_max_err"] < TOL and tiled["rank_max_err"] < TOL, tiled
+        else:
+            default = run_fixture_on_gpu(name, precision, capture=False, return_outputs=True)
+            assert tiled["terms"] == default["terms"]
+            scale = max(1.0, float(np.abs(default["prune"]).max()))
+            assert np.abs(tiled["prune"] - default["prune"]).max() < 3e-4 * scale, (name, precision)
+            assert np.abs(tiled["rank"] - default["rank"]).max() < 3e-4 * scale, (name, precision)

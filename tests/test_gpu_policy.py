@@ -1,0 +1,64 @@
+"""Precision policies through the C ABI (GPU).
+
+* A policy evaluated on its curated kernel set (exactly the MFMA passes it needs) is BIT-IDENTICAL to the same
+  policy evaluated on the all-terms kernels with the unused lo operands cleared -- the identity the precision sweep
+  (scripts/precision_sweep.py) relies on.
+* A bf16 checkpoint drops the hi x lo(weight) terms automatically without changing a bit of the result.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import dims_from_meta, load_golden, rows_from_fixture, state_from_fixture
+from parity_utils import run_fixture_on_gpu
+
+pytestmark = pytest.mark.gpu
+
+NO_POLICY_KERNELS = 16  # OP_FLAG_NO_POLICY_KERNELS
+
+
+@pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
+@pytest.mark.parametrize("precision", ["bf16x2", "bf16"])
+def test_curated_kernel_set_equals_cleared_operands(fixture, precision):
+    fast = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True)
+    slow = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True, flags=NO_POLICY_KERNELS)
+    assert fast["kernel_set"] in ("bf16-weights", "bf16")
+    assert slow["kernel_set"].startswith("all-terms")
+    assert fast["terms"] == slow["terms"]
+    assert np.array_equal(fast["prune"], slow["prune"])
+    assert np.array_equal(fast["rank"], slow["rank"])
+
+
+def test_arbitrary_policy_runs_on_cleared_operands():
+    rep = run_fixture_on_gpu("g1_xsmall", {"pv": 2, "wi": 1}, capture=False)
+    assert rep["kernel_set"].startswith("all-terms")
+    assert rep["terms"]["pv"] == 2 and rep["terms"]["wi"] == 1 and rep["terms"]["qk"] == 3
+    assert rep["finite"]
+
+
+@pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
+def test_bf16_checkpoint_drops_weight_lo_terms_bit_identically(fixture):
+    """Weights rounded to bf16 (what `torch_dtype=torch.bfloat16` loads, standalone.py:219-233): the default bf16x3
+    request resolves to the two-pass weight GEMMs, and the result equals the three-pass evaluation exactly."""
+
+    from open_provence_amd.engine import HipEncoder
+
+    arrays, meta = load_golden(fixture)
+    dims = dims_from_meta(meta)
+    state = {k: v.to(torch.bfloat16) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v
+             for k, v in state_from_fixture(arrays, meta).items()}
+    rows = rows_from_fixture(arrays)
+    outs = []
+    for flags in (0, NO_POLICY_KERNELS):
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
+        enc.load_state_dict(state)
+        policy = enc.effective_policy()
+        assert policy["terms"] == {"wqkv": 1, "qk": 3, "pv": 3, "attn_out": 1, "wi": 1, "mlp_out": 1}
+        assert policy["kernel_set"] == ("bf16-weights" if flags == 0 else "all-terms kernels, cleared lo operands")
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        outs.append((prune.cpu().numpy(), rank.cpu().numpy()))
+        enc.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])

@@ -9,7 +9,8 @@ import torch
 from helpers import dims_from_meta, load_golden, state_from_fixture
 from oracle.modernbert_oracle import keep_probabilities, oracle_forward
 
-FORWARD_FIXTURES = ["g0_tiny_hd16", "g0b_hd64_refinit", "g0c_hd64_synth", "g1m_meanpool", "g1_xsmall"]
+FORWARD_FIXTURES = ["g0_tiny_hd16", "g0b_hd64_refinit", "g0c_hd64_synth", "g1m_meanpool", "g1_xsmall",
+                    "g7_xsmall_refinit", "g8_base_refinit", "g12_prenorm_tf4"]
 TOL = 5e-5
 
 
@@ -20,11 +21,15 @@ def test_oracle_matches_reference_outputs(name):
     state = state_from_fixture(arrays, meta)
     ids = torch.from_numpy(arrays["input_ids"])
     mask = torch.from_numpy(arrays["attention_mask"])
-    out = oracle_forward(state, dims, ids, mask, return_hidden=True)
+    pre_norm = bool(meta.get("prune_pre_final_norm", False))  # transformers-4.x hidden_states[-1] (see make_golden.py)
+    out = oracle_forward(state, dims, ids, mask, return_hidden=True, prune_pre_final_norm=pre_norm)
     m = mask.bool().numpy()
     assert np.abs(out.ranking_logits.numpy() - arrays["ranking_logits"]).max() < TOL
     assert np.abs(out.pruning_logits.numpy() - arrays["pruning_logits"])[m].max() < TOL
     assert len(out.hidden_states) == meta["n_hidden_states"] == dims.num_layers + 1
+    if pre_norm:  # the two conventions really differ on this fixture
+        other = oracle_forward(state, dims, ids, mask, prune_pre_final_norm=False)
+        assert np.abs(other.pruning_logits.numpy() - arrays["pruning_logits"])[m].max() > 0.1
     stride = meta["hidden_stride"]
     if stride:
         for i, h in enumerate(out.hidden_states):
