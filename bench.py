@@ -50,61 +50,93 @@ def algorithmic_flops_per_pair(dims: EncoderDims, seq_len: int) -> float:
     return per_token * L + 2.0 * H * H + 2.0 * H * dims.num_labels
 
 
+def physical_cores() -> int:
+    """Distinct (socket, core) pairs in /proc/cpuinfo (logical CPUs / SMT threads otherwise)."""
+
+    try:
+        seen, phys = set(), None
+        for raw in open("/proc/cpuinfo"):
+            if raw.startswith("physical id"):
+                phys = raw.split(":")[1].strip()
+            elif raw.startswith("core id"):
+                seen.add((phys, raw.split(":")[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
     """The CPU oracle (torch fp32, SDPA attention = what the reference executes on a CPU device) timed on this
-    box's host cores on a bounded sample: batch 32 (the reference's default batch_size) x seq_len."""
+    box's host cores on a bounded sample of the same workload: batch 32 (the reference's default batch_size) x
+    seq_len at the best thread count, plus one pass at batch 256 and a single-thread figure."""
 
     from oracle.modernbert_oracle import oracle_forward
     from open_provence_amd.synthetic import pad_rows
 
-    rows = synth_pair_batch(dims, 32, seq_len, seed=4321)
+    rows = synth_pair_batch(dims, 256, seq_len, seed=4321)
     ids, mask = pad_rows(rows)
     default_threads = torch.get_num_threads()
-    # pick the thread count that serves the CPU best on this box (oversubscription hurts the small GEMMs)
-    best_threads, best_rate = default_threads, 0.0
-    with torch.no_grad():
-        oracle_forward(state, dims, ids[:2], mask[:2], attn="sdpa")  # warm-up
-        for threads in sorted({8, 16, 32, 64, default_threads}):
-            if threads > default_threads:
-                continue
-            torch.set_num_threads(threads)
-            t0 = time.perf_counter()
-            oracle_forward(state, dims, ids[:8], mask[:8], attn="sdpa")
-            rate = 8 / (time.perf_counter() - t0)
-            if rate > best_rate:
-                best_threads, best_rate = threads, rate
-        threads = best_threads
-        torch.set_num_threads(threads)
+    n_phys = physical_cores()
+
+    def timed(batch: int, budget_s: float, max_iters: int) -> tuple[float, int]:
         t0 = time.perf_counter()
         iters = 0
         while True:
-            oracle_forward(state, dims, ids, mask, attn="sdpa")
+            oracle_forward(state, dims, ids[:batch], mask[:batch], attn="sdpa")
             iters += 1
             elapsed = time.perf_counter() - t0
-            if iters >= 3 or elapsed > 20.0:
-                break
+            if iters >= max_iters or elapsed > budget_s:
+                return batch * iters / elapsed, iters
+
+    with torch.no_grad():
+        oracle_forward(state, dims, ids[:2], mask[:2], attn="sdpa")  # warm-up
+        # thread count that serves the CPU best on this box (oversubscription hurts the small GEMMs)
+        best_threads, best_rate = default_threads, 0.0
+        candidates = sorted({t for t in (8, 16, 32, 64, n_phys, default_threads) if 0 < t <= max(default_threads, n_phys)})
+        for threads in candidates:
+            torch.set_num_threads(threads)
+            rate, _ = timed(8, 0.0, 1)
+            if rate > best_rate:
+                best_threads, best_rate = threads, rate
+        torch.set_num_threads(best_threads)
+        rate32, iters32 = timed(32, 10.0, 4)
+        rate256, _ = timed(256, 0.0, 1) if rate32 * 25.0 > 256 else (None, 0)  # one pass, if it fits ~25 s
+        torch.set_num_threads(1)
+        rate1, _ = timed(2, 0.0, 1)
     torch.set_num_threads(default_threads)
     return {
-        "value": 32 * iters / elapsed,
+        "value": rate32,
         "unit": "pairs/s",
-        "cores": threads,
+        "cores": best_threads,
         "kind": "port",
-        "sample": f"oracle/modernbert_oracle.py (torch-CPU fp32, SDPA), {iters} x batch 32 x seq_len {seq_len}, {threads} threads "
-        f"(best of 8/16/32/64/{default_threads} on a batch-8 probe; box has {os.cpu_count()} logical CPUs)",
+        "physical_cores": n_phys,
+        "logical_cpus": os.cpu_count(),
+        "batch_256_pairs_per_s": rate256,
+        "single_thread_pairs_per_s": rate1,
+        "sample": f"oracle/modernbert_oracle.py (torch-CPU fp32, SDPA): {iters32} x batch 32 x seq_len {seq_len} on {best_threads} threads "
+        f"(best of {candidates} on a batch-8 probe), one pass of batch 256 on the same threads, one pass of batch 2 on 1 thread; "
+        f"{n_phys} physical cores / {os.cpu_count()} logical CPUs",
     }
 
 
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=20)
+    parser.add_argument("--steps", type=int, default=100)
     parser.add_argument("--warmup", type=int, default=5)
     parser.add_argument("--pairs", type=int, default=256, help="pairs per GPU")
     parser.add_argument("--seq-len", type=int, default=512)
     parser.add_argument("--model", default="xsmall", choices=["xsmall", "base", "large", "en-gte"])
     parser.add_argument("--precision", default="bf16x3", help="bf16x3 | bf16x2 | bf16 | family=mask,... (see open_provence_amd.engine.parse_precision)")
+    parser.add_argument("--weights", default="bf16", choices=["bf16", "fp32"],
+                        help="dtype of the synthetic checkpoint: bf16 (BASELINE.json configs[1]; what the reference loads on a "
+                        "GPU, standalone.py:219-233) or fp32.  The arithmetic policy is --precision either way; with a bf16 "
+                        "checkpoint the hi x lo(weight) MFMA pass is dropped because that plane is identically zero")
     parser.add_argument("--chunk-rows", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-long", action="store_true", help="skip the seq_len 2048 sub-record")
     parser.add_argument("--varlen", action="store_true",
                         help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
     args = parser.parse_args()
@@ -129,8 +161,11 @@ def main() -> None:
 
     dims = named_dims(args.model)
     state = synth_state_dict(dims, seed=7)
+    if args.weights == "bf16":  # the GEMM weights as a bf16 checkpoint stores them (values exactly representable in bf16)
+        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
     encoder = HipEncoder(dims, device=device, precision=args.precision, chunk_rows=args.chunk_rows or None)
     encoder.load_state_dict(state)
+    policy = encoder.effective_policy()
 
     # 1 query x (pairs * world) contexts; this rank owns a contiguous slice (weak scaling: fixed per-GPU work)
     if args.varlen:  # ragged stress (single GPU): a mixed-length batch of ~pairs*seq_len tokens
@@ -168,11 +203,16 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
+    # per-step device times from events on the launch stream (the library enqueues on torch's current stream)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         out = step()
+    marks[args.steps].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -277,7 +317,9 @@ def main() -> None:
             "seq_len": args.seq_len,
             "global_pairs": n_pairs_rank * world,
             "tokens_per_s": total_tokens * world * args.steps / elapsed,
-            "precision": args.precision + (" (bf16 hi/lo split operands, 3 MFMA passes, fp32 accumulate)" if args.precision == "bf16x3" else " (single-pass bf16 operands, fp32 accumulate)"),
+            "precision": args.precision,
+            "checkpoint_dtype": args.weights,
+            "policy": policy,  # term masks evaluated per contraction family + the kernel set running them
             "parallelism": f"dp{world} (pairs sharded, RCCL gather of per-pair outputs)" if world > 1 else "single GPU",
             "algorithmic_gflop_per_pair": flops_pair / 1e9,
             "outputs_finite": finite,
@@ -285,6 +327,27 @@ def main() -> None:
         "roofline": roofline,
         "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in profile.items()},
     }
+    line["step_ms"] = {"median": float(np.median(step_ms)), "p10": float(np.percentile(step_ms, 10)),
+                       "p90": float(np.percentile(step_ms, 90)), "source": "HIP events on the launch stream, rank 0"}
+    if world == 1 and not args.varlen and args.seq_len != 2048 and not args.no_long:
+        # north_star also asks for seq_len 2048: same model, same token count per step (sub-record, not the headline)
+        long_pairs = max(1, args.pairs * args.seq_len // 2048)
+        rows_l = synth_pair_batch(dims, long_pairs, 2048, seed=1234)
+        ids_l_np, cu_l_np, max_l = pack_rows(rows_l)
+        ids_l, cu_l = torch.from_numpy(ids_l_np).to(device), torch.from_numpy(cu_l_np).to(device)
+        for _ in range(3):
+            encoder.forward_packed(ids_l, cu_l, cu_l_np, max_l)
+        torch.cuda.synchronize(device)
+        long_steps = max(10, args.steps // 4)
+        t1 = time.perf_counter()
+        for _ in range(long_steps):
+            encoder.forward_packed(ids_l, cu_l, cu_l_np, max_l)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t1) / long_steps
+        flops_l = algorithmic_flops_per_pair(dims, 2048)
+        line["seq_len_2048"] = {"value": long_pairs / dt, "unit": "pairs/s", "pairs": long_pairs, "steps": long_steps,
+                                "ms_per_step": dt * 1e3, "algorithmic_gflop_per_pair": flops_l / 1e9,
+                                "whole_forward_frac": long_pairs / dt * flops_l / 1e12 / BF16_MFMA_PEAK_TFLOPS}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dims, state, args.seq_len)
     print(json.dumps(line), flush=True)

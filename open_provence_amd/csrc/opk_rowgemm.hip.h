@@ -99,27 +99,79 @@ __global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, i
 }
 #endif
 
+// ---- hand-placed LDS fragment reads -------------------------------------------------------------------------
+// While a global_load_lds DMA is in flight hipcc (ROCm 7.2) cannot count lgkmcnt: every wait it inserts in front of
+// an MFMA is `s_waitcnt lgkmcnt(0)`, which also waits for the fragment reads issued just before it for the NEXT
+// k-step -- and left to itself it re-uses one register set and puts most ds_read_b128 directly in front of such a
+// wait (~40 % of every wave's cycles were spent there: SQ_WAIT_ANY in profiles/r02*).  So the weight-fragment reads
+// and their waits are inline asm (invisible to the compiler's scoreboard), ordered by data dependencies only:
+//   * volatile asm statements keep their program order among themselves (reads and waits);
+//   * a wait "rewrites" the fragment registers it guards, so the MFMAs that use them cannot move above it;
+//   * a read group "rewrites" one accumulator of the k-step before it, so it cannot sink below that step's MFMAs
+//     (nor can they sink below it): the reads of k-step ks + 1 are in flight during all MFMAs of k-step ks.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_frag(uint32_t lds_addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+// ordered behind the producers (and ahead of the consumers) of the accumulators it "rewrites"
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_frag_after(uint32_t lds_addr, f32x4& p0, f32x4& p1) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %3 offset:%4" : "=v"(v), "+v"(p0), "+v"(p1) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_frag_after(uint32_t lds_addr, f32x4& p0, f32x4& p1, f32x4& p2, f32x4& p3) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %5 offset:%6" : "=v"(v), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait2(bf16x8& a, bf16x8& b) {  // at most N fragment reads still in flight
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
 // One weight chunk (32 output features x K) against this wave's 32 rows: 2 x 2 accumulators, K/32 k-steps of
-// 4 MFMAs per product term.  (hipcc hoists the fragment reads one k-step ahead of their MFMAs by itself; an explicit
-// register double buffer only cost 16 VGPRs.)
-template <int KS, int MF, int T, bool SWAPPED>
-__device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const bf16x8 (&a_hi)[MF][KS],
+// 4 MFMAs per product term, weight fragments two k-steps deep in registers (see above).  `lds_addr` = LDS byte
+// address of this lane's 16 bytes in piece 0 of stage 0; STAGE_BYTES = compile-time offset of the stage to read.
+template <int KS, int MF, int T, bool SWAPPED, int STAGE_BYTES>
+__device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16x8 (&a_hi)[MF][KS],
                                                    const bf16x8 (&a_lo)[MF][KS], f32x4 (&acc)[2][MF]) {
   constexpr bool W_LO = (T & T_RIGHT_LO) != 0, A_LO = (T & T_LEFT_LO) != 0;
   constexpr int PLANES = W_LO ? 2 : 1;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    bf16x8 wh[2], wl[2];
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf) {
-      wh[nf] = lds_frag(stage_lane + (ks * PLANES) * 1024 + nf * 512);
-      wl[nf] = W_LO ? lds_frag(stage_lane + (ks * PLANES + 1) * 1024 + nf * 512) : wh[nf];
+  constexpr int STEP_DS = 2 * PLANES;  // fragment reads per k-step
+  bf16x8 wh[2][2], wl[2][2];           // [register set][fragment]
+  auto read_step = [&](auto ks_tag, auto set_tag, auto pinned_tag) {
+    constexpr int ks = decltype(ks_tag)::value;
+    constexpr int S = decltype(set_tag)::value;
+    constexpr bool PINNED = decltype(pinned_tag)::value;
+    constexpr int base = STAGE_BYTES + (ks * PLANES) * 2048;
+    // the first read of the group is ordered behind every MFMA of the k-step two before it (and ahead of the next's)
+    if (!PINNED) wh[S][0] = lds_read_frag<base>(lds_addr);
+    else if (MF == 2) wh[S][0] = lds_read_frag_after<base>(lds_addr, acc[0][0], acc[0][MF - 1], acc[1][0], acc[1][MF - 1]);
+    else wh[S][0] = lds_read_frag_after<base>(lds_addr, acc[0][0], acc[1][0]);
+    wh[S][1] = lds_read_frag<base + 1024>(lds_addr);
+    if (W_LO) {
+      wl[S][0] = lds_read_frag<base + 2048>(lds_addr);
+      wl[S][1] = lds_read_frag<base + 2048 + 1024>(lds_addr);
     }
+  };
+  auto wait_step = [&](auto set_tag, auto last_tag) {
+    constexpr int S = decltype(set_tag)::value;
+    constexpr int N = decltype(last_tag)::value ? 0 : STEP_DS;  // the next k-step's reads may stay in flight
+    if (W_LO) lds_wait4<N>(wh[S][0], wh[S][1], wl[S][0], wl[S][1]);
+    else lds_wait2<N>(wh[S][0], wh[S][1]);
+  };
+  auto mfma_step = [&](int ks, auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
     // The product terms are issued term-major over the four accumulators: an accumulator is touched every
-    // fourth MFMA, so no MFMA waits for the result of the previous one (back-to-back MFMAs on one accumulator
-    // stall on the read-after-write).  (A unit-major software pipeline that prefetches the next (k-step, 16-feature)
-    // fragment pair during six MFMAs measured the same: the fragment-read latency is already covered by the
-    // partner wave on the SIMD.)
+    // fourth MFMA, so no MFMA waits for the result of the previous one.
 #pragma unroll
     for (int term = 0; term < 3; ++term) {
       if ((term == 0 && !W_LO) || (term == 1 && !A_LO)) continue;
@@ -127,13 +179,46 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(const u16* stage_lane, const 
       for (int nf = 0; nf < 2; ++nf) {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-          const bf16x8 w = term == 0 ? wl[nf] : wh[nf];
+          const bf16x8 w = term == 0 ? wl[S][nf] : wh[S][nf];
           const bf16x8 a = term == 1 ? a_lo[mf][ks] : a_hi[mf][ks];
           acc[nf][mf] = SWAPPED ? mfma16(w, a, acc[nf][mf]) : mfma16(a, w, acc[nf][mf]);
         }
       }
     }
+  };
+  static_assert(KS == 4 || KS == 8, "k-steps are unrolled by hand below");
+  const std::integral_constant<int, 0> s0{};
+  const std::integral_constant<int, 1> s1{};
+  const std::true_type yes{};
+  const std::false_type no{};
+#define OPK_KS(n) std::integral_constant<int, n>{}
+  read_step(OPK_KS(0), s0, no);
+  read_step(OPK_KS(1), s1, no);
+  wait_step(s0, no);
+  mfma_step(0, s0);
+  read_step(OPK_KS(2), s0, yes);
+  wait_step(s1, no);
+  mfma_step(1, s1);
+  read_step(OPK_KS(3), s1, yes);
+  wait_step(s0, no);
+  mfma_step(2, s0);
+  if (KS == 8) {
+    read_step(OPK_KS(4 % KS), s0, yes);
+    wait_step(s1, no);
+    mfma_step(3, s1);
+    read_step(OPK_KS(5 % KS), s1, yes);
+    wait_step(s0, no);
+    mfma_step(4 % KS, s0);
+    read_step(OPK_KS(6 % KS), s0, yes);
+    wait_step(s1, no);
+    mfma_step(5 % KS, s1);
+    read_step(OPK_KS(7 % KS), s1, yes);
+    wait_step(s0, no);
+    mfma_step(6 % KS, s0);
   }
+  wait_step(s1, yes);
+  mfma_step(KS - 1, s1);
+#undef OPK_KS
 }
 
 // T2 = term mask of the chunk loop's GEMM (left = this block's rows, right = the streamed weight), T1 = term mask of
@@ -382,14 +467,21 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
     }
   }
   // Numerics of a narrower policy on this (wider) instantiation: the lo fragments of the in-register operand are
-  // cleared once, so their product term adds exact zeros (bit-identical to the kernel that omits the term).
-  if (A_LO && PRO != RP_PLANES && p.zero_a_lo) {
+  // ANDed with a launch-constant mask (all ones, or zero: their product term then adds exact zeros, bit-identical to
+  // the kernel that omits the term).  Straight-line on purpose: a branch here makes the compiler keep two copies of
+  // the 64 fragment registers and spill.
+  if (A_LO && PRO != RP_PLANES) {
+    const unsigned keep = p.zero_a_lo ? 0u : 0xffffffffu;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) a_lo[mf][ks] = as_frag(make_uint4(0u, 0u, 0u, 0u));
+      for (int ks = 0; ks < KS; ++ks) {
+        FragU f;
+        f.v = a_lo[mf][ks];
+        f.u = make_uint4(f.u.x & keep, f.u.y & keep, f.u.z & keep, f.u.w & keep);
+        a_lo[mf][ks] = f.v;
+      }
   }
-
   // RE_QKV: RoPE rows of this lane's tokens: cos/sin [pos][8g + 4j .. +3] for the half-head j of the chunk whose
   // (deferred) epilogue runs in this iteration are fetched at the top of the iteration, before the DMA is issued.
   const float* rope_c_row[MF];
@@ -534,6 +626,8 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
   for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // LDS byte address of this lane's 16 bytes in piece 0 of stage 0 (the hand-placed fragment reads add immediates)
+  const uint32_t lds_lane = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) u16*)&sW[0][0]) + (uint32_t)lane * 16u;
 
   // Unrolled by two so that the LDS stage index is a compile-time constant in each copy: the compiler can
   // then tell the DMA into stage cur^1 from the fragment reads of stage cur and does NOT drain the DMA
@@ -556,7 +650,9 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
       }
     }
     stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
-    if (EPI == RE_QKV) __builtin_amdgcn_sched_barrier(0);  // keep those loads up here, ahead of the DMA's wait
+    // Nothing crosses this point: the RoPE loads stay ahead of the DMA, and the epilogue's stores stay BEHIND it --
+    // the counted wait in front of the barrier below relies on that order.
+    __builtin_amdgcn_sched_barrier(0);
     if (!FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag, acc_prev);
 
     f32x4 acc[2][MF];
@@ -564,7 +660,7 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rowgemm_chunk_mfma<KS, MF, T2, SW>(&sW[cur][lane * 8], a_hi, a_lo, acc);
+    rowgemm_chunk_mfma<KS, MF, T2, SW, cur * STAGE_ALLOC * 2>(lds_lane, a_hi, a_lo, acc);
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -577,18 +673,26 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
       // phase while its partner waits for the same port; the lever that pays is fewer epilogue instructions.
       constexpr int NT = term_count(T2);
       constexpr int N_MFMA = KS * 2 * MF * NT;
-      constexpr int N_DS = KS * 2 * PLANES;
-      constexpr int DS_LATE = N_DS - 2 * PLANES;  // reads placed between the MFMAs, spread evenly
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * PLANES, 0);
+      constexpr int VALU_PER_MFMA = NT == 3 ? 2 : (NT == 2 ? 3 : 5);
 #pragma unroll
       for (int i = 0; i < N_MFMA; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, NT == 3 ? 2 : (NT == 2 ? 3 : 5), 0);
-        if (((i + 1) * DS_LATE) / N_MFMA - (i * DS_LATE) / N_MFMA == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (((i + 1) * DS_LATE) / N_MFMA - (i * DS_LATE) / N_MFMA == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
       }
     }
-    __syncthreads();
+    // End of the iteration: this wave's share of the next chunk must have landed in LDS, then all waves meet.
+    // vmcnt retires in order, so waiting until only the N_STORES epilogue stores issued AFTER the DMA may still be
+    // in flight covers the DMA without waiting for the stores' write acknowledgements (a __syncthreads() here is
+    // fence + barrier = vmcnt(0): every iteration would wait for its own stores to reach L2).  Every fragment read
+    // of stage `cur` has already returned (its MFMAs were issued), so the raw barrier is enough for the stage reuse.
+    constexpr int PPREV = cur ^ 1;
+    constexpr int N_STORES =
+        FIRST ? 0
+        : EPI == RE_GEGLU ? (PPREV == 1 ? MF * (1 + (O0_LO ? 1 : 0)) : 0)
+        : EPI == RE_QKV ? (SWP ? (PPREV == 1 ? MF * (2 + ((O0_LO && O1_LO) ? 2 : 0)) : 0) : 2 * (1 + (O2_LO ? 1 : 0)))
+                        : 0;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
+    __builtin_amdgcn_s_barrier();
   };
   // Even chunk counts on both sides of the q/k -> v boundary (checked on the host).  The first pair is peeled so
   // that the deferred epilogue is unconditional in the steady-state loops.

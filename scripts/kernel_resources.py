@@ -9,13 +9,19 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-SRC = ROOT / "open_provence_amd" / "csrc" / "op_api.hip"
+CSRC = ROOT / "open_provence_amd" / "csrc"
 
 
 def main() -> None:
-    pattern = sys.argv[1] if len(sys.argv) > 1 else ""
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-           "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/op_resources.o", str(SRC)]
+    """usage: kernel_resources.py <unit: api|row0|row1|row2|attn|panel> [name filter]"""
+
+    unit = sys.argv[1] if len(sys.argv) > 1 else "attn"
+    pattern = sys.argv[2] if len(sys.argv) > 2 else ""
+    src, defines = {"api": ("op_api.hip", []), "attn": ("op_launch_attn.hip", []), "panel": ("op_launch_panel.hip", []),
+                    "row0": ("op_launch_row.hip", ["-DOPL_ROW_PART=0"]), "row1": ("op_launch_row.hip", ["-DOPL_ROW_PART=1"]),
+                    "row2": ("op_launch_row.hip", ["-DOPL_ROW_PART=2"])}[unit]
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", *defines,
+           "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/op_resources.o", str(CSRC / src)]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp").stderr
     rows, cur = [], None
     for line in out.splitlines():

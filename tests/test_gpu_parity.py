@@ -46,21 +46,27 @@ def test_chunking_does_not_change_results(chunk_rows):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16x2", {"qk": 2, "pv": 1, "wi": 2}])
-def test_generic_tiled_kernels_agree(precision, monkeypatch):
+def test_generic_tiled_kernels_agree(precision):
     """Three GEMM families exist: row-stationary fused kernels (hidden <= 256, default), k-streamed panel kernels
     (hidden % 256 == 0: base / large / en-gte; the H=768 fixture takes them by default) and the generic 128x128
     tiles (any other shape; forced here through OP_FLAG_FORCE_TILED).  The tiled kernels must give the same answers
-    as the defaults: within the bar for bf16x3, and for a narrower policy within 1e-4 of that policy's result on the
-    default kernels (same arithmetic, different accumulation order)."""
+    as the defaults: within the bar for bf16x3; for bf16x2 (weights rounded to bf16 -- a deterministic rounding of
+    static data) within 3e-4 of the default kernels (same arithmetic, different accumulation order).  A policy that
+    drops an ACTIVATION's lo plane is not comparable across kernel families (an fp32 difference of one ulp upstream
+    flips bf16 roundings that nothing compensates any more): there only the error band against the reference is
+    checked."""
 
     for name in ["g1_xsmall", "g0c_hd64_synth", "g2_gte_varlen"]:
         tiled = run_fixture_on_gpu(name, precision, flags=1, capture=False, return_outputs=True)
         assert tiled["finite"]
         if precision == "bf16x3":
             assert tiled["prune_max_err"] < TOL and tiled["rank_max_err"] < TOL, tiled
-        else:
-            default = run_fixture_on_gpu(name, precision, capture=False, return_outputs=True)
-            assert tiled["terms"] == default["terms"]
+            continue
+        default = run_fixture_on_gpu(name, precision, capture=False, return_outputs=True)
+        assert tiled["terms"] == default["terms"]
+        if precision == "bf16x2":
             scale = max(1.0, float(np.abs(default["prune"]).max()))
             assert np.abs(tiled["prune"] - default["prune"]).max() < 3e-4 * scale, (name, precision)
             assert np.abs(tiled["rank"] - default["rank"]).max() < 3e-4 * scale, (name, precision)
+        else:
+            assert tiled["prune_max_err"] < 0.3 and default["prune_max_err"] < 0.3, (tiled["prune_max_err"], default["prune_max_err"])
