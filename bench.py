@@ -260,6 +260,8 @@ def main() -> None:
         "fused_attnout_ln_wi_geglu": 2.0 * total_tokens * (H * H + H * 2 * I) * n_layers,
         "fused_mlpout_ln_qkv_rope": 2.0 * total_tokens * (I * H + H * 3 * H) * (n_layers - 1),
         "kstream_mlp_out": 2.0 * total_tokens * I * H,
+        # whole-layer kernel: attention output projection + MLP in every layer, + the next layer's q/k/v in all but the last
+        "fused_layer_attnout_mlp_qkv": 2.0 * total_tokens * ((H * H + 3 * H * I) * n_layers + 3 * H * H * (n_layers - 1)),
         "rowgemm_ln_qkv_rope": 2.0 * total_tokens * H * 3 * H * n_layers,
         "rowgemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
         "rowgemm_ln_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,

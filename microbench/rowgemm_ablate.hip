@@ -1,0 +1,162 @@
+// Measurement aid (not product code): times the REAL fused kernel x += o Wo^T ; h = GeGLU(LN(x) Wi^T)
+// (rowgemm_kernel<8, RE_GEGLU, RP_KSTREAM, T1, T2, 1, 4, 2> of open_provence_amd/csrc/opk_rowgemm.hip.h) at the bench
+// size (131072 rows, H = 256, I = 1024) on random finite data.  Built once per ablation switch of that header
+// (scripts/ablate_rowgemm.sh), each binary prints the kernel's average time: the differences price the components
+// of the chunk loop.  Results of ablated builds are numerically meaningless by design.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize [-DOPK_ABL_...] -DABL_T=1 -o x rowgemm_ablate.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+
+#include "../open_provence_amd/csrc/opk_rowgemm.hip.h"
+
+#ifndef ABL_T
+#define ABL_T 1
+#endif
+#ifndef ABL_NAME
+#define ABL_NAME "baseline"
+#endif
+
+#define CHECK(x)                                                       \
+  do {                                                                 \
+    hipError_t e_ = (x);                                               \
+    if (e_ != hipSuccess) {                                            \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));          \
+      exit(1);                                                         \
+    }                                                                  \
+  } while (0)
+
+using namespace opk;
+
+static void fill_bf16(std::vector<u16>& v, unsigned seed, float scale) {
+  unsigned s = seed * 2654435761u + 12345u;
+  for (auto& x : v) {
+    s = s * 1664525u + 1013904223u;
+    const float f = ((int)(s >> 9) / 8388608.0f - 0.5f) * 2.0f * scale;  // uniform in [-scale, scale)
+    unsigned u;
+    memcpy(&u, &f, 4);
+    x = (u16)(u >> 16);
+  }
+}
+
+int main() {
+  const int R = 131072, H = 256, I = 1024, KS = 8;
+  std::vector<u16> o((size_t)R * H * 2), wo((size_t)H * H * 2), wi((size_t)2 * I * H * 2);
+  std::vector<float> x((size_t)R * H), lnw(H, 1.0f);
+  fill_bf16(o, 1, 1.0f);
+  fill_bf16(wo, 2, 0.06f);
+  fill_bf16(wi, 3, 0.06f);
+  {
+    unsigned s = 77;
+    for (auto& v : x) {
+      s = s * 1664525u + 1013904223u;
+      v = ((int)(s >> 9) / 8388608.0f - 0.5f) * 4.0f;
+    }
+  }
+  u16 *d_o, *d_wo, *d_wi, *d_h;
+  float *d_x, *d_ln;
+  CHECK(hipMalloc(&d_o, o.size() * 2));
+  CHECK(hipMalloc(&d_wo, wo.size() * 2));
+  CHECK(hipMalloc(&d_wi, wi.size() * 2));
+  CHECK(hipMalloc(&d_h, (size_t)R * I * 2 * 2));
+  CHECK(hipMalloc(&d_x, x.size() * 4));
+  CHECK(hipMalloc(&d_ln, H * 4));
+  CHECK(hipMemcpy(d_o, o.data(), o.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_wo, wo.data(), wo.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_wi, wi.data(), wi.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_ln, lnw.data(), H * 4, hipMemcpyHostToDevice));
+
+  RowGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.eps = 1e-5f;
+  p.hidden = H;
+  p.r_pad = R;
+  p.ln_w = d_ln;
+  p.wp = d_wi;
+  p.n_chunks = 2 * I / ROW_CHUNK;
+  p.o0_hi = d_h;
+  p.ld_out = I;
+  p.a1_fp = d_o;
+  p.w1p = d_wo;
+  p.k1_steps = H / 32;
+  p.x_io = d_x;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+#ifdef ABL_LAYER
+  // whole-layer kernel: attention output projection + MLP (+ next q/k/v projection when ABL_LAYER == 2)
+  std::vector<u16> wo2((size_t)H * I * 2), wqkv((size_t)3 * H * H * 2);
+  fill_bf16(wo2, 4, 0.03f);
+  fill_bf16(wqkv, 5, 0.06f);
+  u16 *d_wo2, *d_wqkv, *d_q, *d_k, *d_v;
+  float *d_cos, *d_sin;
+  int32_t* d_pos;
+  CHECK(hipMalloc(&d_wo2, wo2.size() * 2));
+  CHECK(hipMalloc(&d_wqkv, wqkv.size() * 2));
+  CHECK(hipMalloc(&d_q, (size_t)R * H * 4));
+  CHECK(hipMalloc(&d_k, (size_t)R * H * 4));
+  CHECK(hipMalloc(&d_v, (size_t)R * H * 4));
+  CHECK(hipMalloc(&d_cos, 8192 * 32 * 4));
+  CHECK(hipMalloc(&d_sin, 8192 * 32 * 4));
+  CHECK(hipMalloc(&d_pos, R * 4));
+  CHECK(hipMemcpy(d_wo2, wo2.data(), wo2.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_wqkv, wqkv.data(), wqkv.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemset(d_cos, 0, 8192 * 32 * 4));
+  CHECK(hipMemset(d_sin, 0, 8192 * 32 * 4));
+  {
+    std::vector<int32_t> pos(R);
+    for (int i = 0; i < R; ++i) pos[i] = i % 512;
+    CHECK(hipMemcpy(d_pos, pos.data(), R * 4, hipMemcpyHostToDevice));
+  }
+  p.ln_w_mlp = d_ln;
+  p.wi_pk = d_wi;
+  p.wo2_ks = d_wo2;
+  p.n_pairs = I / 32;
+  p.wp = d_wqkv;
+  p.n_chunks = 3 * H / ROW_CHUNK;
+  p.n_swapped = 2 * H / ROW_CHUNK;
+  p.o0_hi = d_q;
+  p.o1_hi = d_k;
+  p.o2_hi = d_v;
+  p.ld_out = H;
+  p.row_pos = d_pos;
+  p.rope_cos = d_cos;
+  p.rope_sin = d_sin;
+  p.max_pos = 8192;
+  auto launch = [&]() {
+    if (ABL_LAYER == 2)
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, ABL_T, ABL_T, 7, 4, 2, ABL_T, ABL_T>), dim3(R / 128), dim3(256), 0, 0, p);
+    else
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, ABL_T, 0, 0, 4, 2, ABL_T, ABL_T>), dim3(R / 128), dim3(256), 0, 0, p);
+  };
+#else
+  auto launch = [&]() {
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_GEGLU, RP_KSTREAM, ABL_T, ABL_T, 1, 4, 2>), dim3(R / 128), dim3(256), 0, 0, p);
+  };
+#endif
+  for (int i = 0; i < 5; ++i) {
+    CHECK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));  // keep the residual stream bounded
+    launch();
+  }
+  CHECK(hipDeviceSynchronize());
+  float best = 1e9f, sum = 0.f;
+  const int reps = 10;
+  for (int i = 0; i < reps; ++i) {
+    CHECK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipEventRecord(e0));
+    launch();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+    sum += ms;
+  }
+  CHECK(hipGetLastError());
+  printf("%-22s terms=%d  avg %.1f us  best %.1f us\n", ABL_NAME, ABL_T, sum / reps * 1e3f, best * 1e3f);
+  return 0;
+}

@@ -47,6 +47,7 @@ enum ProfileKind {
   PK_FUSED_ATTN_OUT_WI,
   PK_FUSED_MLP_OUT_QKV,
   PK_CLEAR_LO,
+  PK_FUSED_LAYER,
   PK_COUNT
 };
 const char* kProfileNames[PK_COUNT] = {"rowmap",        "embed_ln",      "layer_norm",    "gemm_qk_rope", "gemm_v_t",
@@ -54,7 +55,7 @@ const char* kProfileNames[PK_COUNT] = {"rowmap",        "embed_ln",      "layer_
                                        "gemm_mlp_out",  "final_ln_prune", "rank_head",    "capture",
                                        "rowgemm_ln_qkv_rope", "rowgemm_attn_out", "rowgemm_ln_wi_geglu",
                                        "kstream_mlp_out", "fused_attnout_ln_wi_geglu", "fused_mlpout_ln_qkv_rope",
-                                       "clear_lo_planes"};
+                                       "clear_lo_planes", "fused_layer_attnout_mlp_qkv"};
 
 struct LayerWeights {
   float* attn_norm = nullptr;  // absent on layer 0
@@ -64,7 +65,7 @@ struct LayerWeights {
   u16 *wi_hi = nullptr, *wi_lo = nullptr;
   u16 *wo2_hi = nullptr, *wo2_lo = nullptr;
   // row-stationary layouts (hidden <= 256): chunk-major, fragment-ordered, hi/lo planes interleaved per k-step
-  u16 *wqkv_pk = nullptr, *wo_pk = nullptr, *wi_pk = nullptr;
+  u16 *wqkv_pk = nullptr, *wi_pk = nullptr;
   u16* wo2_pk = nullptr;  // k-streamed layouts (output features permuted): MLP output projection ...
   u16* wo_ks = nullptr;   // ... and attention output projection (fused kernels)
 };
@@ -445,6 +446,9 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   const bool small_blocks = (r_pad / ROW_BM) <= h->n_cus && !(h->cfg.flags & OP_FLAG_NO_SMALL_BLOCKS);
   const unsigned row_grid = (unsigned)(r_pad / (small_blocks ? 64 : ROW_BM));
   const char* no_kernel = "internal: no row-stationary kernel for hidden %d";
+  // Kernel sets whose GEMM weights are single-plane run a whole layer (attention output projection, MLP, next q/k/v
+  // projection) as ONE kernel with h kept on chip; the all-terms set keeps the two fused kernels per layer.
+  const bool layer_fused = h->row_path && !h->emulate && opl::has_row_layer_fused(h->pi) && !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION);
 
   for (int li = 0; li < h->N; ++li) {
     const LayerWeights& lw = h->layers[li];
@@ -461,6 +465,26 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         OP_TRY(clear_qkv());
       }  // else: q/k/v of this layer were produced by the fused kernel that closed layer li-1
       OP_TRY(attention(is_global));
+
+      if (layer_fused) {
+        // x += o Wo^T ; x += GeGLU(LN(x) Wi^T) Wo^T ; q, k, v^T of the NEXT layer -- one kernel, h stays on chip
+        const bool with_qkv = li + 1 < h->N;
+        RowGemmParams rl = qkv_params(with_qkv ? li + 1 : li);
+        rl.a1_fp = ws.o_hi;
+        rl.w1p = lw.wo_ks;
+        rl.k1_steps = H / 32;
+        rl.x_io = ws.x;
+        rl.ln_w_mlp = lw.mlp_norm;
+        rl.wi_pk = lw.wi_pk;
+        rl.wo2_ks = lw.wo2_pk;
+        rl.n_pairs = I / 32;
+        OP_TRY(L.begin(PK_FUSED_LAYER));
+        if (!opl::launch_row_layer_fused(st, rl, H / 32, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM),
+                                         (h->cfg.flags & OP_FLAG_LAYER_8X16) != 0 || (opl::kPolicies[h->pi].wi & 1) == 0))
+          return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+        OP_TRY(L.end());
+        continue;
+      }
 
       // x += o Wo^T ; h = GeGLU(LN(x) Wi^T)   -- one kernel, the hidden state stays in registers in between
       RowGemmParams rp;
@@ -813,7 +837,6 @@ int op_create(const op_config* cfg, op_handle** out) {
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_lo, (size_t)H * I));
     } else {  // fragment-ordered layouts (hi and lo planes interleaved): chunk-major (row path) or panel-major
       OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_pk, 2 * 3 * HH));
-      if (h->row_path) OP_CREATE_TRY(dev_alloc(h, &lw.wo_pk, 2 * HH));
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
@@ -906,7 +929,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       dst_pk = lw.wqkv_pk; pk_mode = RE_QKV; family = OP_FAM_WQKV;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
-      dst_pk = lw.wo_pk; pk_mode = RE_RESIDUAL; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
+      dst_pk = nullptr; pk_mode = 101; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
       dst_pk = lw.wi_pk; pk_mode = RE_GEGLU; family = OP_FAM_WI;
@@ -974,7 +997,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     if (pk_mode == RE_QKV) {
       pack(2 * H / 256, PE_QK, dst_pk);
       pack(H / 256, PE_V, dst_pk + (size_t)(2 * H / 256) * (K / 32) * 2 * 8192);
-    } else if (pk_mode == RE_RESIDUAL) {
+    } else if (pk_mode == 101) {
       pack(H / 256, PE_RESIDUAL, dst_ks);  // attention output projection
     } else if (pk_mode == RE_GEGLU) {
       pack(I / 128, PE_GEGLU, dst_pk);
@@ -982,10 +1005,10 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       pack(H / 256, PE_RESIDUAL, dst_pk);  // MLP output projection
     }
   }
-  if (dst_pk && h->row_path) {
-    if (pk_mode == 100)
+  if ((dst_pk || dst_ks) && h->row_path) {
+    if (dst_pk && pk_mode == 100)
       hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_pk, zero_lo, any_lo);
-    else
+    else if (dst_pk)
       hipLaunchKernelGGL(pack_rowgemm_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_pk,
                          zero_lo, any_lo);
     if (dst_ks)

@@ -47,6 +47,10 @@ bool launch_row_qkv0(hipStream_t st, const opk::RowGemmParams& p, int ks, bool s
 bool launch_row_geglu_fused(hipStream_t st, const opk::RowGemmParams& p, int ks, bool small, int pi, unsigned grid);
 bool launch_row_qkv_fused(hipStream_t st, const opk::RowGemmParams& p, int ks, bool small, int pi, unsigned grid);
 bool launch_kstream(hipStream_t st, const opk::KStreamParams& p, int nf, int pi, unsigned grid);
+// one kernel per layer: x += o Wo^T; x += GeGLU(LN(x) Wi^T) Wo^T; (with_qkv) next layer's q / k / v^T.  128-row blocks.
+bool has_row_layer_fused(int pi);
+bool launch_row_layer_fused(hipStream_t st, const opk::RowGemmParams& p, int ks, int pi, bool with_qkv, unsigned grid,
+                            bool waves8);
 // waves x kt: (8, 2) and (4, 2) full attention / long and short sequences, (4, 1) sliding window.
 // zero_p_lo (pi == 0 only): the policy has no lo(p) x hi(v) term.
 bool launch_attn(hipStream_t st, const opk::AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid);

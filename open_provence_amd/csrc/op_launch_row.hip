@@ -77,4 +77,46 @@ bool launch_kstream(hipStream_t st, const KStreamParams& p, int nf, int pi, unsi
 }
 #endif
 
+#if OPL_ROW_PART == 3
+// Whole-layer kernel (attention output projection + MLP + next layer's q/k/v projection, h kept on chip): kernel sets
+// whose weights are single-plane only (bf16 checkpoints / bf16x2 / bf16), 4 waves x 32 rows per block, one block per CU.
+namespace {
+template <int PI, int KS>
+bool launch_layer_ks(hipStream_t st, const RowGemmParams& p, bool with_qkv, unsigned grid, bool waves8) {
+  constexpr Policy P = kPolicies[PI];
+  if constexpr ((P.wi & 2) != 0 || (P.mlp_out & 2) != 0) {
+    return false;
+  } else {
+    if (waves8 && with_qkv)
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, P.attn_out, P.wqkv, qkv_olo(P), 8, 1, P.wi, P.mlp_out>), dim3(grid),
+                         dim3(512), 0, st, p);
+    else if (waves8)
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, P.attn_out, 0, 0, 8, 1, P.wi, P.mlp_out>), dim3(grid), dim3(512), 0,
+                         st, p);
+    else if (with_qkv)
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, P.attn_out, P.wqkv, qkv_olo(P), 4, 2, P.wi, P.mlp_out>), dim3(grid),
+                         dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, P.attn_out, 0, 0, 4, 2, P.wi, P.mlp_out>), dim3(grid), dim3(256), 0,
+                         st, p);
+    return true;
+  }
+}
+template <int PI>
+bool launch_layer_pi(hipStream_t st, const RowGemmParams& p, int ks, bool with_qkv, unsigned grid, bool waves8) {
+  if (ks == 8) return launch_layer_ks<PI, 8>(st, p, with_qkv, grid, waves8);
+  if (ks == 4) return launch_layer_ks<PI, 4>(st, p, with_qkv, grid, waves8);
+  return false;
+}
+}  // namespace
+
+bool has_row_layer_fused(int pi) { return pi >= 0 && pi < N_POLICIES && (kPolicies[pi].wi & 2) == 0 && (kPolicies[pi].mlp_out & 2) == 0; }
+
+bool launch_row_layer_fused(hipStream_t st, const RowGemmParams& p, int ks, int pi, bool with_qkv, unsigned grid, bool waves8) {
+#define OPL_CALL(PI) (launch_layer_pi<PI>(st, p, ks, with_qkv, grid, waves8))
+  OPL_SWITCH(OPL_CALL)
+#undef OPL_CALL
+}
+#endif
+
 }  // namespace opl

@@ -90,6 +90,12 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 x, bf16x8 y, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
 }
 
+// RoPE pair (HF :188-219: x cos + rotate_half(x) sin) with the fused multiply-adds written out: left to -ffp-contract
+// the compiler picks which product of `x1 c - x2 s` it fuses per instantiation, and the 16-row and 32-row variants of
+// one kernel then differ in the last bit of q / k -- results must not depend on the batch size that selects them.
+__device__ __forceinline__ float rope_lo(float x1, float x2, float c, float s) { return __fmaf_rn(x1, c, -__fmul_rn(x2, s)); }
+__device__ __forceinline__ float rope_hi(float x1, float x2, float c, float s) { return __fmaf_rn(x2, c, __fmul_rn(x1, s)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -114,8 +120,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaf(-he, ax, __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()));
 }
 
-enum RowEpilogue { RE_QKV = 0, RE_RESIDUAL = 1, RE_GEGLU = 2 };
-enum RowPrologue { RP_LN = 0, RP_SPLIT = 1, RP_PLANES = 2, RP_KSTREAM = 3 };
+// rowgemm_kernel epilogues: q/k/v projection (RoPE, fragment-packed q, k, v^T), GeGLU (fragment-packed h), or no chunk
+// loop at all (RE_NONE: the fused layer kernel of the LAST layer only updates the residual stream); and prologues:
+// plain split of x (layer 0), one fused k-streamed GEMM + residual + LayerNorm (RP_KSTREAM), or the whole
+// attention-output projection + MLP of a layer with h kept on chip (RP_MLP).
+enum RowEpilogue { RE_QKV = 0, RE_NONE = 1, RE_GEGLU = 2 };
+enum RowPrologue { RP_SPLIT = 1, RP_KSTREAM = 3, RP_MLP = 4 };
 constexpr int ROW_BM = 128;
 constexpr int ROW_CHUNK = 32;  // output features per streamed chunk
 enum PanelEpi { PE_RESIDUAL = 0, PE_QK = 1, PE_V = 2, PE_GEGLU = 3 };

@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float x1 = acc[4 * hh + u][mf][r], x2 = acc[4 * hh + 2 + u][mf][r];
-            lo_half[4 * u + r] = (x1 * c4[u][r] - x2 * s4[u][r]) * qscale;
-            hi_half[4 * u + r] = (x2 * c4[u][r] + x1 * s4[u][r]) * qscale;
+            lo_half[4 * u + r] = rope_lo(x1, x2, c4[u][r], s4[u][r]) * qscale;
+            hi_half[4 * u + r] = rope_hi(x1, x2, c4[u][r], s4[u][r]) * qscale;
           }
         bf16x8 h0, l0, h1, l1;
         pack8<(O0_LO || O1_LO)>(lo_half, h0, l0);

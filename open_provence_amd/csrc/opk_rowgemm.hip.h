@@ -2,9 +2,15 @@
 #pragma once
 
 #include <type_traits>
+#include <utility>
 
 #include "opk_common.hip.h"
 
+// Measurement-only switches (microbench/rowgemm_ablate.hip compiles this header with one of them defined to price a
+// component of the chunk loop; results are wrong with any of them set, the library never defines them):
+//   OPK_ABL_NO_BARRIER   no block barrier per chunk        OPK_ABL_NO_STORE   epilogue stores dropped
+//   OPK_ABL_NO_GELU      GELU replaced by the identity     OPK_ABL_NO_DMA     no weight DMA inside the loop
+//   OPK_ABL_NO_EPILOGUE  the deferred epilogue is skipped  OPK_ABL_NO_PHASE1  phase 1 (x += A1 W1^T) skipped
 namespace opk {
 
 // ----------------------------------------------------------------------------------------------
@@ -21,35 +27,34 @@ namespace opk {
 // ----------------------------------------------------------------------------------------------
 
 struct RowGemmParams {
-  const float* x_in;  // RP_LN / RP_SPLIT: fp32 [r_pad][K]
-  const float* ln_w;  // RP_LN
+  const float* x_in;  // RP_SPLIT: fp32 [r_pad][K]
+  const float* ln_w;  // LayerNorm weight in front of the chunk loop (RP_KSTREAM, RP_MLP)
   float eps;
-  const u16* a_hi;  // RP_PLANES: planes [r_pad][K]
-  const u16* a_lo;
-  const u16* wp;  // packed weights, n_chunks x (K/32) x 2 planes x 2 frags x 512 elements
+  const u16* wp;  // packed weights of the chunk loop, n_chunks x (K/32) x 2 planes x 2 frags x 512 elements
   int n_chunks;
   int n_swapped;  // RE_QKV: chunks [0, n_swapped) are q/k (RoPE), the rest v (transposed store)
-  float* x;       // RE_RESIDUAL: fp32 [r_pad][ld_out], updated in place
-  u16* o0_hi;     // RE_QKV: q   RE_GEGLU: h
-  u16* o0_lo;
-  u16* o1_hi;  // RE_QKV: k
-  u16* o1_lo;
-  u16* o2_hi;  // RE_QKV: v^T [H][r_pad]
-  u16* o2_lo;
-  int ld_out;  // RE_RESIDUAL: H   RE_GEGLU: I   RE_QKV: H
+  u16* o0_hi;     // RE_QKV: q   RE_GEGLU: h      (fragment-packed, hi / lo planes interleaved per piece)
+  u16* o1_hi;     // RE_QKV: k
+  u16* o2_hi;     // RE_QKV: v^T pieces [head][r_pad/32][plane][4][512]
+  int ld_out;     // RE_GEGLU: I   RE_QKV: H
   int hidden;
   int r_pad;
   const int32_t* row_pos;
   const float* rope_cos;
   const float* rope_sin;
   int max_pos;
-  // RP_KSTREAM (fused block): x_new = x + A1 W1^T first, A1 fragment-packed [r_pad/16][k1_steps][2][512], W1 packed
-  // by pack_kstream_kernel with permuted output features; then LayerNorm(x_new) feeds the chunk loop.
+  // RP_KSTREAM / RP_MLP: x_new = x + A1 W1^T first, A1 fragment-packed [r_pad/16][k1_steps][2][512], W1 packed
+  // by pack_kstream_kernel with permuted output features; then LayerNorm(x_new) feeds the next GEMM.
   const u16* a1_fp;
   const u16* w1p;
   int k1_steps;
   float* x_io;
   int zero_a_lo;  // clear the lo fragments of the in-register (LayerNorm / split) operand: see rowgemm_kernel
+  // RP_MLP: the whole MLP between phase 1 and the chunk loop, h kept on chip
+  const float* ln_w_mlp;  // this layer's mlp_norm weight (ln_w is then the NEXT layer's attn_norm)
+  const u16* wi_pk;       // Wi, chunk-major pack (as wp of the RE_GEGLU kernel)
+  const u16* wo2_ks;      // MLP Wo, k-streamed pack (as w1p of the RE_QKV / RP_KSTREAM kernel)
+  int n_pairs;            // intermediate / 32 (even)
 };
 
 // source row of packed row `pr` (0..31) of chunk `c`
@@ -115,17 +120,23 @@ __device__ __forceinline__ bf16x8 lds_read_frag(uint32_t lds_addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
   return v;
 }
-// ordered behind the producers (and ahead of the consumers) of the accumulators it "rewrites"
-template <int OFF>
+// ordered behind the producers (and ahead of the consumers) of the accumulators it "rewrites".  IN_AGPR: the
+// one-wave-per-SIMD kernels (512-register budget) get their MFMA accumulators in AGPRs; a "v" constraint there makes
+// the compiler copy them to VGPRs and back around every read group.
+template <int OFF, bool IN_AGPR = false>
 __device__ __forceinline__ bf16x8 lds_read_frag_after(uint32_t lds_addr, f32x4& p0, f32x4& p1) {
   bf16x8 v;
-  asm volatile("ds_read_b128 %0, %3 offset:%4" : "=v"(v), "+v"(p0), "+v"(p1) : "v"(lds_addr), "n"(OFF));
+  if constexpr (IN_AGPR) asm volatile("ds_read_b128 %0, %3 offset:%4" : "=v"(v), "+a"(p0), "+a"(p1) : "v"(lds_addr), "n"(OFF));
+  else asm volatile("ds_read_b128 %0, %3 offset:%4" : "=v"(v), "+v"(p0), "+v"(p1) : "v"(lds_addr), "n"(OFF));
   return v;
 }
-template <int OFF>
+template <int OFF, bool IN_AGPR = false>
 __device__ __forceinline__ bf16x8 lds_read_frag_after(uint32_t lds_addr, f32x4& p0, f32x4& p1, f32x4& p2, f32x4& p3) {
   bf16x8 v;
-  asm volatile("ds_read_b128 %0, %5 offset:%6" : "=v"(v), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(lds_addr), "n"(OFF));
+  if constexpr (IN_AGPR)
+    asm volatile("ds_read_b128 %0, %5 offset:%6" : "=v"(v), "+a"(p0), "+a"(p1), "+a"(p2), "+a"(p3) : "v"(lds_addr), "n"(OFF));
+  else
+    asm volatile("ds_read_b128 %0, %5 offset:%6" : "=v"(v), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(lds_addr), "n"(OFF));
   return v;
 }
 template <int N>
@@ -137,10 +148,60 @@ __device__ __forceinline__ void lds_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// The same discipline for an arbitrary stream of NSTEPS steps that each consume TWO weight fragments (one weight
+// plane): the fragments of step s are at LDS byte offsets Off::at(s, 0 / 1) from `lds_addr` and are requested DEPTH
+// steps ahead into DEPTH + 1 rotating register sets; body(step, w0, w1) holds the step's MFMAs AND the slice of
+// vector work that is to run between them.  Here the order is fixed by scheduling fences instead of accumulator
+// pins (the one-wave-per-SIMD kernel keeps 128 accumulators in AGPRs; "+v" pins would drag them through VGPRs):
+// nothing crosses the fence after a step's body, the volatile read group and the next wait follow in program order.
+template <int NSTEPS, int DEPTH, class Off, class Body>
+__device__ __forceinline__ void frag_stream2(uint32_t lds_addr, Body&& body) {
+  constexpr int SETS = DEPTH + 1;
+  bf16x8 w[SETS][2];
+  auto read_group = [&](auto step_tag) {
+    constexpr int s = decltype(step_tag)::value;
+    w[s % SETS][0] = lds_read_frag<Off::at(s, 0)>(lds_addr);
+    w[s % SETS][1] = lds_read_frag<Off::at(s, 1)>(lds_addr);
+  };
+  static_for<(DEPTH + 1 < NSTEPS ? DEPTH + 1 : NSTEPS)>([&](auto t) { read_group(t); });
+  static_for<NSTEPS>([&](auto t) {
+    constexpr int s = decltype(t)::value;
+    constexpr int set = s % SETS;
+    constexpr int ahead = (NSTEPS - 1 - s) < DEPTH ? (NSTEPS - 1 - s) : DEPTH;  // read groups that may stay in flight
+    lds_wait2<2 * ahead>(w[set][0], w[set][1]);
+    body(t, w[set][0], w[set][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (s + DEPTH + 1 < NSTEPS) read_group(std::integral_constant<int, s + DEPTH + 1>{});
+  });
+}
+
+// LDS byte offsets of the fused MLP's macro-iteration stream inside one stage:
+//   [Wi chunk 2t : KS k-steps x 2 fragments][Wi chunk 2t+1][MLP-Wo slab t-1 : NF1 fragments]
+// steps 0..KS-1 = chunk 2t, then (SLAB) NF1/2 steps of the slab, then KS steps of chunk 2t+1.
+template <int KS, int NF1, bool SLAB>
+struct MlpStreamOff {
+  static constexpr int WI = KS * 2048;
+  static constexpr int NS = SLAB ? NF1 / 2 : 0;
+  static constexpr int at(int s, int j) {
+    if (s < KS) return s * 2048 + j * 1024;
+    if (s < KS + NS) return 2 * WI + ((s - KS) * 2 + j) * 1024;
+    return WI + (s - KS - NS) * 2048 + j * 1024;
+  }
+};
+
 // One weight chunk (32 output features x K) against this wave's 32 rows: 2 x 2 accumulators, K/32 k-steps of
 // 4 MFMAs per product term, weight fragments two k-steps deep in registers (see above).  `lds_addr` = LDS byte
 // address of this lane's 16 bytes in piece 0 of stage 0; STAGE_BYTES = compile-time offset of the stage to read.
-template <int KS, int MF, int T, bool SWAPPED, int STAGE_BYTES>
+template <int KS, int MF, int T, bool SWAPPED, int STAGE_BYTES, bool PIN_AGPR = false>
 __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16x8 (&a_hi)[MF][KS],
                                                    const bf16x8 (&a_lo)[MF][KS], f32x4 (&acc)[2][MF]) {
   constexpr bool W_LO = (T & T_RIGHT_LO) != 0, A_LO = (T & T_LEFT_LO) != 0;
@@ -154,8 +215,8 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16
     constexpr int base = STAGE_BYTES + (ks * PLANES) * 2048;
     // the first read of the group is ordered behind every MFMA of the k-step two before it (and ahead of the next's)
     if (!PINNED) wh[S][0] = lds_read_frag<base>(lds_addr);
-    else if (MF == 2) wh[S][0] = lds_read_frag_after<base>(lds_addr, acc[0][0], acc[0][MF - 1], acc[1][0], acc[1][MF - 1]);
-    else wh[S][0] = lds_read_frag_after<base>(lds_addr, acc[0][0], acc[1][0]);
+    else if (MF == 2) wh[S][0] = lds_read_frag_after<base, PIN_AGPR>(lds_addr, acc[0][0], acc[0][MF - 1], acc[1][0], acc[1][MF - 1]);
+    else wh[S][0] = lds_read_frag_after<base, PIN_AGPR>(lds_addr, acc[0][0], acc[1][0]);
     wh[S][1] = lds_read_frag<base + 1024>(lds_addr);
     if (W_LO) {
       wl[S][0] = lds_read_frag<base + 2048>(lds_addr);
@@ -224,8 +285,11 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16
 // T2 = term mask of the chunk loop's GEMM (left = this block's rows, right = the streamed weight), T1 = term mask of
 // the fused phase-1 GEMM (RP_KSTREAM only), OLO = which outputs also get a lo plane (bit 0: o0 = q / h, bit 1: o1 = k,
 // bit 2: o2 = v^T).
-template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2>
-__global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void rowgemm_kernel(RowGemmParams p) {
+// RP_MLP only: TW = term mask of LN(x) x Wi, TM = of h x Wo(mlp); T1 is then the attention output projection and T2
+// the next layer's q/k/v projection.  Both weights must be single-plane (no hi x lo(weight) term): two LDS stages of
+// [two Wi chunks | one Wo slab] are 96 KiB then.
+template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0>
+__global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : ((MF == 1 && WAVES == 8) ? 4 : 2)) void rowgemm_kernel(RowGemmParams p) {
   // A block is WAVES x MF x 16 rows; the library launches 4 waves x 2 fragments = 128 rows, two blocks per CU, and
   // 4 waves x 1 fragment = 64 rows for small batches (fewer than one 128-row block per CU-slot: twice the blocks, so
   // twice the CUs work on a latency-bound request).
@@ -234,13 +298,22 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
   // <= 128 VGPRs, 4 waves per SIMD, twice the fragment reads per MFMA) is equal on q/k/v and 10 % slower on GeGLU.
   static_assert(MF == 1 || MF == 2, "one or two 16-row fragments per wave");
   constexpr bool W_LO = (T2 & T_RIGHT_LO) != 0, A_LO = (T2 & T_LEFT_LO) != 0;
-  constexpr bool W_LO1 = PRO == RP_KSTREAM && (T1 & T_RIGHT_LO) != 0, A_LO1 = PRO == RP_KSTREAM && (T1 & T_LEFT_LO) != 0;
+  constexpr bool PHASE1 = PRO == RP_KSTREAM || PRO == RP_MLP;
+  constexpr bool W_LO1 = PHASE1 && (T1 & T_RIGHT_LO) != 0, A_LO1 = PHASE1 && (T1 & T_LEFT_LO) != 0;
+  // RP_MLP: 4 waves x 32 rows, ONE wave per SIMD with the 512-register budget: the normalised rows (2 x 64 registers
+  // with their lo plane) and the 256 x 32 output accumulators (128) are both resident for the whole MLP; two waves of
+  // 16 rows per SIMD (256 registers each) spill.  The fragment streams prefetch by hand, so latency is covered
+  // without a partner wave.
+  static_assert(PRO != RP_MLP || (((WAVES == 4 && MF == 2) || (WAVES == 8 && MF == 1)) && (TW & T_RIGHT_LO) == 0 && (TM & T_RIGHT_LO) == 0),
+                "fused MLP: 4 waves x 32 rows or 8 waves x 16 rows, single-plane Wi and Wo");
   constexpr int PLANES = W_LO ? 2 : 1;
   constexpr int PLANES1 = W_LO1 ? 2 : 1;
   constexpr int K = KS * 32;
   constexpr int CHUNK_SRC = KS * 2 * 1024;        // elements per packed chunk in global memory
   constexpr int STAGE = KS * PLANES * 1024;       // elements per LDS stage
-  constexpr int STAGE_ALLOC = KS * (PLANES > PLANES1 ? PLANES : PLANES1) * 1024;  // phase 1 slabs: 2 KS fragments per plane
+  constexpr int MLP_UNIT = PRO == RP_MLP ? 3 * KS * 1024 : 0;  // two Wi chunks + one Wo slab (2 KS fragments), one plane
+  constexpr int STAGE_GEMM = KS * (PLANES > PLANES1 ? PLANES : PLANES1) * 1024;  // phase 1 slabs: 2 KS fragments per plane
+  constexpr int STAGE_ALLOC = STAGE_GEMM > MLP_UNIT ? STAGE_GEMM : MLP_UNIT;
   static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE_ALLOC];
 
@@ -272,7 +345,11 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
     }
   };
   bf16x8 a_hi[MF][KS], a_lo[MF][KS];
-  if (PRO == RP_KSTREAM) {
+  // LDS byte address of this lane's 16 bytes in piece 0 of each stage (the hand-placed fragment reads add immediates)
+  uint32_t lds_stage[2];
+  lds_stage[0] = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) u16*)&sW[0][0]) + (uint32_t)lane * 16u;
+  lds_stage[1] = lds_stage[0] + (uint32_t)(STAGE_ALLOC * 2);
+  if (PHASE1) {
     // ---- fused phase 1: x_new[32 rows, H] = x + A1[32 rows, K1] W1[H, K1]^T, K1 streamed ----------------
     // Same structure as kstream_gemm_kernel (one [H x 32] weight slab per k-step by DMA, A1 fragments straight
     // from the fragment-packed activation, prefetched one k-step ahead), all H outputs of the 32 rows in
@@ -350,104 +427,49 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
       }
       __syncthreads();
     };
+#ifdef OPK_ABL_NO_PHASE1
+    for (int k0 = 0; k0 < 0; k0 += 2) {
+#else
     for (int k0 = 0; k0 < nks1; k0 += 2) {  // even number of k-steps (checked on the host)
+#endif
       slab_step(k0, std::integral_constant<int, 0>{});
       slab_step(k0 + 1, std::integral_constant<int, 1>{});
     }
-    stage_chunk(0, 0);  // first weight chunk of phase 2 flies while the LayerNorm below runs
-
-    // ---- transition: residual add, store the new hidden state, LayerNorm, split -> fragments --------------
+    // ---- transition: residual add, (store the new hidden state,) LayerNorm, split -> fragments -------------------
+    // LOAD: acc1 += x rows from memory; STORE: write the rows back; then LayerNorm with `lnw` into a_hi / a_lo.
+    auto residual_ln = [&](auto load_tag, auto store_tag, auto lo_tag, const float* __restrict__ lnw) {
+      constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value, LO = decltype(lo_tag)::value;
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      float* xrow = p.x_io + (size_t)(m0 + mf * 16 + l15) * K + g * 8;
-      float sum = 0.f;
+      for (int mf = 0; mf < MF; ++mf) {
+        float* xrow = p.x_io + (size_t)(m0 + mf * 16 + l15) * K + g * 8;
+        float sum = 0.f;
 #pragma unroll
-      for (int nf = 0; nf < NF1; ++nf) {
-        float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
-        float4 r4 = *px;
-        r4.x += acc1[nf][mf][0];
-        r4.y += acc1[nf][mf][1];
-        r4.z += acc1[nf][mf][2];
-        r4.w += acc1[nf][mf][3];
-        *px = r4;
-        acc1[nf][mf] = f32x4{r4.x, r4.y, r4.z, r4.w};
-        sum += (r4.x + r4.y) + (r4.z + r4.w);
-        // keep the scheduler from hoisting all 16 row loads (64 more registers) on top of the accumulators
-        if ((nf & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum / (float)K;
-      float q = 0.f;
-#pragma unroll
-      for (int nf = 0; nf < NF1; ++nf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = acc1[nf][mf][r] - mean;
-          q += d * d;
+        for (int nf = 0; nf < NF1; ++nf) {
+          float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
+          float4 r4 = make_float4(acc1[nf][mf][0], acc1[nf][mf][1], acc1[nf][mf][2], acc1[nf][mf][3]);
+          if (LOAD) {
+            const float4 x4 = *px;
+            r4.x += x4.x;
+            r4.y += x4.y;
+            r4.z += x4.z;
+            r4.w += x4.w;
+            acc1[nf][mf] = f32x4{r4.x, r4.y, r4.z, r4.w};
+          }
+          if (STORE) *px = r4;
+          sum += (r4.x + r4.y) + (r4.z + r4.w);
+          // keep the scheduler from hoisting all 16 row loads (64 more registers) on top of the accumulators
+          if ((LOAD || STORE) && (nf & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      const float rstd = 1.0f / sqrtf(q / (float)K + p.eps);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8);
-        const float4 w1 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8 + 4);
-        const float v[8] = {(acc1[2 * ks][mf][0] - mean) * rstd * w0.x,     (acc1[2 * ks][mf][1] - mean) * rstd * w0.y,
-                            (acc1[2 * ks][mf][2] - mean) * rstd * w0.z,     (acc1[2 * ks][mf][3] - mean) * rstd * w0.w,
-                            (acc1[2 * ks + 1][mf][0] - mean) * rstd * w1.x, (acc1[2 * ks + 1][mf][1] - mean) * rstd * w1.y,
-                            (acc1[2 * ks + 1][mf][2] - mean) * rstd * w1.z, (acc1[2 * ks + 1][mf][3] - mean) * rstd * w1.w};
-        pack8<A_LO>(v, a_hi[mf][ks], a_lo[mf][ks]);
-      }
-    }
-  } else {
-    stage_chunk(0, 0);
-  }
-
-  // ---- prologue: this wave's 32 rows as fragments ---------------------------------------------
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
-    if (PRO == RP_KSTREAM) break;
-    const size_t row = (size_t)(m0 + mf * 16 + l15);
-    if (PRO == RP_PLANES) {  // fragment-packed input: piece (row block, k-step, plane), 16 bytes per lane
-      const u16* base = p.a_hi + (((size_t)((m0 >> 4) + mf) * KS) * 2) * 512 + lane * 8;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        a_hi[mf][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)ks * 1024);
-        if (A_LO) a_lo[mf][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)ks * 1024 + 512);
-      }
-      // Pin the fragment loads in front of the chunk loop: an empty asm that "rewrites" each register makes
-      // the compiler wait for the load HERE; otherwise it sinks the loads next to their first MFMA inside the
-      // loop and then drains the weight DMA (vmcnt(0)) at the top of every iteration.
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        asm volatile("" : "+v"(a_hi[mf][ks]));
-        if (A_LO) asm volatile("" : "+v"(a_lo[mf][ks]));
-      }
-    } else {
-      float v[KS][8];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 f0 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8);
-        const float4 f1 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8 + 4);
-        v[ks][0] = f0.x; v[ks][1] = f0.y; v[ks][2] = f0.z; v[ks][3] = f0.w;
-        v[ks][4] = f1.x; v[ks][5] = f1.y; v[ks][6] = f1.z; v[ks][7] = f1.w;
-      }
-      if (PRO == RP_LN) {
-        float s = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) s += v[ks][e];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const float mean = s / (float)K;
+        if (lnw == nullptr) continue;  // RE_NONE: the residual stream is all the last layer leaves behind
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum / (float)K;
         float q = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int nf = 0; nf < NF1; ++nf)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = v[ks][e] - mean;
+          for (int r = 0; r < 4; ++r) {
+            const float d = acc1[nf][mf][r] - mean;
             q += d * d;
           }
         q += __shfl_xor(q, 16, 64);
@@ -455,22 +477,218 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
         const float rstd = 1.0f / sqrtf(q / (float)K + p.eps);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8);
-          const float4 w1 = *reinterpret_cast<const float4*>(p.ln_w + ks * 32 + g * 8 + 4);
-          const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[ks][e] = (v[ks][e] - mean) * rstd * ww[e];
+          const float4 w0 = *reinterpret_cast<const float4*>(lnw + ks * 32 + g * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(lnw + ks * 32 + g * 8 + 4);
+          const float v[8] = {(acc1[2 * ks][mf][0] - mean) * rstd * w0.x,     (acc1[2 * ks][mf][1] - mean) * rstd * w0.y,
+                              (acc1[2 * ks][mf][2] - mean) * rstd * w0.z,     (acc1[2 * ks][mf][3] - mean) * rstd * w0.w,
+                              (acc1[2 * ks + 1][mf][0] - mean) * rstd * w1.x, (acc1[2 * ks + 1][mf][1] - mean) * rstd * w1.y,
+                              (acc1[2 * ks + 1][mf][2] - mean) * rstd * w1.z, (acc1[2 * ks + 1][mf][3] - mean) * rstd * w1.w};
+          pack8<LO>(v, a_hi[mf][ks], a_lo[mf][ks]);
         }
       }
+    };
+    const std::true_type yes_{};
+    const std::false_type no_{};
+    if constexpr (PRO == RP_KSTREAM) {
+      stage_chunk(0, 0);  // first weight chunk of phase 2 flies while the LayerNorm below runs
+      residual_ln(yes_, yes_, std::integral_constant<bool, A_LO>{}, p.ln_w);
+    } else {
+      // ---- fused MLP (RP_MLP): x_mid = x + o Wo^T stays in the accumulators acc1; for every pair t of Wi chunks
+      //   h[:, 32t .. 32t+31] = GeGLU(LN(x_mid) Wi^T) is produced as ONE MFMA operand fragment per lane (the packing
+      //   of Wi puts a lane's 8 consecutive h columns in the two chunks' accumulators) and immediately multiplied into
+      //   acc1 += h_t Wo[:, 32t..]^T.  h never leaves the registers: the 2 x 4 I bytes per token of the h round trip
+      //   -- the largest HBM stream of the layer -- and the x round trip between the two fused kernels are gone.
+      // One LDS stage = [Wi chunk 2t | Wi chunk 2t+1 | Wo slab t-1]; macro-iteration t runs, as one fragment stream,
+      //   chunk 2t (with the GeGLU of chunk 2t-1 between its MFMAs), slab t-1 (GeGLU of chunk 2t), chunk 2t+1.
+      constexpr bool A_LOW = (TW & T_LEFT_LO) != 0;  // lo(LN(x)) x hi(Wi)
+      constexpr bool H_LO = (TM & T_LEFT_LO) != 0;   // lo(h) x hi(Wo)
+      constexpr int UNIT_PIECES = MLP_UNIT / 512;
+      constexpr int WI_PIECES = 2 * KS * 2;  // both chunks
+      static_assert(UNIT_PIECES % WAVES == 0 && WI_PIECES % WAVES == 0, "stage regions must split over the waves");
+      const int n_pairs = p.n_pairs;
+      constexpr int UNIT_DMA = UNIT_PIECES / WAVES;  // DMA instructions per wave per stage
+      // piece u of this wave's share of stage `stage` for macro-iteration t.  Chunk / slab indices are clamped into
+      // range: the first stage has no slab yet, the last one no chunks any more (their pieces are copied again,
+      // harmlessly) -- a DMA under a branch would be drained at the join.
+      auto stage_piece = [&](auto u_tag, int t, int stage) {
+        constexpr int u = decltype(u_tag)::value;
+        const int tc = t < n_pairs ? t : n_pairs - 1;
+        const int ts = t > 0 ? t - 1 : 0;
+        const int piece = wave + WAVES * u;  // wave-uniform
+        const u16* src;
+        if (u < WI_PIECES / WAVES) {  // [chunk 0..1][ks][frag]: hi pieces of the chunk-major pack
+          const int c = piece / (2 * KS), within = piece % (2 * KS);
+          src = p.wi_pk + (size_t)(2 * tc + c) * CHUNK_SRC + (within >> 1) * 2048 + (within & 1) * 512;
+        } else {
+          src = p.wo2_ks + (size_t)ts * (NF1 * 2 * 512) + (piece - WI_PIECES) * 512;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+      };
+      auto stage_unit = [&](int t, int stage) { static_for<UNIT_DMA>([&](auto u) { stage_piece(u, t, stage); }); };
+      stage_unit(0, 0);  // flies while the LayerNorm below runs
+      residual_ln(yes_, no_, std::integral_constant<bool, A_LOW>{}, p.ln_w_mlp);
+
+      f32x4 acc_b[2][MF];  // accumulators of the pair's second chunk: [input | gate] fragment x row fragment
+      uint2 hold_hi[MF], hold_lo[MF];
+      bf16x8 h_hi[MF], h_lo[MF];
+      float g_prev[MF][4], g_cur[MF][4];  // GeGLU values of the chunk finished last / of this pair's first chunk
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) pack8<A_LO>(v[ks], a_hi[mf][ks], a_lo[mf][ks]);
+      for (int mf = 0; mf < MF; ++mf) {
+        hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
+        h_hi[mf] = h_lo[mf] = as_frag(make_uint4(0u, 0u, 0u, 0u));
+        acc_b[0][mf] = acc_b[1][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // The GeGLU epilogues are cut into slices that ride along with the fragment stream's steps (8 MFMAs each):
+      // value i of a chunk = gelu(input) * gate of (row fragment i / 4, slot i % 4); VPS values per step; a row
+      // fragment is split / packed as soon as its four values exist.
+      constexpr int NV = MF * 4;
+      constexpr int VPS = (NV + KS - 1) / KS;
+      auto geglu_slice = [&](const f32x4 (&av)[2][MF], float (&gv)[MF][4], auto slice_tag, auto&& pack) {
+        constexpr int sl = decltype(slice_tag)::value;
+        static_for<VPS>([&](auto j_tag) {
+          constexpr int i = sl * VPS + decltype(j_tag)::value;
+          if constexpr (i < NV) {
+#if defined(OPK_ABL_NO_GELU) || defined(OPK_ABL_NO_EPILOGUE)
+            gv[i >> 2][i & 3] = av[0][i >> 2][i & 3] * av[1][i >> 2][i & 3];
+#else
+            gv[i >> 2][i & 3] = gelu_erf(av[0][i >> 2][i & 3]) * av[1][i >> 2][i & 3];
+#endif
+            if constexpr ((i & 3) == 3) pack(std::integral_constant<int, (i >> 2)>{});
+          }
+        });
+      };
+      auto pack_h = [&](auto mf_tag) {  // second half of a pair -> the pair's h fragment of this row fragment
+        constexpr int mf = decltype(mf_tag)::value;
+        uint2 h2, l2;
+        split4<H_LO>(g_prev[mf], h2, l2);
+        h_hi[mf] = as_frag(make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y));
+        h_lo[mf] = as_frag(make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y));
+      };
+      auto pack_hold = [&](auto mf_tag) {
+        constexpr int mf = decltype(mf_tag)::value;
+        split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
+      };
+      auto chunk_step = [&](f32x4 (&acc)[2][MF], auto ks_tag, const bf16x8& w0, const bf16x8& w1) {
+        constexpr int ks = decltype(ks_tag)::value;
+        // the first MFMA of an accumulator takes the constant 0 as its C operand (no zero-fill of the registers)
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (A_LOW) {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc[0][mf] = mfma16(w0, a_lo[mf][ks], ks == 0 ? zero : acc[0][mf]);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16(w1, a_lo[mf][ks], ks == 0 ? zero : acc[1][mf]);
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[0][mf] = mfma16(w0, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[0][mf]);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16(w1, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[1][mf]);
+      };
+      auto slab_pair = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1) {
+        constexpr int nf = decltype(nf_tag)::value;
+        if (H_LO) {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, h_lo[mf], acc1[nf][mf]);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, h_lo[mf], acc1[nf + 1][mf]);
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, h_hi[mf], acc1[nf][mf]);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, h_hi[mf], acc1[nf + 1][mf]);
+      };
+      // one MFMA : up to three vector instructions inside a step (the slice's VALU spread between its MFMAs)
+      auto interleave_step = [&]() {
+        constexpr int STEP_MFMA = 2 * MF * ((A_LOW || H_LO) ? 2 : 1);
+#pragma unroll
+        for (int i = 0; i < STEP_MFMA; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      };
+      constexpr int DEPTH = 2;  // fragment groups in flight ahead of the one being consumed (a step = 8 MFMAs)
+      // The stage index is a RUNTIME value here (one copy of the loop body): the fragment reads are inline asm with
+      // the stage's base address in a register, so the compiler has no DMA-vs-read aliasing to resolve, and a body
+      // unrolled by two would permute the 128 accumulator registers between its copies on every back edge.
+      auto macro = [&](int t, int cur, auto slab_tag) {
+        constexpr bool SLAB = decltype(slab_tag)::value;  // false only for t = 0
+        using Off = MlpStreamOff<KS, NF1, SLAB>;
+        constexpr int NS = Off::NS;
+        // The next stage's DMA instructions are spread over the first steps of the stream, one per step: issued in
+        // one burst at the top they cost this (only) wave of the SIMD their full issue time with no MFMA in flight.
+        f32x4 na[2][MF], nb[2][MF];  // written by their first k-step (C operand = 0)
+        frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+          constexpr int s = decltype(step_tag)::value;
+#ifndef OPK_ABL_NO_DMA
+          if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
+#endif
+          if constexpr (s < KS) {  // chunk 2t, with the GeGLU of chunk 2t-1 (-> h of pair t-1 ready for the slab)
+            chunk_step(na, std::integral_constant<int, s>{}, w0, w1);
+            if constexpr (SLAB) geglu_slice(acc_b, g_prev, std::integral_constant<int, s>{}, pack_h);
+          } else if constexpr (s < KS + NS) {  // slab t-1, with the GeGLU of chunk 2t
+            slab_pair(std::integral_constant<int, 2 * (s - KS)>{}, w0, w1);
+            geglu_slice(na, g_cur, std::integral_constant<int, s - KS>{}, pack_hold);
+          } else {  // chunk 2t+1 (t = 0: with the GeGLU of chunk 0)
+            chunk_step(nb, std::integral_constant<int, s - KS - NS>{}, w0, w1);
+            if constexpr (!SLAB) geglu_slice(na, g_cur, std::integral_constant<int, s - KS>{}, pack_hold);
+          }
+          interleave_step();
+        });
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          acc_b[0][mf] = nb[0][mf];
+          acc_b[1][mf] = nb[1][mf];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (no other VMEM in this loop)
+#ifndef OPK_ABL_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+      };
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // stage 0 has landed
+      macro(0, 0, no_);
+      for (int t = 1; t < n_pairs; ++t) macro(t, t & 1, yes_);  // n_pairs is even (checked on the host): the tail reads stage 0
+      {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
+        static_for<KS>([&](auto sl) { geglu_slice(acc_b, g_prev, sl, pack_h); });
+        struct TailOff {
+          static constexpr int at(int s, int j) { return 2 * KS * 2048 + (s * 2 + j) * 1024; }
+        };
+        frag_stream2<NF1 / 2, DEPTH, TailOff>(lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+          slab_pair(std::integral_constant<int, 2 * decltype(step_tag)::value>{}, w0, w1);
+        });
+      }
+      __builtin_amdgcn_s_barrier();  // every wave is done with the ring: the chunk loop may reuse stage 0
+      if constexpr (EPI == RE_NONE) {
+        residual_ln(no_, yes_, no_, nullptr);  // acc1 = x + o Wo^T + h Wo^T: the layer's output
+        return;
+      } else {
+        stage_chunk(0, 0);
+        residual_ln(no_, yes_, std::integral_constant<bool, A_LO>{}, p.ln_w);
+      }
+    }
+  } else {
+    stage_chunk(0, 0);
+  }
+
+  // ---- prologue (layer 0, RP_SPLIT): this wave's rows of x as fragments, no LayerNorm (attn_norm is Identity) ----
+  if (PRO == RP_SPLIT) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const size_t row = (size_t)(m0 + mf * 16 + l15);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 f0 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8);
+        const float4 f1 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8 + 4);
+        const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        pack8<A_LO>(v, a_hi[mf][ks], a_lo[mf][ks]);
+      }
     }
   }
   // Numerics of a narrower policy on this (wider) instantiation: the lo fragments of the in-register operand are
   // ANDed with a launch-constant mask (all ones, or zero: their product term then adds exact zeros, bit-identical to
   // the kernel that omits the term).  Straight-line on purpose: a branch here makes the compiler keep two copies of
   // the 64 fragment registers and spill.
-  if (A_LO && PRO != RP_PLANES) {
+  if (A_LO && PRO != RP_MLP) {
     const unsigned keep = p.zero_a_lo ? 0u : 0xffffffffu;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
@@ -517,21 +735,7 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
   auto epilogue = [&](int cc, auto parity_tag, auto sw_tag, const f32x4 (&av)[2][MF]) {
     constexpr int PP = decltype(parity_tag)::value;
     constexpr bool sw = decltype(sw_tag)::value;  // q/k chunk ("swapped" MFMA orientation) or v chunk
-    if (EPI == RE_RESIDUAL) {
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const size_t row = (size_t)(m0 + mf * 16 + l15);
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-          float4* px = reinterpret_cast<float4*>(p.x + row * p.ld_out + cc * ROW_CHUNK + nf * 16 + g * 4);
-          float4 r4 = *px;
-          r4.x += av[nf][mf][0];
-          r4.y += av[nf][mf][1];
-          r4.z += av[nf][mf][2];
-          r4.w += av[nf][mf][3];
-          *px = r4;
-        }
-      }
+    if (EPI == RE_NONE) {
     } else if (EPI == RE_GEGLU) {
       // Output = "fragment-packed" h (see hfp_offset): chunk 2t gives this lane h-columns 32t + 8g + (0..3),
       // chunk 2t+1 columns 32t + 8g + (4..7) (the Wi rows were permuted that way at load time), so after the
@@ -541,7 +745,11 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
       for (int mf = 0; mf < MF; ++mf) {
         float v[4];
 #pragma unroll
+#ifdef OPK_ABL_NO_GELU
+        for (int r = 0; r < 4; ++r) v[r] = av[0][mf][r] * av[1][mf][r];
+#else
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(av[0][mf][r]) * av[1][mf][r];
+#endif
         uint2 h2, l2;
         split4<O0_LO>(v, h2, l2);
         if (PP == 0) {
@@ -550,8 +758,13 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
         } else {
           const size_t rb = (size_t)((m0 >> 4) + mf);
           const size_t off = ((rb * (size_t)(p.ld_out >> 5) + (size_t)(cc >> 1)) * 2) * 512 + lane * 8;
+#ifdef OPK_ABL_NO_STORE
+          asm volatile("" ::"v"(hold_hi[mf].x), "v"(hold_hi[mf].y), "v"(h2.x), "v"(h2.y), "v"(off));
+          if (O0_LO) asm volatile("" ::"v"(hold_lo[mf].x), "v"(hold_lo[mf].y), "v"(l2.x), "v"(l2.y));
+#else
           *reinterpret_cast<uint4*>(p.o0_hi + off) = make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y);
           if (O0_LO) *reinterpret_cast<uint4*>(p.o0_hi + off + 512) = make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y);
+#endif
         }
       }
     } else {  // RE_QKV: fragment-packed q, k (pieces [row/16][H/32][plane]) and v^T (pieces [head][row/32][plane][4])
@@ -571,8 +784,8 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float x1 = av[0][mf][r], x2 = av[1][mf][r];
-            lo_half[r] = (x1 * c4[r] - x2 * s4[r]) * qscale;
-            hi_half[r] = (x2 * c4[r] + x1 * s4[r]) * qscale;
+            lo_half[r] = rope_lo(x1, x2, c4[r], s4[r]) * qscale;
+            hi_half[r] = rope_hi(x1, x2, c4[r], s4[r]) * qscale;
           }
           uint2 h0, l0, h1, l1;
           split4<QK_LO>(lo_half, h0, l0);
@@ -626,8 +839,6 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
   for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // LDS byte address of this lane's 16 bytes in piece 0 of stage 0 (the hand-placed fragment reads add immediates)
-  const uint32_t lds_lane = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) u16*)&sW[0][0]) + (uint32_t)lane * 16u;
 
   // Unrolled by two so that the LDS stage index is a compile-time constant in each copy: the compiler can
   // then tell the DMA into stage cur^1 from the fragment reads of stage cur and does NOT drain the DMA
@@ -649,18 +860,24 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
         rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + (cur ^ 1) * 4);
       }
     }
+#ifndef OPK_ABL_NO_DMA
     stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
+#endif
     // Nothing crosses this point: the RoPE loads stay ahead of the DMA, and the epilogue's stores stay BEHIND it --
     // the counted wait in front of the barrier below relies on that order.
     __builtin_amdgcn_sched_barrier(0);
+#ifdef OPK_ABL_NO_EPILOGUE
+    if (!FIRST) asm volatile("" ::"v"(acc_prev[0][0]), "v"(acc_prev[1][0]), "v"(acc_prev[0][MF - 1]), "v"(acc_prev[1][MF - 1]));
+#else
     if (!FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag, acc_prev);
+#endif
 
     f32x4 acc[2][MF];
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rowgemm_chunk_mfma<KS, MF, T2, SW, cur * STAGE_ALLOC * 2>(lds_lane, a_hi, a_lo, acc);
+    rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP)>(lds_stage[cur], a_hi, a_lo, acc);
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -691,8 +908,14 @@ __global__ __launch_bounds__(WAVES * 64, (MF == 1 && WAVES == 8) ? 4 : 2) void r
         : EPI == RE_GEGLU ? (PPREV == 1 ? MF * (1 + (O0_LO ? 1 : 0)) : 0)
         : EPI == RE_QKV ? (SWP ? (PPREV == 1 ? MF * (2 + ((O0_LO && O1_LO) ? 2 : 0)) : 0) : 2 * (1 + (O2_LO ? 1 : 0)))
                         : 0;
+#if defined(OPK_ABL_NO_STORE) || defined(OPK_ABL_NO_EPILOGUE) || defined(OPK_STRICT_VMCNT)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
+#endif
+#ifndef OPK_ABL_NO_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
   };
   // Even chunk counts on both sides of the q/k -> v boundary (checked on the host).  The first pair is peeled so
   // that the deferred epilogue is unconditional in the steady-state loops.

@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float x1 = acc[i][j][r], x2 = acc[i + 2][j][r];
-          lo_half[r] = (x1 * cs[r] - x2 * sn[r]) * qscale;
-          hi_half[r] = (x2 * cs[r] + x1 * sn[r]) * qscale;
+          lo_half[r] = rope_lo(x1, x2, cs[r], sn[r]) * qscale;
+          hi_half[r] = rope_hi(x1, x2, cs[r], sn[r]) * qscale;
         }
         uint2 h2, l2;
         const size_t off = (size_t)m * p.ld_out + out_col + i * 16 + g * 4;

@@ -25,6 +25,8 @@ _ENV_FLAGS = {
     "OPEN_PROVENCE_FORCE_TILED": _lib.OP_FLAG_FORCE_TILED,
     "OPEN_PROVENCE_NO_SMALL_BLOCKS": _lib.OP_FLAG_NO_SMALL_BLOCKS,
     "OPEN_PROVENCE_NO_POLICY_KERNELS": _lib.OP_FLAG_NO_POLICY_KERNELS,
+    "OPEN_PROVENCE_NO_LAYER_FUSION": _lib.OP_FLAG_NO_LAYER_FUSION,
+    "OPEN_PROVENCE_LAYER_8X16": _lib.OP_FLAG_LAYER_8X16,
 }
 
 

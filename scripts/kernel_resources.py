@@ -19,7 +19,7 @@ def main() -> None:
     pattern = sys.argv[2] if len(sys.argv) > 2 else ""
     src, defines = {"api": ("op_api.hip", []), "attn": ("op_launch_attn.hip", []), "panel": ("op_launch_panel.hip", []),
                     "row0": ("op_launch_row.hip", ["-DOPL_ROW_PART=0"]), "row1": ("op_launch_row.hip", ["-DOPL_ROW_PART=1"]),
-                    "row2": ("op_launch_row.hip", ["-DOPL_ROW_PART=2"])}[unit]
+                    "row2": ("op_launch_row.hip", ["-DOPL_ROW_PART=2"]), "row3": ("op_launch_row.hip", ["-DOPL_ROW_PART=3"])}[unit]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", *defines,
            "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/op_resources.o", str(CSRC / src)]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp").stderr

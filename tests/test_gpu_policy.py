@@ -16,12 +16,13 @@ from parity_utils import run_fixture_on_gpu
 pytestmark = pytest.mark.gpu
 
 NO_POLICY_KERNELS = 16  # OP_FLAG_NO_POLICY_KERNELS
+NO_LAYER_FUSION = 32    # OP_FLAG_NO_LAYER_FUSION: two fused kernels per layer (the shape the all-terms set has too)
 
 
 @pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
 @pytest.mark.parametrize("precision", ["bf16x2", "bf16"])
 def test_curated_kernel_set_equals_cleared_operands(fixture, precision):
-    fast = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True)
+    fast = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True, flags=NO_LAYER_FUSION)
     slow = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True, flags=NO_POLICY_KERNELS)
     assert fast["kernel_set"] in ("bf16-weights", "bf16")
     assert slow["kernel_set"].startswith("all-terms")
@@ -50,15 +51,53 @@ def test_bf16_checkpoint_drops_weight_lo_terms_bit_identically(fixture):
              for k, v in state_from_fixture(arrays, meta).items()}
     rows = rows_from_fixture(arrays)
     outs = []
-    for flags in (0, NO_POLICY_KERNELS):
+    for flags in (NO_LAYER_FUSION, NO_POLICY_KERNELS):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
         enc.load_state_dict(state)
         policy = enc.effective_policy()
         assert policy["terms"] == {"wqkv": 1, "qk": 3, "pv": 3, "attn_out": 1, "wi": 1, "mlp_out": 1}
-        assert policy["kernel_set"] == ("bf16-weights" if flags == 0 else "all-terms kernels, cleared lo operands")
+        assert policy["kernel_set"] == ("bf16-weights" if flags == NO_LAYER_FUSION else "all-terms kernels, cleared lo operands")
         prune, rank, _ = enc.forward_rows(rows)
         torch.cuda.synchronize()
         outs.append((prune.cpu().numpy(), rank.cpu().numpy()))
         enc.close()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("fixture", ["g1_xsmall", "g0c_hd64_synth", "g7_xsmall_refinit"])
+def test_whole_layer_kernel_matches_two_kernel_path(fixture):
+    """hidden <= 256 with single-plane weights runs a layer as ONE kernel (attention output projection + MLP with h kept
+    on chip + next q/k/v projection).  Same terms as the two-kernel path, different accumulation order (the MLP output is
+    accumulated onto the residual instead of being added at the end): equal to fp32 noise on a bf16 checkpoint, and
+    within the 1e-3 bar of the oracle evaluated on the same bf16-valued weights."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import pad_rows
+    from oracle.modernbert_oracle import oracle_forward
+
+    arrays, meta = load_golden(fixture)
+    dims = dims_from_meta(meta)
+    state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v
+             for k, v in state_from_fixture(arrays, meta).items()}
+    rows = rows_from_fixture(arrays)
+    outs = {}
+    for label, flags in (("layer", 0), ("two", NO_LAYER_FUSION)):
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
+        enc.load_state_dict(state)
+        assert enc.effective_policy()["kernel_set"] == "bf16-weights"
+        enc.profile_enable(True)
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        kinds = set(enc.profile_read())
+        assert ("fused_layer_attnout_mlp_qkv" in kinds) == (label == "layer"), kinds
+        outs[label] = (prune.cpu().numpy(), rank.cpu().numpy())
+        enc.close()
+    scale = max(1.0, float(np.abs(outs["two"][0]).max()))
+    assert np.abs(outs["layer"][0] - outs["two"][0]).max() < 3e-4 * scale
+    assert np.abs(outs["layer"][1] - outs["two"][1]).max() < 3e-4 * scale
+    ids, mask = pad_rows(rows)
+    ref = oracle_forward(state, dims, ids, mask)
+    m = mask.bool().numpy()
+    assert np.abs(outs["layer"][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3
+    assert np.abs(outs["layer"][1] - ref.ranking_logits.numpy()).max() < 1e-3
