@@ -167,7 +167,9 @@ def main() -> None:
     encoder.load_state_dict(state)
     policy = encoder.effective_policy()
 
-    # 1 query x (pairs * world) contexts; this rank owns a contiguous slice (weak scaling: fixed per-GPU work)
+    # 1 query x (pairs * world) contexts, sharded over the ranks by the product's own plan (token-balanced partition,
+    # one gather of keep-probabilities + ranking logits to rank 0): weak scaling, fixed per-GPU work
+    plan = None
     if args.varlen:  # ragged stress (single GPU): a mixed-length batch of ~pairs*seq_len tokens
         if world > 1:
             raise SystemExit("--varlen is a single-GPU workload")
@@ -176,23 +178,25 @@ def main() -> None:
         n_pairs_rank = len(rows)
     else:
         rows_all = synth_pair_batch(dims, args.pairs * world, args.seq_len, seed=1234)
-        rows = rows_all[rank * args.pairs : (rank + 1) * args.pairs]
-        n_pairs_rank = args.pairs
+        if world > 1:
+            from open_provence_amd.sharding import ShardPlan
+
+            plan = ShardPlan([len(r) for r in rows_all], world, width=1, num_labels=dims.num_labels)
+            rows = [rows_all[i] for i in plan.local_rows(rank)]
+        else:
+            rows = rows_all
+        n_pairs_rank = len(rows)
     ids_np, cu_np, max_len = pack_rows(rows)
     ids = torch.from_numpy(ids_np).to(device)
     cu = torch.from_numpy(cu_np).to(device)
     total_tokens = int(cu_np[-1])
 
-    gather_rank = gather_prune = None
-    if world > 1 and rank == 0:
-        gather_rank = [torch.empty((n_pairs_rank, dims.num_labels), dtype=torch.float32, device=device) for _ in range(world)]
-        gather_prune = [torch.empty((total_tokens, 2), dtype=torch.float32, device=device) for _ in range(world)]
+    keep_dev = torch.empty(total_tokens, dtype=torch.float32, device=device)
 
     def step():
-        prune, rank_logits = encoder.forward_packed(ids, cu, cu_np, max_len)
-        if world > 1:
-            dist.gather(rank_logits, gather_list=gather_rank, dst=0)
-            dist.gather(prune, gather_list=gather_prune, dst=0)
+        prune, rank_logits = encoder.forward_packed(ids, cu, cu_np, max_len, keep_prob=keep_dev)
+        if plan is not None:  # the exchange step of the path: ShardPlan.gather (open_provence_amd/sharding.py)
+            plan.gather(keep_dev, rank_logits, dst=0)
         return prune, rank_logits
 
     def fence():

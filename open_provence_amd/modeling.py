@@ -438,12 +438,64 @@ class OpenProvenceModel:
             OpenProvenceForSequenceClassification.forward,
         )
 
-    def _predict_rows(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
-        """Rows of token ids -> (ranking_logits[B, nl] fp32 CPU, per-row keep probabilities fp32).
+    # -- data parallelism over (query, block) rows -----------------------------------
+    def attach_process_group(self, group: Any | None = None, *, dst: int = 0, enabled: bool = True) -> None:
+        """Shard every forward batch of ``process()`` / ``get_raw_predictions_batch`` over the ranks of a
+        ``torch.distributed`` process group (backend "nccl" = RCCL over xGMI with one process per GPU; "gloo" in the
+        CPU tests).  Every rank calls ``process()`` with the SAME arguments; each runs its token-balanced share of the
+        rows (full weight replica per GPU, no data-path collective), ONE gather moves the keep-probabilities
+        (4 B per token) + ranking logits to rank ``dst``, which post-processes and returns the result; the other
+        ranks' ``process()`` returns ``None``.  The reference has no multi-GPU path (its jobs are independent:
+        standalone.py:2748-2756)."""
 
-        Native path: one packed H2D copy, one forward, softmax over the two pruning logits on the
-        device, one D2H copy.  Overridden ``forward``: the reference's padded protocol
-        (standalone.py:2832-2924)."""
+        import torch.distributed as dist
+
+        if not enabled:
+            self._dist = None
+            return
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("attach_process_group needs an initialised torch.distributed process group")
+        self._dist = {"group": group, "dst": int(dst), "rank": dist.get_rank(group), "world": dist.get_world_size(group)}
+
+    def _predict_rows(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
+        """Rows of token ids -> (ranking_logits[B, nl] fp32 CPU, per-row keep probabilities fp32); sharded over the
+        attached process group when there is one (non-root ranks get zero-filled placeholders: their ``process()``
+        result is discarded)."""
+
+        info = getattr(self, "_dist", None)
+        if not info or info["world"] <= 1:
+            return self._predict_rows_local(rows, type_rows)
+        import torch.distributed as dist
+
+        from .sharding import ShardPlan
+
+        lengths = [len(r) for r in rows]
+        nl = int(getattr(getattr(self, "dims", None), "num_labels", 0) or getattr(getattr(self, "config", None), "num_labels", 1) or 1)
+        plan = ShardPlan(lengths, info["world"], width=1, num_labels=nl)
+        mine = plan.local_rows(info["rank"])
+        local_rank, local_keeps = self._predict_rows_local(
+            [rows[i] for i in mine], [type_rows[i] for i in mine] if type_rows else None
+        ) if mine else (torch.zeros((0, nl), dtype=torch.float32), [])
+        backend = dist.get_backend(info["group"])
+        comm_device = self._runtime_device if backend == "nccl" else torch.device("cpu")
+        keep_flat = np.concatenate([np.asarray(k[: lengths[i]], dtype=np.float32) for k, i in zip(local_keeps, mine)]) if mine else np.zeros(0, np.float32)
+        gathered = plan.gather(
+            torch.from_numpy(np.ascontiguousarray(keep_flat)).to(comm_device),
+            local_rank.to(torch.float32).reshape(len(mine), nl).to(comm_device),
+            dst=info["dst"], group=info["group"],
+        )
+        if gathered is None:
+            return torch.zeros((len(rows), nl), dtype=torch.float32), [np.zeros(n, dtype=np.float32) for n in lengths]
+        keep_all, rank_all = gathered
+        keep_np = keep_all.reshape(-1).cpu().numpy()
+        cu = plan.cu
+        return rank_all.cpu(), [keep_np[cu[i] : cu[i + 1]] for i in range(len(rows))]
+
+    def _predict_rows_local(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
+        """This process's rows -> (ranking_logits[B, nl] fp32 CPU, per-row keep probabilities fp32).
+
+        Native path: one packed H2D copy, one forward (keep-probability evaluated by the head kernel), one D2H copy.
+        Overridden ``forward``: the reference's padded protocol (standalone.py:2832-2924)."""
 
         if self._forward_is_native():
             ids_np, cu_np, max_len = pack_rows(rows)
@@ -1112,6 +1164,9 @@ class OpenProvenceModel:
             payload["removed_sentences"] = removed
         if probs is not None:
             payload["sentence_probabilities"] = probs
+        info = getattr(self, "_dist", None)
+        if info and info["world"] > 1 and info["rank"] != info["dst"]:
+            return None  # type: ignore[return-value]  # only the gather's destination rank holds the forward outputs
         return payload
 
 

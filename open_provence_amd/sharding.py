@@ -8,9 +8,10 @@ all-reduce anywhere.
 
 * :func:`partition_rows` -- deterministic token-balanced assignment (longest-first greedy), computed
   identically on every rank from the row lengths alone (no communication).
-* :func:`gather_row_outputs` -- ``torch.distributed.gather`` of fixed-size padded payloads to ``dst``
-  (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).  The payload is KB-MB, i.e.
-  latency-bound: one direct gather (each peer uses its own xGMI link to the root) rather than a ring.
+* :class:`ShardPlan` / :func:`gather_row_outputs` -- ``torch.distributed.gather`` of fixed-size padded payloads to
+  ``dst`` (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests) and a vectorised restore of the
+  original row order.  The payload is KB-MB, i.e. latency-bound: one direct gather (each peer uses its own xGMI link to
+  the root) rather than a ring.  ``process()`` ships keep-probabilities (4 B per token) + ranking logits.
 * :func:`sharded_forward` -- partition, run the local shard through a caller-supplied forward, gather,
   and restore the original row order on ``dst``.
 """
@@ -44,6 +45,89 @@ def partition_rows(lengths: Sequence[int], world_size: int) -> list[list[int]]:
     return [sorted(s) for s in shards]
 
 
+class ShardPlan:
+    """Everything about one sharded batch that follows from the row lengths alone -- computed identically on every
+    rank, without communication: which rows each rank runs, the size of the (padded) payload each rank sends, and the
+    index map that puts the gathered per-token values back into the original row order with ONE indexing operation.
+
+    Payload of a rank = ``[max_tokens * width]`` per-token values (its rows end to end) + ``[max_rows * nl]`` ranking
+    logits, fp32.  ``width`` is 1 for keep-probabilities (4 B per token: what ``process()`` ships) or 2 for the raw
+    pruning logits."""
+
+    def __init__(self, lengths: Sequence[int], world_size: int, *, width: int = 1, num_labels: int = 1) -> None:
+        self.lengths = np.asarray([int(n) for n in lengths], dtype=np.int64)
+        self.world_size = int(world_size)
+        self.width = int(width)
+        self.num_labels = int(num_labels)
+        self.shards = partition_rows(self.lengths.tolist(), self.world_size)
+        self.tokens = [int(self.lengths[s].sum()) if s else 0 for s in self.shards]
+        self.rows = [len(s) for s in self.shards]
+        self.max_tokens = max(self.tokens + [1])
+        self.max_rows = max(self.rows + [1])
+        self.payload_size = self.max_tokens * self.width + self.max_rows * self.num_labels
+        n = len(self.lengths)
+        self.cu = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(self.lengths, out=self.cu[1:])
+        # where row i starts inside the stacked [world, payload_size] bucket (in units of tokens), and its rank slot
+        start = np.zeros(n, dtype=np.int64)
+        slot = np.zeros(n, dtype=np.int64)
+        for r, shard in enumerate(self.shards):
+            if not shard:
+                continue
+            idx = np.asarray(shard, dtype=np.int64)
+            off = np.zeros(len(idx), dtype=np.int64)
+            np.cumsum(self.lengths[idx][:-1], out=off[1:])
+            start[idx] = r * self.payload_size + off * self.width
+            slot[idx] = r * self.payload_size + self.max_tokens * self.width + np.arange(len(idx)) * self.num_labels
+        total = int(self.cu[-1])
+        token_row_start = np.repeat(start - self.cu[:-1] * self.width, self.lengths * self.width) if total else np.zeros(0, np.int64)
+        self.token_index = token_row_start + np.arange(total * self.width, dtype=np.int64)
+        self.rank_index = (slot[:, None] + np.arange(self.num_labels, dtype=np.int64)[None, :]).reshape(-1)
+
+    def local_rows(self, rank: int) -> list[int]:
+        return self.shards[rank]
+
+    def pack(self, rank: int, values: torch.Tensor, rank_logits: torch.Tensor) -> torch.Tensor:
+        """This rank's payload (on the tensors' device)."""
+
+        if values.numel() != self.tokens[rank] * self.width or rank_logits.numel() != self.rows[rank] * self.num_labels:
+            raise ValueError("local outputs do not match this rank's shard")
+        payload = torch.zeros(self.payload_size, dtype=torch.float32, device=values.device)
+        payload[: values.numel()] = values.reshape(-1)
+        base = self.max_tokens * self.width
+        payload[base : base + rank_logits.numel()] = rank_logits.reshape(-1)
+        return payload
+
+    def unpack(self, bucket: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """``bucket[world * payload_size]`` (the gathered payloads, rank-major) -> per-token values ``[T, width]`` and
+        ranking logits ``[B, nl]`` in the ORIGINAL row order: two index_select operations, no per-row loop."""
+
+        flat = bucket.reshape(-1)
+        tok = flat[torch.from_numpy(self.token_index).to(flat.device)].reshape(-1, self.width)
+        rk = flat[torch.from_numpy(self.rank_index).to(flat.device)].reshape(len(self.lengths), self.num_labels)
+        return tok, rk
+
+    def gather(
+        self,
+        values: torch.Tensor,
+        rank_logits: torch.Tensor,
+        *,
+        dst: int = 0,
+        group: dist.ProcessGroup | None = None,
+    ) -> tuple[torch.Tensor, torch.Tensor] | None:
+        """ONE ``torch.distributed.gather`` of the fixed-size payloads to ``dst`` (no size exchange: every rank derives
+        the sizes from the plan).  Returns ``unpack`` of the bucket on ``dst``, ``None`` elsewhere."""
+
+        me = dist.get_rank(group)
+        payload = self.pack(me, values, rank_logits)
+        if me == dst:
+            bucket = torch.empty(self.world_size * self.payload_size, dtype=torch.float32, device=payload.device)
+            dist.gather(payload, gather_list=list(bucket.split(self.payload_size)), dst=dst, group=group)
+            return self.unpack(bucket)
+        dist.gather(payload, gather_list=None, dst=dst, group=group)
+        return None
+
+
 def gather_row_outputs(
     prune: torch.Tensor,
     rank_logits: torch.Tensor,
@@ -54,47 +138,20 @@ def gather_row_outputs(
     dst: int = 0,
     group: dist.ProcessGroup | None = None,
 ) -> tuple[list[torch.Tensor], torch.Tensor] | None:
-    """Gather every rank's packed ``prune[T_r, 2]`` and ``rank_logits[B_r, nl]`` on ``dst``.
-
-    Buffer sizes follow from ``shards``/``lengths`` (known on every rank), so no size exchange is needed:
-    each rank pads its payload to the largest shard and one ``gather`` moves it.  Returns, on ``dst``, the
-    per-row pruning logits (original row order) and ``rank_logits[B, nl]``; ``None`` elsewhere."""
+    """Gather every rank's packed ``prune[T_r, 2]`` and ``rank_logits[B_r, nl]`` on ``dst``; returns, on ``dst``, the
+    per-row pruning logits (views of one tensor, original row order) and ``rank_logits[B, nl]``; ``None`` elsewhere."""
 
     world = dist.get_world_size(group)
     me = dist.get_rank(group)
-    if len(shards) != world:
-        raise ValueError("shards must have one entry per rank")
-    tokens = [sum(int(lengths[i]) for i in shard) for shard in shards]
-    rows = [len(shard) for shard in shards]
-    max_tokens, max_rows = max(tokens + [1]), max(rows + [1])
     nl = rank_logits.shape[1] if rank_logits.ndim == 2 else 1
-    if prune.shape[0] != tokens[me] or rank_logits.shape[0] != rows[me] or list(local_rows) != list(shards[me]):
+    plan = ShardPlan(lengths, world, width=2, num_labels=nl)
+    if [list(s) for s in shards] != plan.shards or list(local_rows) != plan.shards[me]:
         raise ValueError("local outputs do not match this rank's shard")
-
-    payload = torch.zeros(max_tokens * 2 + max_rows * nl, dtype=torch.float32, device=prune.device)
-    payload[: tokens[me] * 2] = prune.reshape(-1)
-    payload[max_tokens * 2 : max_tokens * 2 + rows[me] * nl] = rank_logits.reshape(-1)
-    if me == dst:
-        bucket = [torch.empty_like(payload) for _ in range(world)]
-        dist.gather(payload, gather_list=bucket, dst=dst, group=group)
-    else:
-        dist.gather(payload, gather_list=None, dst=dst, group=group)
+    out = plan.gather(prune, rank_logits, dst=dst, group=group)
+    if out is None:
         return None
-
-    n_rows = len(lengths)
-    per_row: list[torch.Tensor | None] = [None] * n_rows
-    all_rank = torch.zeros((n_rows, nl), dtype=torch.float32, device=prune.device)
-    for r, shard in enumerate(shards):
-        buf = bucket[r]
-        p = buf[: tokens[r] * 2].reshape(tokens[r], 2)
-        rk = buf[max_tokens * 2 : max_tokens * 2 + rows[r] * nl].reshape(rows[r], nl)
-        cursor = 0
-        for j, idx in enumerate(shard):
-            n = int(lengths[idx])
-            per_row[idx] = p[cursor : cursor + n]
-            cursor += n
-            all_rank[idx] = rk[j]
-    return [t if t is not None else prune.new_zeros((0, 2)) for t in per_row], all_rank
+    tok, all_rank = out
+    return list(tok.split(plan.lengths.tolist())), all_rank
 
 
 def sharded_forward(

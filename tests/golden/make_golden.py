@@ -283,6 +283,8 @@ def _jsonable(value: Any) -> Any:
         return [_jsonable(v) for v in value]
     if isinstance(value, (np.floating, np.integer)):
         return value.item()
+    if isinstance(value, np.ndarray):
+        return [_jsonable(v) for v in value.tolist()]
     return value
 
 
@@ -504,6 +506,178 @@ def mldr_fixture(name: str, cfg: dict[str, Any], *, max_length: int) -> None:
     print(f"[golden] {name}: {[(r['label'], len(r['expected']['records'])) for r in runs]}")
 
 
+def _load_script(ref, name: str):
+    """Import one of the reference's scripts (scripts/eval_datasets.py, scripts/eval_mldr.py) with `open_provence`
+    resolving to the standalone module, `litellm` (absent; LLM-judge half only) stubbed and `datetime.UTC` aliased."""
+
+    import datetime as _dt
+
+    if not hasattr(_dt, "UTC"):
+        _dt.UTC = _dt.timezone.utc  # type: ignore[attr-defined]
+    pkg = types.ModuleType("open_provence")
+    pkg.__path__ = []  # type: ignore[attr-defined]
+    sys.modules["open_provence"] = pkg
+    sys.modules["open_provence.modeling_open_provence_standalone"] = ref
+    sys.modules.setdefault("litellm", types.ModuleType("litellm"))
+    spec = importlib.util.spec_from_file_location(f"reference_{name}", f"/root/reference/scripts/{name}.py")
+    script = importlib.util.module_from_spec(spec)
+    sys.modules[f"reference_{name}"] = script
+    spec.loader.exec_module(script)
+    return script
+
+
+def _sentence_margin(value: Any, threshold: float) -> float:
+    """Smallest |probability - threshold| over every sentence probability in a (nested) process() result."""
+
+    if isinstance(value, (list, tuple)):
+        return min((_sentence_margin(v, threshold) for v in value), default=1.0)
+    if isinstance(value, float):
+        return abs(value - threshold)
+    return 1.0
+
+
+def long_mldr_rows() -> list[dict[str, Any]]:
+    """MLDR-shaped rows whose passages are LONG documents (3 - 5 k characters = 2 - 3 blocks at max_length 2048 with
+    the one-token-per-character tokenizer), all with explicit titles as scripts/eval_mldr.py passes them (:388)."""
+
+    def doc(seed: int, n: int) -> str:
+        topics = ["rivers", "towers", "bread", "mountains", "harbours", "bridges", "orchards"]
+        parts = []
+        for i in range(n):
+            t = topics[(seed + i * 3) % len(topics)]
+            parts.append(f"Section {seed}.{i} explains how {t} shape the region and why item {i * 7 + seed} matters for {t}.")
+        return " ".join(parts)
+
+    return [
+        {"query_id": "L1", "query": "how do rivers shape the region?",
+         "positive_passages": [{"docid": "p1", "title": "Rivers of the north", "text": doc(1, 48)}],
+         "negative_passages": [{"docid": "n1", "title": "Bread and ovens", "text": doc(2, 36)}]},
+        {"query_id": "L2", "query": "which bridges matter most?",
+         "positive_passages": [{"docid": "p2", "title": ["Bridges", " ", "and harbours"], "text": doc(3, 40)}],
+         "negative_passages": []},
+    ]
+
+
+def mldr_model_fixture(name: str, cfg: dict[str, Any], *, max_length: int, weight_seed: int, threshold: float) -> None:
+    """G9 (BASELINE.json configs[3]): the reference's MLDR path -- scripts/eval_mldr.py build_records (:238-524) over
+    process() with explicit per-passage titles, multi-block documents at max_length 2048 -- with the REAL forward of a
+    large-shaped model (H = 768, I = 3072, 12 heads, full depth; synthetic seed weights), both score conventions."""
+
+    import inspect as _inspect
+
+    from open_provence_amd.eval_harness import clean_title  # pinned against the reference's normalize_title by G5
+
+    ref = load_reference(emit_specials=True)
+    script = _load_script(ref, "eval_mldr")
+    model, _dims = build_model(ref, cfg, max_length=max_length, seed=0, weight_seed=weight_seed)
+
+    def process_fn(**kwargs):
+        return model.process(sentence_splitter=period_splitter, **kwargs)
+
+    process_fn.__signature__ = _inspect.signature(model.process)  # type: ignore[attr-defined]
+    rows = long_mldr_rows()
+    runs = []
+    with torch.no_grad():
+        # the same process() call the script makes, kept whole: sentence probabilities do not depend on the threshold,
+        # so the fixture's threshold is the candidate FARTHEST from every sentence probability (a kept / removed
+        # decision within the 1e-3 numerical bar of the threshold would make "identical kept sets" a coin toss)
+        probe = model.process(question=[r["query"] for r in rows],
+                              context=[[p["text"] for p in r["positive_passages"] + r["negative_passages"]] for r in rows],
+                              title=[[clean_title(p.get("title")) for p in r["positive_passages"] + r["negative_passages"]] for r in rows],
+                              sentence_splitter=period_splitter, threshold=threshold, batch_size=4, show_progress=False,
+                              return_sentence_metrics=True, return_sentence_texts=False)
+        probs = _jsonable(probe["sentence_probabilities"])
+        threshold = max((round(threshold + 0.01 * k, 2) for k in range(-10, 11)), key=lambda t: _sentence_margin(probs, t))
+        margin = _sentence_margin(probs, threshold)
+        assert margin > 5e-3, f"no candidate threshold is farther than {margin:.2e} from every sentence probability"
+        for label, best in (("best_block_score", True), ("last_block_score", False)):
+            records, stats, n_queries = script.build_records(process_fn, rows, threshold=threshold, batch_size=4, log_timing=False,
+                                                             use_best_reranker_score=best, show_progress=False)
+            runs.append({"label": label, "use_best_reranker_score": best,
+                         "expected": _jsonable({"records": records, "stats": stats, "n_queries": n_queries})})
+    n_blocks = sum(len(str(p["text"])) // (max_length - 64) + 1 for r in rows for p in r["positive_passages"] + r["negative_passages"])
+    meta = {
+        "name": name,
+        "base_model_config": cfg,
+        "max_length": max_length,
+        "weight_seed": weight_seed,
+        "weight_init": "synth",
+        "threshold": threshold,
+        "rows": rows,
+        "runs": runs,
+        "min_margin_to_threshold": margin,
+        "approx_blocks": n_blocks,
+        "generator": "tests/golden/make_golden.py (reference scripts/eval_mldr.py build_records over the REAL forward, CPU fp32)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: {[(r['label'], len(r['expected']['records'])) for r in runs]} margin {margin:.3e}")
+
+
+def eval_model_fixture(name: str, cfg: dict[str, Any], *, max_length: int, weight_seed: int) -> None:
+    """G4m: the reference's dataset evaluator (scripts/eval_datasets.py:247-486) over the REAL forward (small model)."""
+
+    ref = load_reference(emit_specials=True)
+    script = _load_script(ref, "eval_datasets")
+    model, _dims = build_model(ref, cfg, max_length=max_length, seed=0, weight_seed=weight_seed)
+    dataset = eval_dataset_examples()
+    runs = []
+    with torch.no_grad():
+        for threshold in (0.5, 0.3):
+            result = script.evaluate_dataset(model, dataset, threshold=threshold, batch_size=4, dataset_label="synthetic",
+                                             show_progress=False, debug_messages=False, print_timing_summary=False, silent=True)
+            result.pop("process_time_seconds")
+            result.pop("timing")
+            margin = min((abs(float(sc) - threshold) for sc in result["roc_data"]["scores"]), default=1.0)
+            assert margin > 5e-3, (threshold, margin)
+            runs.append({"threshold": threshold, "expected": _jsonable(result), "min_margin_to_threshold": margin})
+    meta = {
+        "name": name, "base_model_config": cfg, "max_length": max_length, "weight_seed": weight_seed, "weight_init": "synth",
+        "dataset": dataset, "runs": runs,
+        "generator": "tests/golden/make_golden.py (reference scripts/eval_datasets.py evaluate_dataset over the REAL forward)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: {[(r['threshold'], r['expected']['confusion_matrix']) for r in runs]}")
+
+
+def raw_predictions_fixture(name: str, cfg: dict[str, Any], *, max_length: int, weight_seed: int) -> None:
+    """G10: the single-block API with the REAL forward -- get_raw_predictions_batch (shared and per-sample queries),
+    get_raw_predictions and predict_with_thresholds (mean and majority rule) (standalone.py:1742-1881)."""
+
+    ref = load_reference(emit_specials=True)
+    model, _dims = build_model(ref, cfg, max_length=max_length, seed=0, weight_seed=weight_seed)
+    contexts_batch = [
+        ["Cats purr a lot. ", "Dogs bark loudly! ", "The sky is blue."],
+        ["A single context sentence that is somewhat longer than the others in this batch."],
+        ["Short. ", "Tiny. ", "Brief one here. ", "And the last."],
+    ]
+    queries = ["what do cats do?", "single?", "which is brief?"]
+    thresholds = [0.2, 0.5, 0.8]
+
+    def dump(pred) -> dict[str, Any]:
+        return {"ranking_score": float(pred.ranking_score), "pruning_probs": [float(v) for v in np.asarray(pred.pruning_probs)],
+                "context_ranges": [[int(a), int(b)] for a, b in pred.context_ranges]}
+
+    with torch.no_grad():
+        shared = [dump(p) for p in model.get_raw_predictions_batch(queries[0], contexts_batch)]
+        per_sample = [dump(p) for p in model.get_raw_predictions_batch(queries, contexts_batch, batch_size=2)]
+        single = dump(model.get_raw_predictions(queries[2], contexts_batch[2]))
+        thr_mean = model.predict_with_thresholds(queries[0], contexts_batch[0], thresholds)
+        thr_major = model.predict_with_thresholds(queries[2], contexts_batch[2], thresholds, use_majority=True)
+    meta = {
+        "name": name, "base_model_config": cfg, "max_length": max_length, "weight_seed": weight_seed, "weight_init": "synth",
+        "queries": queries, "contexts_batch": contexts_batch, "thresholds": thresholds,
+        "expected": _jsonable({"shared_query": shared, "per_sample_queries": per_sample, "single": single,
+                               "predict_with_thresholds_mean": {k: (v if not isinstance(v, dict) else {str(t): x for t, x in v.items()}) for k, v in thr_mean.items()},
+                               "predict_with_thresholds_majority": {k: (v if not isinstance(v, dict) else {str(t): x for t, x in v.items()}) for k, v in thr_major.items()}}),
+        "generator": "tests/golden/make_golden.py (reference get_raw_predictions(_batch) / predict_with_thresholds, REAL forward)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: scores {[round(p['ranking_score'], 4) for p in shared]}")
+
+
 class RegexPunkt:
     """Deterministic stand-in for nltk's Punkt model (absent here): spans of text up to and including a run of
     ``.!?`` that is followed by whitespace or the end, trailing whitespace excluded -- the contract
@@ -670,6 +844,17 @@ def main() -> None:
         mldr_fixture("g5_mldr_records", g3_cfg, max_length=96)
     if want("g6_english_splitter"):
         splitter_fixture("g6_english_splitter")
+    if want("g4m_eval_dataset_model"):
+        eval_model_fixture("g4m_eval_dataset_model", g3_cfg, max_length=96, weight_seed=41)
+    if want("g10_raw_predictions"):
+        raw_predictions_fixture("g10_raw_predictions", g3_cfg, max_length=96, weight_seed=41)
+    # G9 = BASELINE.json configs[3]: large dims at FULL depth, max_length 2048, the MLDR caller
+    if want("g9_large_mldr"):
+        mldr_model_fixture(
+            "g9_large_mldr",
+            base_cfg(vocab_size=256, hidden_size=768, intermediate_size=3072, num_hidden_layers=25, num_attention_heads=12),
+            max_length=2048, weight_seed=71, threshold=0.4,
+        )
 
 
 if __name__ == "__main__":

@@ -34,7 +34,10 @@ class CharTokenizer:
         self.special_tokens_map: dict[str, Any] = {}
 
     def _ids(self, text: str) -> list[int]:
-        return [ord(ch) for ch in text]
+        try:  # one C-level pass for Latin-1 text (ids = code points either way)
+            return list(text.encode("latin-1"))
+        except UnicodeEncodeError:
+            return [ord(ch) for ch in text]
 
     def __call__(
         self,
@@ -70,9 +73,17 @@ class CharTokenizer:
         ids = self._ids(text)
         return [self.cls_token_id, *ids, self.sep_token_id] if add_special_tokens else ids
 
+    _SPECIALS_LATIN1 = bytes([pad_token_id, cls_token_id, sep_token_id])
+
     def decode(self, tokens, skip_special_tokens: bool = True, clean_up_tokenization_spaces: bool = False) -> str:
-        specials = {self.pad_token_id, self.cls_token_id, self.sep_token_id} if skip_special_tokens else set()
-        return "".join(chr(int(t)) for t in tokens if int(t) not in specials)
+        try:  # Latin-1 ids: one C-level pass (bytes(...) raises for ids >= 256)
+            raw = bytes(tokens)
+            if skip_special_tokens:
+                raw = raw.translate(None, self._SPECIALS_LATIN1)
+            return raw.decode("latin-1")
+        except (ValueError, TypeError):
+            specials = {self.pad_token_id, self.cls_token_id, self.sep_token_id} if skip_special_tokens else set()
+            return "".join(chr(int(t)) for t in tokens if int(t) not in specials)
 
     def batch_decode(self, batch, skip_special_tokens: bool = True, clean_up_tokenization_spaces: bool = False):
         return [self.decode(tokens, skip_special_tokens=skip_special_tokens) for tokens in batch]

@@ -241,7 +241,8 @@ def test_panel_path_ragged_edge_cases():
         assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3, (i, n)
 
 
-@pytest.mark.parametrize("model_name,lengths", [("base", [512, 300, 77]), ("large", [512, 129]), ("en-gte", [640, 64])])
+@pytest.mark.parametrize("model_name,lengths", [("base", [512, 300, 77]), ("large", [512, 129]), ("large", [2048]),
+                                                ("en-gte", [640, 64])])
 def test_full_depth_published_shapes_match_oracle(model_name, lengths):
     """BASELINE.json configs 3-5 at their real depth (19 / 25 / 22 layers, H = 512 / 768): error accumulation through
     the whole stack of the panel kernels stays inside 1e-3 of the fp32 oracle (the H=768 golden fixture has 3 layers)."""
@@ -375,3 +376,151 @@ def test_batch_composition_invariance_at_baseline_size():
         ref = oracle_forward(state, dims, ids, torch.ones_like(ids))
         assert (prune[cu[i] : cu[i + 1]].cpu() - ref.pruning_logits[0]).abs().max() < 1e-3
         assert (rank[i].cpu() - ref.ranking_logits[0]).abs().max() < 1e-3
+
+
+def _model_from_meta(meta, precision="bf16x3"):
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.modeling import OpenProvenceModel
+    from open_provence_amd.synthetic import synth_state_dict
+
+    cfg = OpenProvenceConfig(
+        base_model_config=meta["base_model_config"], tokenizer_name_or_path="char-tokenizer",
+        pruning_config={"hidden_size": meta["base_model_config"]["hidden_size"]}, max_length=meta["max_length"], num_labels=1,
+    )
+    state = synth_state_dict(dims_from_meta(meta), meta["weight_seed"])
+    return OpenProvenceModel(cfg, device="cuda:0", tokenizer=CharTokenizer(), state_dict=state, precision=precision)
+
+
+def _same_records(got, exp, path="", tol=1e-3):
+    """Integers, strings and structure exact; floats (scores, probabilities, compression) within `tol`."""
+
+    import math
+
+    if isinstance(exp, float) or isinstance(got, float):
+        if exp is None or got is None:
+            assert got is exp, path
+        elif isinstance(exp, float) and math.isnan(exp):
+            assert math.isnan(got), path
+        else:
+            assert math.isclose(float(got), float(exp), rel_tol=0.0, abs_tol=tol), (path, got, exp)
+    elif isinstance(exp, dict):
+        assert isinstance(got, dict) and set(got) == set(exp), (path, sorted(got), sorted(exp))
+        for key in exp:
+            _same_records(got[key], exp[key], f"{path}.{key}", tol)
+    elif isinstance(exp, (list, tuple)):
+        assert isinstance(got, (list, tuple)) and len(got) == len(exp), (path, got, exp)
+        for i, (g, e) in enumerate(zip(got, exp)):
+            _same_records(g, e, f"{path}[{i}]", tol)
+    else:
+        assert got == exp, (path, got, exp)
+
+
+def test_mldr_records_large_model_max_length_2048_match_reference():
+    """BASELINE.json configs[3] on the GPU: the MLDR caller (reference scripts/eval_mldr.py build_records) over process()
+    with explicit per-passage titles and multi-block documents at max_length 2048, large dims (H=768, I=3072, 12 heads)
+    at FULL depth (25 layers) -- golden produced by the reference's own script over its REAL forward
+    (tests/golden/g9_large_mldr.json).  Records identical (texts, ids, kept/removed structure), floats within 1e-3."""
+
+    import inspect
+
+    from open_provence_amd.eval_harness import build_mldr_records
+
+    meta = json.loads((GOLDEN_DIR / "g9_large_mldr.json").read_text(encoding="utf-8"))
+    assert meta["max_length"] == 2048 and meta["base_model_config"]["num_hidden_layers"] == 25
+    model = _model_from_meta(meta)
+
+    def process_fn(**kwargs):
+        return model.process(sentence_splitter=period_splitter, **kwargs)
+
+    process_fn.__signature__ = inspect.signature(model.process)
+    for run in meta["runs"]:
+        records, stats, n_queries = build_mldr_records(
+            process_fn, meta["rows"], threshold=meta["threshold"], batch_size=4, log_timing=False,
+            use_best_reranker_score=run["use_best_reranker_score"], show_progress=False,
+        )
+        exp = run["expected"]
+        assert n_queries == exp["n_queries"]
+        _same_records(records, exp["records"], run["label"] + ".records")
+        _same_records(stats, exp["stats"], run["label"] + ".stats", tol=2e-3)  # compression is in percent
+
+
+def test_evaluate_dataset_through_hip_model_matches_reference():
+    """The dataset evaluator (reference scripts/eval_datasets.py:247-486) over the HIP model: confusion matrix, kept
+    spans and predictions identical to the reference's run over its REAL forward, floats within 1e-3."""
+
+    from open_provence_amd.eval_harness import evaluate_dataset
+
+    meta = json.loads((GOLDEN_DIR / "g4m_eval_dataset_model.json").read_text(encoding="utf-8"))
+    model = _model_from_meta(meta)
+    for run in meta["runs"]:
+        got = evaluate_dataset(model, meta["dataset"], threshold=run["threshold"], batch_size=4, dataset_label="synthetic")
+        exp = run["expected"]
+        for key in ("span_total", "span_correct", "span_skipped", "contexts", "confusion_matrix"):
+            assert got[key] == exp[key], (run["threshold"], key, got[key], exp[key])
+        assert got["roc_data"]["labels"] == exp["roc_data"]["labels"]
+        assert got["roc_data"]["predictions"] == exp["roc_data"]["predictions"]
+        _same_records(got["roc_data"]["scores"], exp["roc_data"]["scores"], "scores")
+        for key in ("span_accuracy", "mean_compression", "precision", "recall", "f2"):
+            _same_records(got[key], exp[key], key, tol=2e-3)
+
+
+def test_single_block_api_matches_reference_values():
+    """get_raw_predictions(_batch) / predict_with_thresholds against the reference's values (REAL forward, g10)."""
+
+    meta = json.loads((GOLDEN_DIR / "g10_raw_predictions.json").read_text(encoding="utf-8"))
+    model = _model_from_meta(meta)
+    exp = meta["expected"]
+    queries, batch, thresholds = meta["queries"], meta["contexts_batch"], meta["thresholds"]
+
+    def check(pred, ref, label):
+        assert [list(r) for r in pred.context_ranges] == ref["context_ranges"], label
+        assert abs(float(pred.ranking_score) - ref["ranking_score"]) < 1e-3, label
+        probs = np.asarray(pred.pruning_probs, dtype=np.float64)
+        want = np.asarray(ref["pruning_probs"], dtype=np.float64)
+        # the reference pads pruning_probs to the batch width (standalone.py:1820-1823); this class returns the row's
+        # real tokens only -- everything the ranges can address
+        assert ref["context_ranges"][-1][1] <= len(probs) <= len(want), label
+        assert np.abs(probs - want[: len(probs)]).max() < 1e-3, label
+
+    for i, pred in enumerate(model.get_raw_predictions_batch(queries[0], batch)):
+        check(pred, exp["shared_query"][i], f"shared[{i}]")
+    for i, pred in enumerate(model.get_raw_predictions_batch(queries, batch, batch_size=2)):
+        check(pred, exp["per_sample_queries"][i], f"per_sample[{i}]")
+    check(model.get_raw_predictions(queries[2], batch[2]), exp["single"], "single")
+    for key, q, ctx, kwargs in (("predict_with_thresholds_mean", queries[0], batch[0], {}),
+                                ("predict_with_thresholds_majority", queries[2], batch[2], {"use_majority": True})):
+        got = model.predict_with_thresholds(q, ctx, thresholds, **kwargs)
+        ref = exp[key]
+        assert {str(t): v for t, v in got["predictions"].items()} == ref["predictions"], key
+        assert [list(r) for r in got["context_ranges"]] == ref["context_ranges"] and got["contexts"] == ref["contexts"]
+        assert abs(got["ranking_score"] - ref["ranking_score"]) < 1e-3
+
+
+def test_sharded_forward_over_a_one_rank_nccl_group_is_bit_identical():
+    """The N > 1 code path with the real encoder and the real backend (RCCL; gpurun grants one GPU, so world_size 1):
+    partition -> HipEncoder.forward_rows -> ShardPlan.gather over NCCL -> reorder, bit-identical to the plain call."""
+
+    import os
+
+    import torch.distributed as dist
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.sharding import sharded_forward
+
+    arrays, meta = load_golden("g1_xsmall")
+    dims = dims_from_meta(meta)
+    enc = HipEncoder(dims, device="cuda:0")
+    enc.load_state_dict(state_from_fixture(arrays, meta))
+    rows = rows_from_fixture(arrays)
+    prune, rank, cu = enc.forward_rows(rows)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        per_row, all_rank = sharded_forward(rows, enc.forward_rows, dst=0)
+        torch.cuda.synchronize()
+        assert torch.equal(all_rank, rank)
+        for i in range(len(rows)):
+            assert torch.equal(per_row[i], prune[cu[i] : cu[i + 1]]), i
+    finally:
+        dist.destroy_process_group()

@@ -72,3 +72,74 @@ def test_sharded_forward_gloo_matches_single_process(tmp_path, world):
     assert torch.equal(got["rank"], rank)
     for i in range(len(rows)):
         assert torch.equal(got["per_row"][i], prune[cu[i] : cu[i + 1]]), i
+
+
+def test_shard_plan_round_trip_vectorised():
+    from open_provence_amd.sharding import ShardPlan
+
+    rng = np.random.default_rng(3)
+    lengths = [int(n) for n in rng.integers(0, 50, size=23)]
+    for world in (1, 2, 5):
+        for width, nl in ((1, 1), (2, 3)):
+            plan = ShardPlan(lengths, world, width=width, num_labels=nl)
+            total = sum(lengths)
+            values = torch.arange(total * width, dtype=torch.float32).reshape(total, width)
+            ranks = torch.arange(len(lengths) * nl, dtype=torch.float32).reshape(len(lengths), nl) + 0.5
+            cu = np.concatenate([[0], np.cumsum(lengths)])
+            bucket = []
+            for r in range(world):
+                mine = plan.local_rows(r)
+                v = torch.cat([values[cu[i] : cu[i + 1]] for i in mine]) if mine else torch.zeros((0, width))
+                bucket.append(plan.pack(r, v, ranks[mine] if mine else torch.zeros((0, nl))))
+            tok, rk = plan.unpack(torch.cat(bucket))
+            assert torch.equal(tok, values) and torch.equal(rk, ranks)
+
+
+def _process_worker(rank, world, port, out_path):
+    """process() with the golden stub forward on every rank of a gloo group: rank 0's result must equal the
+    single-process result exactly; the other ranks return None."""
+
+    import json
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from helpers import GOLDEN_DIR, CharTokenizer, golden_stub_forward, host_only_model, period_splitter
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        meta = json.loads((GOLDEN_DIR / "g3_process_stub.json").read_text(encoding="utf-8"))
+        model = host_only_model(tokenizer=CharTokenizer(), max_length=meta["max_length"], forward=golden_stub_forward)
+        model.attach_process_group(None, dst=0)
+        results = []
+        for case in meta["cases"]:
+            res = model.process(question=case["question"], context=case["context"], sentence_splitter=period_splitter,
+                                show_progress=False, return_sentence_metrics=True, return_sentence_texts=True, batch_size=4,
+                                **case["kwargs"])
+            if rank == 0:
+                res.pop("timing")
+                res.pop("performance_trace")
+                results.append(res)
+            else:
+                assert res is None
+        if rank == 0:
+            torch.save(results, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_process_sharded_over_two_gloo_ranks_matches_golden(tmp_path):
+    import json
+
+    from helpers import GOLDEN_DIR, assert_process_result_matches
+
+    out_path = str(tmp_path / "proc.pt")
+    mp.spawn(_process_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    results = torch.load(out_path, weights_only=False)
+    meta = json.loads((GOLDEN_DIR / "g3_process_stub.json").read_text(encoding="utf-8"))
+    assert len(results) == len(meta["cases"])
+    for res, case in zip(results, meta["cases"]):
+        assert_process_result_matches(res, case["expected"], prob_tol=1e-6, score_tol=1e-6)
