@@ -267,7 +267,16 @@ def tokenize_sentences(tokenizer: Any, sentences: Sequence[str]) -> list[list[in
             encoded = dict(encoded)
         except Exception:
             return []
-    return [[int(t) for t in ids] for ids in encoded.get("input_ids", [])]
+    return [_int_list(ids) for ids in encoded.get("input_ids", [])]
+
+
+def _int_list(ids: Any) -> list[int]:
+    """``[int(t) for t in ids]`` without the per-token call when ``ids`` already is a list of Python ints (what HF
+    fast tokenizers and this module's own stages hand over): the hot loops below copy ~500 ids per context."""
+
+    if type(ids) is list and (not ids or (type(ids[0]) is int and type(ids[-1]) is int)):
+        return ids
+    return [int(t) for t in ids]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -283,11 +292,11 @@ def split_token_lists(
     step = max(1, int(max_fragment_tokens))
     out: list[tuple[list[int], int, int, int]] = []
     for sentence_index, ids in enumerate(token_lists):
-        tokens = list(ids)
+        tokens = ids if type(ids) is list else list(ids)
         if not tokens:
             continue
         if keep_sentence_boundaries and len(tokens) <= max_fragment_tokens:
-            out.append((tokens, sentence_index, 0, len(out)))
+            out.append((tokens[:], sentence_index, 0, len(out)))
             continue
         for fragment_index, start in enumerate(range(0, len(tokens), step)):
             out.append((tokens[start : start + step], sentence_index, fragment_index, len(out)))
@@ -307,7 +316,7 @@ def fragmentize(
     dropped, and if that empties the context the first fragment is resurrected."""
 
     pieces = split_token_lists(
-        [[int(t) for t in ids] for ids in token_lists],
+        [_int_list(ids) for ids in token_lists],
         max_fragment_tokens,
         keep_sentence_boundaries=respect_sentence_boundaries,
     )
@@ -323,7 +332,7 @@ def fragmentize(
         shown = text.strip() if strip_sentences else text
         if not (shown if strip_sentences else text):
             continue
-        records.append(FragmentRecord(shown, s_idx, f_idx, g_idx, len(tokens), list(tokens)))
+        records.append(FragmentRecord(shown, s_idx, f_idx, g_idx, len(tokens), tokens))  # `tokens` is this piece's own slice
     if not records:
         tokens, s_idx, f_idx, g_idx = pieces[0]
         text = tokenizer.decode(tokens, skip_special_tokens=True, clean_up_tokenization_spaces=False)
@@ -438,11 +447,11 @@ def prepare_block_inputs(
 ) -> tuple[list[int], list[int], list[int], list[tuple[int, int]]]:
     """(input_ids, attention_mask, token_type_ids, token range of every fragment inside input_ids)."""
 
-    query = list(map(int, query_tokens))
+    query = _int_list(query_tokens)
     ctx: list[int] = []
     for frag in fragments:
-        ctx.extend(map(int, frag.token_ids))
-    built = list(map(int, tokenizer.build_inputs_with_special_tokens(query, ctx)))
+        ctx.extend(_int_list(frag.token_ids))
+    built = _int_list(tokenizer.build_inputs_with_special_tokens(query, ctx))
 
     if manual_specials:
         ids: list[int] = []
@@ -459,7 +468,7 @@ def prepare_block_inputs(
 
     try:
         type_ids = tokenizer.create_token_type_ids_from_sequences(query, ctx)
-        type_ids = list(map(int, type_ids)) if type_ids is not None else None
+        type_ids = _int_list(type_ids) if type_ids is not None else None
     except Exception:
         type_ids = None
 
@@ -585,11 +594,18 @@ def score_fragments(state: ContextState, use_best_reranker_score: bool) -> tuple
     per_fragment: dict[int, list[float]] = defaultdict(list)
     ranking: float | None = None
     ordered = sorted(state.raw_blocks, key=lambda item: item[0])
+    # offsets[k] = sum(prefix_token_counts[:k]) (a slice past the end sums everything), computed once per context
+    counts = state.prefix_token_counts
+    offsets = [0]
+    for c in counts:
+        offsets.append(offsets[-1] + c)
+    last = len(counts)
     for (_, raw), block in zip(ordered, state.blocks):
         probs = raw.pruning_probs
         n = len(probs)
         for fragment, (start, end) in zip(block, raw.context_ranges):
-            offset = sum(state.prefix_token_counts[: fragment.sentence_index])
+            k = fragment.sentence_index
+            offset = offsets[k if k < last else last] if k > 0 else 0
             start = max(0, start - offset)
             end = max(start, end - offset)
             end = min(end, n)
