@@ -133,6 +133,30 @@ def _load_checkpoint_tensors(directory: Path) -> dict[str, torch.Tensor]:
     raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {directory}")
 
 
+def resolve_pruning_hidden_state(config: OpenProvenceConfig, override: str | None = None) -> str:
+    """Which hidden state the pruning head reads: ``"post_final_norm"`` or ``"pre_final_norm"``.
+
+    The reference feeds ``outputs.hidden_states[-1]`` of the HF backbone to the head (standalone.py:1695).  Under
+    transformers >= 5 that entry is tied to ``last_hidden_state`` = the ``final_norm`` output
+    (utils/output_capturing.py:269-277); the 4.x line the reference pins (uv.lock: 4.57.1) appended the last layer's
+    output BEFORE ``final_norm`` -- so a released checkpoint's head was trained on, and the reference under its own
+    lock evaluates, the un-normalised state.  Order of precedence: the ``pruning_hidden_state`` argument, the config
+    field of the same name, then ``"auto"``: the ``transformers_version`` HF wrote into the checkpoint's config.json
+    (major < 5 -> pre-norm), and post-norm -- what the reference computes in this image -- when nothing is recorded."""
+
+    choice = override or getattr(config, "extra", {}).get("pruning_hidden_state") or "auto"
+    if choice in ("post_final_norm", "pre_final_norm"):
+        return choice
+    if choice != "auto":
+        raise ValueError("pruning_hidden_state must be 'auto', 'post_final_norm' or 'pre_final_norm'")
+    version = str(getattr(config, "extra", {}).get("transformers_version") or "")
+    try:
+        major = int(version.split(".")[0])
+    except ValueError:
+        return "post_final_norm"
+    return "pre_final_norm" if major < 5 else "post_final_norm"
+
+
 class OpenProvenceModel:
     """Reranker + pruning head on hand-written gfx950 kernels, with the reference's public API."""
 
@@ -151,6 +175,7 @@ class OpenProvenceModel:
         precision: str | None = None,
         torch_dtype: Any | None = None,
         chunk_rows: int | None = None,
+        pruning_hidden_state: str | None = None,
     ) -> None:
         self.config = config
         self.max_length = int(config.max_length)
@@ -170,7 +195,11 @@ class OpenProvenceModel:
         self.precision = precision or _precision_from_dtype(torch_dtype)
         if chunk_rows is None and os.getenv("OPEN_PROVENCE_CHUNK_ROWS"):
             chunk_rows = int(os.environ["OPEN_PROVENCE_CHUNK_ROWS"])
-        self.encoder = HipEncoder(self.dims, device=self._runtime_device, precision=self.precision, chunk_rows=chunk_rows)
+        self.pruning_hidden_state = resolve_pruning_hidden_state(config, pruning_hidden_state)
+        self.encoder = HipEncoder(
+            self.dims, device=self._runtime_device, precision=self.precision, chunk_rows=chunk_rows,
+            prune_pre_final_norm=self.pruning_hidden_state == "pre_final_norm",
+        )
         if state_dict is not None:
             self.load_state_dict(state_dict)
         self.tokenizer = tokenizer if tokenizer is not None else self._init_tokenizer(config)
@@ -295,9 +324,9 @@ class OpenProvenceModel:
         """Write a checkpoint directory in the reference's format (writer: encoder.py:1040-1094; reader:
         standalone.py:1557-1664 and :func:`from_pretrained` here): ``config.json`` with the OpenProvence fields plus
         ``architectures`` / ``auto_map`` / ``vocab_size`` / ``hidden_size``, ``model.safetensors`` with the prefixed
-        tensors, and the tokenizer's own files.  The reference additionally copies its standalone modeling file
-        next to the weights for ``AutoModel(trust_remote_code=True)``; that file belongs to the reference package and
-        is not reproduced here."""
+        tensors, the tokenizer's own files, and -- where the reference copies its standalone modeling file for
+        ``AutoModel.from_pretrained(dir, trust_remote_code=True)`` -- a freshly written module of the same name that
+        re-exports THIS implementation (open_provence_amd/hf_auto.py)."""
 
         directory = Path(save_directory)
         directory.mkdir(parents=True, exist_ok=True)
@@ -313,6 +342,7 @@ class OpenProvenceModel:
         payload["vocab_size"] = base.get("vocab_size", self.dims.vocab_size)
         payload["hidden_size"] = base.get("hidden_size", self.dims.hidden_size)
         payload["architectures"] = ["OpenProvenceForSequenceClassification"]
+        payload["pruning_hidden_state"] = self.pruning_hidden_state  # explicit: no transformers-version guess on reload
         module = "modeling_open_provence_standalone"
         payload["auto_map"] = {
             "AutoConfig": f"{module}.OpenProvenceConfig",
@@ -331,6 +361,7 @@ class OpenProvenceModel:
         saver = getattr(self.tokenizer, "save_pretrained", None)
         if callable(saver):
             saver(str(directory))
+        (directory / "modeling_open_provence_standalone.py").write_text(_remote_code_shim_source(), encoding="utf-8")
 
     @classmethod
     def from_pretrained(
@@ -353,11 +384,21 @@ class OpenProvenceModel:
             raise FileNotFoundError(
                 f"{pretrained_model_name_or_path!r} is not a local checkpoint directory (hub download is unavailable)"
             )
-        config = OpenProvenceConfig.from_json_file(directory / "config.json")
+        auto_config = kwargs.pop("config", None)  # AutoModel.from_pretrained passes the AutoConfig result along
+        if auto_config is not None and hasattr(auto_config, "to_native"):
+            config = auto_config.to_native()
+        elif isinstance(auto_config, OpenProvenceConfig):
+            config = auto_config
+        else:
+            config = OpenProvenceConfig.from_json_file(directory / "config.json")
         config._name_or_path = str(directory)
         if "dtype" in kwargs and torch_dtype is None:
             torch_dtype = kwargs.pop("dtype")
-        kwargs.pop("attn_implementation", None)  # HF knob; the HIP attention kernel is the only implementation
+        # HF plumbing the Auto* factories add; the HIP attention kernel is the only attention implementation
+        for hf_only in ("attn_implementation", "_from_auto", "adapter_kwargs", "cache_dir", "force_download", "local_files_only",
+                        "proxies", "revision", "subfolder", "token", "code_revision", "_commit_hash", "low_cpu_mem_usage",
+                        "device_map", "quantization_config"):
+            kwargs.pop(hf_only, None)
         if max_length is not None:
             config.max_length = int(max_length)
         state = _load_checkpoint_tensors(directory)
@@ -369,6 +410,7 @@ class OpenProvenceModel:
             torch_dtype=torch_dtype,
             precision=kwargs.pop("precision", None),
             chunk_rows=kwargs.pop("chunk_rows", None),
+            pruning_hidden_state=kwargs.pop("pruning_hidden_state", None),
         )
         if max_length is not None:
             model.max_length = int(max_length)
@@ -426,6 +468,13 @@ class OpenProvenceModel:
 
     def __call__(self, *args: Any, **kwargs: Any):
         return self.forward(*args, **kwargs)
+
+    @classmethod
+    def register_for_auto_class(cls, auto_class: Any = "AutoModel") -> None:
+        """``AutoModel.from_pretrained(..., trust_remote_code=True)`` calls this on the class it resolved through
+        ``auto_map`` (transformers auto_factory); the HIP classes keep no per-class registry."""
+
+        cls._auto_class = getattr(auto_class, "__name__", auto_class)
 
     def _forward_is_native(self) -> bool:
         """True unless ``forward`` was overridden / monkeypatched (the reference's tests do that, and the
@@ -1304,6 +1353,12 @@ class OpenProvenceModel:
         if info and info["world"] > 1 and info["rank"] != info["dst"]:
             return None  # type: ignore[return-value]  # only the gather's destination rank holds the forward outputs
         return payload
+
+
+def _remote_code_shim_source() -> str:
+    from .hf_auto import SHIM_SOURCE
+
+    return SHIM_SOURCE
 
 
 class OpenProvenceForSequenceClassification(OpenProvenceModel):

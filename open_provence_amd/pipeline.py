@@ -417,11 +417,24 @@ def requires_manual_special_tokens(tokenizer: Any) -> bool:
         return False
     if not q or not c:
         return False
-    built = [int(t) for t in tokenizer.build_inputs_with_special_tokens(q, c)]
+    built = [int(t) for t in build_inputs_with_special_tokens(tokenizer, q, c)]
     cls_c, sep_c = special_token_candidates(tokenizer)
     missing_cls = bool(cls_c) and not any(t in cls_c for t in built)
     missing_sep = bool(sep_c) and not any(t in sep_c for t in built)
     return missing_cls or missing_sep
+
+
+def build_inputs_with_special_tokens(tokenizer: Any, first: Sequence[int], second: Sequence[int]) -> Sequence[int]:
+    """``tokenizer.build_inputs_with_special_tokens(first, second)`` as the reference calls it (standalone.py:1513,
+    2114).  transformers >= 5 removed that method from the fast-tokenizer class; what the generic
+    ``PreTrainedTokenizerFast`` of the 4.x line (the reference's pin) returned for it is the plain concatenation with NO
+    special tokens -- the very case the reference's manual CLS/SEP path exists for (:1501-1538) -- so that is the
+    answer for a tokenizer without the method."""
+
+    method = getattr(tokenizer, "build_inputs_with_special_tokens", None)
+    if callable(method):
+        return method(first, second)
+    return list(first) + list(second or [])
 
 
 def _find_subsequence(haystack: Sequence[int], needle: Sequence[int]) -> int:
@@ -451,7 +464,7 @@ def prepare_block_inputs(
     ctx: list[int] = []
     for frag in fragments:
         ctx.extend(_int_list(frag.token_ids))
-    built = _int_list(tokenizer.build_inputs_with_special_tokens(query, ctx))
+    built = _int_list(build_inputs_with_special_tokens(tokenizer, query, ctx))
 
     if manual_specials:
         ids: list[int] = []
@@ -476,7 +489,7 @@ def prepare_block_inputs(
     if ctx:
         start = _find_subsequence(ids, ctx)
         if start < 0:
-            start = len(tokenizer.build_inputs_with_special_tokens(query, []))
+            start = len(build_inputs_with_special_tokens(tokenizer, query, []))
         cursor = start
         for frag in fragments:
             ranges.append((cursor, cursor + len(frag.token_ids)))

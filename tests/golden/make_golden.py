@@ -35,7 +35,7 @@ REPO = HERE.parents[1]
 sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
-from helpers import CharTokenizer, period_splitter  # noqa: E402
+from helpers import WORDPIECE_CASES, CharTokenizer, build_wordpiece_tokenizer, period_splitter, wordpiece_vocab  # noqa: E402
 
 from open_provence_amd.config import EncoderDims  # noqa: E402
 from open_provence_amd.synthetic import refinit_state_dict, synth_state_dict  # noqa: E402
@@ -506,6 +506,54 @@ def mldr_fixture(name: str, cfg: dict[str, Any], *, max_length: int) -> None:
     print(f"[golden] {name}: {[(r['label'], len(r['expected']['records'])) for r in runs]}")
 
 
+def wordpiece_fixture(name: str, cfg: dict[str, Any], *, weight_seed: int, max_length: int, stub: bool) -> None:
+    """G11: process() through the reference with a REAL Hugging Face fast tokenizer (WordPiece over a fixed vocabulary,
+    tests/helpers.py:build_wordpiece_tokenizer), once with a tokenizer that emits [CLS]/[SEP] itself and once with one
+    that does not -- the reference's manual special-token path (standalone.py:1501-1538, 2123-2135).  ``stub`` as G3."""
+
+    variants = []
+    for emit in (True, False):
+        ref = load_reference(emit_specials=True)
+        ref.AutoTokenizer.from_pretrained = staticmethod(lambda *_a, _emit=emit, **_k: build_wordpiece_tokenizer(_emit))
+        model, _dims = build_model(ref, cfg, max_length=max_length, seed=0, weight_seed=weight_seed)
+        assert bool(model._manual_special_tokens_required) == (not emit)
+        if stub:
+
+            def stub_forward(input_ids=None, attention_mask=None, **_kw):
+                b, length = input_ids.shape
+                pos = torch.arange(length, dtype=torch.float32)[None, :].expand(b, length)
+                tok = input_ids.to(torch.float32)
+                keep = torch.sin(0.37 * pos + 0.011 * tok) * 3.0
+                prune = torch.stack([torch.zeros_like(keep), keep], dim=-1)
+                rank = (input_ids.sum(dim=1, keepdim=True).to(torch.float32) % 17.0) / 4.0 - 2.0
+                return {"ranking_logits": rank, "pruning_logits": prune}
+
+            model.forward = stub_forward  # type: ignore[method-assign]
+        cases_out = []
+        for case in WORDPIECE_CASES:
+            kwargs = dict(case["kwargs"])
+            with torch.no_grad():
+                result = model.process(question=case["question"], context=case["context"], sentence_splitter=period_splitter,
+                                       show_progress=False, return_sentence_metrics=True, return_sentence_texts=True,
+                                       batch_size=4, **kwargs)
+            result.pop("timing")
+            result.pop("performance_trace")
+            if not stub:
+                margin = _sentence_margin(_jsonable(result["sentence_probabilities"]), kwargs["threshold"])
+                assert margin > 5e-3, (case["case"], emit, margin)
+            cases_out.append({"case": case["case"], "kwargs": kwargs, "expected": _jsonable(result)})
+        variants.append({"emit_specials": emit, "manual_special_tokens_required": not emit, "cases": cases_out})
+    meta = {
+        "name": name, "base_model_config": cfg, "num_labels": 1, "weight_seed": weight_seed, "weight_init": "synth",
+        "max_length": max_length, "stub_forward": stub, "vocab_size_tokenizer": len(wordpiece_vocab()), "variants": variants,
+        "generator": "tests/golden/make_golden.py (reference OpenProvenceModel.process with a PreTrainedTokenizerFast built "
+                     "offline; 4.x build_inputs_with_special_tokens semantics restored by tests/helpers.py)",
+        "versions": versions(),
+    }
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1, sort_keys=True, ensure_ascii=False))
+    print(f"[golden] {name}: {[(v['emit_specials'], len(v['cases'])) for v in variants]}")
+
+
 def _load_script(ref, name: str):
     """Import one of the reference's scripts (scripts/eval_datasets.py, scripts/eval_mldr.py) with `open_provence`
     resolving to the standalone module, `litellm` (absent; LLM-judge half only) stubbed and `datetime.UTC` aliased."""
@@ -743,10 +791,71 @@ def splitter_fixture(name: str) -> None:
     print(f"[golden] {name}: {[len(o) for o in runs[0]['outputs']]}")
 
 
+def check_writer(report_name: str = "check_writer_report") -> None:
+    """Row f4: a checkpoint written by ``open_provence_amd``'s ``save_pretrained`` is read back by the REFERENCE --
+    its OpenProvenceConfig parses config.json, its OpenProvenceModel takes model.safetensors with strict key matching,
+    and its forward on those weights equals the oracle.  Also records what the reference's own ``from_pretrained`` does
+    with the directory under this image's transformers (it fails: an incompatibility of the reference with
+    transformers >= 5, not of the checkpoint).  Writes tests/golden/<report_name>.json."""
+
+    import tempfile
+
+    from safetensors.torch import load_file
+
+    from open_provence_amd import modeling
+    from open_provence_amd.config import OpenProvenceConfig as NativeConfig
+    from oracle.modernbert_oracle import oracle_forward
+
+    cfg = base_cfg(vocab_size=256, hidden_size=128, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2, local_attention=32)
+    dims = EncoderDims.from_base_model_config(cfg, num_labels=1)
+    state = synth_state_dict(dims, 41)
+    native = NativeConfig(base_model_config=cfg, tokenizer_name_or_path="char-tokenizer", pruning_config={"hidden_size": 128},
+                          max_length=96, default_threadshold=0.2)
+    writer = modeling.OpenProvenceModel.__new__(modeling.OpenProvenceModel)  # writer only: no GPU in this container
+    writer.config, writer.max_length, writer.num_labels, writer.dims = native, 96, 1, dims
+    writer.tokenizer, writer._weights, writer.pruning_hidden_state = CharTokenizer(), dict(state), "post_final_norm"
+    report: dict[str, Any] = {"generator": "tests/golden/make_golden.py --check-writer", "versions": versions()}
+    with tempfile.TemporaryDirectory() as tmp:
+        writer.save_pretrained(tmp)
+        ref = load_reference(emit_specials=True)
+        ref_cfg = ref.OpenProvenceConfig.from_pretrained(tmp)
+        report["reference_config_reads"] = {"max_length": ref_cfg.max_length, "num_labels": ref_cfg.num_labels,
+                                            "hidden_size": ref_cfg.base_model_config["hidden_size"],
+                                            "default_threadshold": getattr(ref_cfg, "default_threadshold", None)}
+        torch.manual_seed(0)
+        model = ref.OpenProvenceModel(ref_cfg)
+        saved = load_file(str(Path(tmp) / "model.safetensors"))
+        missing, unexpected = model.load_state_dict(saved, strict=False)
+        report["strict_load"] = {"missing": [k for k in missing if "inv_freq" not in k], "unexpected": list(unexpected)}
+        model.eval()
+        ids, mask = make_rows(dims, [96, 40, 77], 1234)
+        with torch.no_grad():
+            out = model(input_ids=ids, attention_mask=mask)
+        orc = oracle_forward(state, dims, ids, mask)
+        m = mask.bool()
+        report["reference_on_written_checkpoint_vs_oracle"] = {
+            "max_abs_prune": float((out.pruning_logits - orc.pruning_logits)[m].abs().max()),
+            "max_abs_rank": float((out.ranking_logits - orc.ranking_logits).abs().max()),
+        }
+        try:
+            ref.OpenProvenceModel.from_pretrained(tmp, device="cpu")
+            report["reference_from_pretrained"] = "ok"
+        except Exception as exc:  # noqa: BLE001
+            report["reference_from_pretrained"] = f"{type(exc).__name__}: {str(exc)[:300]}"
+    (HERE / f"{report_name}.json").write_text(json.dumps(report, indent=1, sort_keys=True))
+    print(json.dumps(report, indent=1))
+    assert not report["strict_load"]["missing"] and not report["strict_load"]["unexpected"]
+    assert report["reference_on_written_checkpoint_vs_oracle"]["max_abs_prune"] < 5e-5
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--only", nargs="*", default=None)
+    parser.add_argument("--check-writer", action="store_true")
     args = parser.parse_args()
+    if args.check_writer:
+        check_writer()
+        return
 
     def want(name: str) -> bool:
         return args.only is None or name in args.only
@@ -844,6 +953,11 @@ def main() -> None:
         mldr_fixture("g5_mldr_records", g3_cfg, max_length=96)
     if want("g6_english_splitter"):
         splitter_fixture("g6_english_splitter")
+    wp_cfg = base_cfg(vocab_size=256, hidden_size=128, intermediate_size=128, num_hidden_layers=4, num_attention_heads=2, local_attention=32)
+    if want("g11_process_wordpiece_stub"):
+        wordpiece_fixture("g11_process_wordpiece_stub", wp_cfg, weight_seed=43, max_length=64, stub=True)
+    if want("g11_process_wordpiece_model"):
+        wordpiece_fixture("g11_process_wordpiece_model", wp_cfg, weight_seed=43, max_length=64, stub=False)
     if want("g4m_eval_dataset_model"):
         eval_model_fixture("g4m_eval_dataset_model", g3_cfg, max_length=96, weight_seed=41)
     if want("g10_raw_predictions"):

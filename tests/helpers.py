@@ -219,3 +219,76 @@ def assert_process_result_matches(result, expected, *, prob_tol: float, score_to
     walk(result["compression_rate"], expected["compression_rate"], "compression_rate", 1e-9)
     walk(result["sentence_probabilities"], expected["sentence_probabilities"], "sentence_probabilities", prob_tol)
     walk(result["reranking_score"], expected["reranking_score"], "reranking_score", score_tol)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A REAL Hugging Face fast tokenizer, built offline: WordPiece over a fixed vocabulary (no training, so the same
+# object is rebuilt bit for bit wherever this file runs).  Two variants, as the reference distinguishes them
+# (standalone.py:1501-1538): ``emit_specials=True`` = a BertTokenizerFast-like tokenizer whose
+# build_inputs_with_special_tokens adds [CLS] / [SEP]; ``False`` = the generic PreTrainedTokenizerFast of transformers
+# 4.x (e.g. gte-ModernBERT's), whose build_inputs_with_special_tokens is the bare concatenation and forces the
+# reference's manual special-token path.  transformers >= 5 dropped both methods from the fast-tokenizer class; the
+# subclass below restores the 4.x behaviour the reference was written against (its uv.lock pins 4.57.1).
+# ---------------------------------------------------------------------------------------------------------------
+_WP_WORDS = ("the tower is tall river rivers flow to sea bread made from flour it was built long ago many people visit what "
+             "how do carry water and silt a cat cats purr dogs bark mountains are which in of for on with that this there "
+             "high old new small large city north south bridge harbour boats fish salt stone wood king year years").split()
+_WP_PIECES = ["##" + c for c in "setanroildmpchgbfkwyvxzqju"] + ["##ed", "##ing", "##er", "##ly", "##es"]
+_WP_CHARS = list("abcdefghijklmnopqrstuvwxyz0123456789.,!?;:'\"-()")
+
+
+def wordpiece_vocab() -> dict[str, int]:
+    vocab: dict[str, int] = {}
+    for tok in ["[PAD]", "[CLS]", "[SEP]", "[UNK]", "[MASK]"] + _WP_CHARS + _WP_PIECES + _WP_WORDS:
+        vocab.setdefault(tok, len(vocab))
+    return vocab
+
+
+def build_wordpiece_tokenizer(emit_specials: bool, legacy_methods: bool = True):
+    """``legacy_methods=False`` returns the plain transformers >= 5 object (no build_inputs_with_special_tokens)."""
+
+    from tokenizers import Tokenizer, decoders, models, normalizers, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+
+    tok = Tokenizer(models.WordPiece(vocab=wordpiece_vocab(), unk_token="[UNK]", continuing_subword_prefix="##"))
+    tok.normalizer = normalizers.Lowercase()
+    tok.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tok.decoder = decoders.WordPiece(prefix="##", cleanup=False)
+    if emit_specials:
+        tok.post_processor = processors.TemplateProcessing(
+            single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1", special_tokens=[("[CLS]", 1), ("[SEP]", 2)]
+        )
+
+    class WordPieceFast4x(PreTrainedTokenizerFast):
+        def build_inputs_with_special_tokens(self, token_ids_0, token_ids_1=None):
+            second = list(token_ids_1 or [])
+            if not emit_specials:  # transformers 4.x PreTrainedTokenizerBase default
+                return list(token_ids_0) + second
+            out = [self.cls_token_id, *token_ids_0, self.sep_token_id]  # 4.x BertTokenizerFast
+            return out + second + [self.sep_token_id] if second else out
+
+        def create_token_type_ids_from_sequences(self, token_ids_0, token_ids_1=None):
+            second = list(token_ids_1 or [])
+            if not emit_specials:
+                return [0] * len(token_ids_0) + [1] * len(second)
+            first = [0] * (len(token_ids_0) + 2)
+            return first + [1] * (len(second) + 1) if second else first
+
+    cls = WordPieceFast4x if legacy_methods else PreTrainedTokenizerFast
+    return cls(tokenizer_object=tok, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
+               mask_token="[MASK]", model_max_length=512)
+
+
+WORDPIECE_CASES = [
+    dict(case="wp_single", question="How tall is the tower?",
+         context="The tower is tall. It was built long ago! Many people visit it. Bread is made from flour.",
+         kwargs=dict(threshold=0.5)),
+    dict(case="wp_docs_titles", question=["what do rivers carry?", "which city is old?"],
+         context=[["Rivers flow to the sea. Mountains are tall. Rivers carry water and silt.",
+                   "The old bridge is made of stone. Boats carry fish and salt."],
+                  ["There is a small city in the north. The king built a harbour. Many years ago it was new."]],
+         kwargs=dict(threshold=0.45, title=[["Rivers", "The bridge"], ["North city"]])),
+    dict(case="wp_long_multiblock", question="Which boats carry salt?",
+         context=" ".join(f"In year {i} the boats carry fish and salt to the harbour of the north city." for i in range(30)),
+         kwargs=dict(threshold=0.5)),
+]

@@ -35,6 +35,7 @@ def _writer_only_model(state, config, tokenizer):
     model.dims = EncoderDims.from_base_model_config(BASE, num_labels=1)
     model.tokenizer = tokenizer
     model._weights = dict(state)
+    model.pruning_hidden_state = "post_final_norm"
     return model
 
 
@@ -45,7 +46,8 @@ def test_save_pretrained_writes_the_reference_format(tmp_path):
                                 max_length=96, default_threadshold=0.2, some_future_key="kept")
     model = _writer_only_model(state, config, SavingTokenizer())
     model.save_pretrained(tmp_path)
-    assert sorted(p.name for p in tmp_path.iterdir()) == ["config.json", "model.safetensors", "tokenizer_config.json"]
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["config.json", "model.safetensors",
+                                                          "modeling_open_provence_standalone.py", "tokenizer_config.json"]
 
     payload = json.loads((tmp_path / "config.json").read_text(encoding="utf-8"))
     assert payload["model_type"] == "open_provence" and payload["mode"] == "reranking_pruning"
@@ -76,3 +78,62 @@ def test_state_dict_requires_loaded_weights_and_bin_format(tmp_path):
     model.save_pretrained(tmp_path, safe_serialization=False)
     loaded = torch.load(str(tmp_path / "pytorch_model.bin"), map_location="cpu", weights_only=True)
     assert set(loaded) == set(model._weights)
+
+
+def test_auto_classes_resolve_to_the_hip_classes(tmp_path, monkeypatch):
+    """The reference's documented entry is AutoModel.from_pretrained(id, trust_remote_code=True) through `auto_map`
+    (README.md:53-74, standalone.py:3814-3906).  Both routes must land on the HIP classes: registered Auto* classes,
+    and the remote-code module save_pretrained writes under the name the auto_map points to.  (CPU: the classes'
+    from_pretrained is intercepted -- constructing the model needs a GPU; tests/test_gpu_model.py loads for real.)"""
+
+    from transformers import AutoConfig, AutoModel, AutoModelForTokenClassification
+
+    from open_provence_amd import hf_auto
+
+    monkeypatch.setenv("HF_MODULES_CACHE", str(tmp_path / "hf_modules"))
+    import transformers.dynamic_module_utils as dmu
+
+    monkeypatch.setattr(dmu, "HF_MODULES_CACHE", str(tmp_path / "hf_modules"))
+    dims = EncoderDims.from_base_model_config(BASE, num_labels=1)
+    config = OpenProvenceConfig(base_model_config=BASE, tokenizer_name_or_path="char", pruning_config={"hidden_size": 128},
+                                max_length=96, default_threadshold=0.2)
+    ckpt = tmp_path / "ckpt"
+    _writer_only_model(synth_state_dict(dims, 41), config, SavingTokenizer()).save_pretrained(ckpt)
+
+    calls = []
+
+    def fake_from_pretrained(cls, path, *args, **kwargs):
+        calls.append((cls.__name__, hasattr(kwargs.get("config"), "to_native"), kwargs["config"].to_native().max_length))
+        return cls.__name__
+
+    monkeypatch.setattr(modeling.OpenProvenceModel, "from_pretrained", classmethod(fake_from_pretrained))
+
+    # route 1: registered classes, no remote code
+    hf_auto.register_auto_classes()
+    cfg = AutoConfig.from_pretrained(str(ckpt))
+    assert type(cfg) is hf_auto.OpenProvenceHFConfig and cfg.to_native().encoder_dims() == dims
+    assert cfg.to_native().default_threshold == 0.2 and cfg.to_native().extra.get("pruning_hidden_state") == "post_final_norm"
+    assert AutoModel.from_pretrained(str(ckpt)) == "OpenProvenceForSequenceClassification"
+    assert AutoModelForTokenClassification.from_pretrained(str(ckpt)) == "OpenProvenceForTokenClassification"
+
+    # route 2: trust_remote_code=True through the auto_map -> the module written next to the weights
+    assert AutoModel.from_pretrained(str(ckpt), trust_remote_code=True) == "OpenProvenceForSequenceClassification"
+    assert [c[0] for c in calls] == ["OpenProvenceForSequenceClassification", "OpenProvenceForTokenClassification",
+                                     "OpenProvenceForSequenceClassification"]
+    assert all(c[1] and c[2] == 80 for c in calls)
+
+
+def test_reference_reads_the_written_checkpoint_report():
+    """tests/golden/check_writer_report.json is produced by `make_golden.py --check-writer` in the build container (the
+    reference is importable there): the reference's config class parses the written config.json, its model takes the
+    written model.safetensors with strict key matching and reproduces the oracle.  (Its own from_pretrained raises
+    under transformers 5.15 -- `all_tied_weights_keys` -- for ANY checkpoint directory: recorded, not a format issue.)"""
+
+    from helpers import GOLDEN_DIR
+
+    report = json.loads((GOLDEN_DIR / "check_writer_report.json").read_text(encoding="utf-8"))
+    assert report["strict_load"] == {"missing": [], "unexpected": []}
+    assert report["reference_config_reads"] == {"max_length": 96, "num_labels": 1, "hidden_size": 128, "default_threadshold": 0.2}
+    assert report["reference_on_written_checkpoint_vs_oracle"]["max_abs_prune"] < 5e-5
+    assert report["reference_on_written_checkpoint_vs_oracle"]["max_abs_rank"] < 5e-5
+    assert "all_tied_weights_keys" in report["reference_from_pretrained"]

@@ -524,3 +524,28 @@ def test_sharded_forward_over_a_one_rank_nccl_group_is_bit_identical():
             assert torch.equal(per_row[i], prune[cu[i] : cu[i + 1]]), i
     finally:
         dist.destroy_process_group()
+
+
+def test_automodel_from_pretrained_lands_on_the_hip_class(tmp_path, monkeypatch):
+    """README.md:53-74 of the reference: AutoModel.from_pretrained(dir, trust_remote_code=True).  A checkpoint written
+    by save_pretrained (auto_map + the remote-code module under the name it points to) loads through transformers'
+    AutoModel into the HIP class, and gives the same logits as the instance that wrote it."""
+
+    import transformers.dynamic_module_utils as dmu
+    from transformers import AutoModel, AutoModelForTokenClassification
+
+    from open_provence_amd.modeling import OpenProvenceForSequenceClassification, OpenProvenceForTokenClassification
+
+    monkeypatch.setattr(dmu, "HF_MODULES_CACHE", str(tmp_path / "hf_modules"))
+    model, _meta = _g3_model()
+    model.tokenizer = None  # the char tokenizer has no files; AutoModel users pass / load their own
+    model.save_pretrained(tmp_path / "ckpt")
+    ids = torch.tensor([[1, 81, 82, 2, 97, 98, 99, 46, 100, 101, 2, 0, 0], [1, 81, 2, 120, 121, 46, 2, 0, 0, 0, 0, 0, 0]])
+    mask = (ids != 0).long()
+    want = model(input_ids=ids, attention_mask=mask)
+    for auto, klass, key in ((AutoModel, OpenProvenceForSequenceClassification, "ranking_logits"),
+                             (AutoModelForTokenClassification, OpenProvenceForTokenClassification, "pruning_logits")):
+        loaded = auto.from_pretrained(str(tmp_path / "ckpt"), trust_remote_code=True, tokenizer=CharTokenizer(), device="cuda:0")
+        assert type(loaded).__name__ == klass.__name__ and type(loaded).__module__ == "open_provence_amd.modeling"
+        got = loaded(input_ids=ids, attention_mask=mask)
+        assert torch.equal(got.logits, want[key]) and torch.equal(got.ranking_logits, want.ranking_logits)
