@@ -278,11 +278,15 @@ def main() -> None:
         launches_per_forward = entry["launches"] / prof_steps
         flops_per_launch = flops_per_forward[dominant] / launches_per_forward
         achieved = flops_per_launch / (entry["avg_ms"] * 1e-3) / 1e12
+        # HBM bytes per launch from the committed PMC passes of this exact workload (scripts/rocprof_pass.sh ->
+        # scripts/collect_traffic.py); null when this workload / kernel set has not been through a PMC pass
         traffic = None
+        shape = "varlen" if args.varlen else f"{args.pairs}x{args.seq_len}"
+        traffic_key = f"{dominant}|{args.model}|{shape}|{policy['kernel_set']}"
         pmc_file = ROOT / "profiles" / "pmc_traffic.json"
         if pmc_file.exists():
             try:
-                traffic = json.loads(pmc_file.read_text()).get(f"{dominant}:{args.precision}", {}).get("hbm_bytes_per_launch")
+                traffic = json.loads(pmc_file.read_text()).get(traffic_key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {
@@ -293,6 +297,7 @@ def main() -> None:
             "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
             "traffic": traffic,
+            "traffic_key": traffic_key,
             "avg_launch_ms": entry["avg_ms"],
             "algorithmic_flops_per_launch": flops_per_launch,
             "whole_forward_tflops": whole_tflops,

@@ -32,6 +32,81 @@ constexpr int STAGE = KS * 2 * 1024;   // u16 elements per stage: [ks][plane][2 
 
 __device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+// Clock probe: N back-to-back independent MFMAs per wave (8 accumulators, operands in registers), timed with the
+// shader clock (s_memtime, counts at the current core clock) and the constant 100 MHz counter (s_memrealtime).
+//   cycles / MFMA / SIMD      -> issue rate (16 for v_mfma_f32_16x16x32_bf16 at one wave per SIMD)
+//   shader cycles / real time -> the clock the chip actually runs at under this MFMA load
+// The guide's 2.5 PFLOP/s dense bf16 peak is 1024 SIMDs x 1024 flop/cycle x 2.4 GHz; at the clock measured here the
+// ceiling of this part is 1024 x 1024 x f, which is what the TFLOP/s figures printed below should be read against.
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256 * WAVES_PER_SIMD > 1024 ? 1024 : 256 * WAVES_PER_SIMD) void clock_probe_kernel(
+    int n_iters, unsigned long long* __restrict__ out, float* __restrict__ sink) {
+  __shared__ u16 pad[48 * 1024];  // 96 KiB: one block per CU, so the block size sets the waves per SIMD
+  const int lane = threadIdx.x & 63;
+  pad[threadIdx.x] = (u16)lane;
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (__bf16)(0.001f * (float)(lane + i));
+    b[i] = (__bf16)(0.002f * (float)(lane ^ i));
+  }
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  const unsigned long long t0 = wall_clock64();
+  for (int it = 0; it < n_iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) total += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  const unsigned long long t1 = wall_clock64();
+  if (total == 123.456f) sink[threadIdx.x] = total + (float)pad[(threadIdx.x * 7) & 1023];
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = t1 - t0;
+  }
+}
+
+template <int WAVES_PER_SIMD>
+static double clock_probe(const char* label, float* sink) {
+  const int blocks = 256 * 8, n_iters = 4096;  // 8 blocks per CU queued behind each other
+  const int threads = 256 * WAVES_PER_SIMD > 1024 ? 1024 : 256 * WAVES_PER_SIMD;
+  unsigned long long* out;
+  CHECK(hipMalloc(&out, (size_t)blocks * 2 * sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((clock_probe_kernel<WAVES_PER_SIMD>), dim3(blocks), dim3(threads), 0, 0, n_iters, out, sink);
+  CHECK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL((clock_probe_kernel<WAVES_PER_SIMD>), dim3(blocks), dim3(threads), 0, 0, n_iters, out, sink);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> host((size_t)blocks * 2);
+  CHECK(hipMemcpy(host.data(), out, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double cyc = 0.0, real = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    cyc += (double)host[2 * b];
+    real += (double)host[2 * b + 1];
+  }
+  const double mfma_per_wave = (double)n_iters * 32;
+  const double waves_per_simd = threads / 256.0;
+  const double ghz = cyc / real * 0.1;  // s_memrealtime ticks at 100 MHz
+  const double flops = (double)blocks * (threads / 64) * mfma_per_wave * 16 * 16 * 32 * 2;
+  printf("%-44s %6.3f GHz shader clock, %5.2f cycles per MFMA per SIMD, %7.1f TFLOP/s by HIP events; ceiling at this clock %7.1f\n",
+         label, ghz, cyc / blocks / (mfma_per_wave * waves_per_simd), flops / ms * 1e-9, 1024.0 * 1024.0 * ghz * 1e-3);
+  CHECK(hipFree(out));
+  return ghz;
+}
+
 // STORE: 0 = no global stores; 1 = the epilogue stores 2 x 16 B per lane per chunk and the iteration ends with
 // __syncthreads() (fence: s_waitcnt vmcnt(0) covers the just-issued stores); 2 = s_waitcnt vmcnt(0) BEFORE the
 // stores (only the weight DMA issued at the top of the iteration is outstanding then) and a bare s_barrier.
@@ -445,6 +520,11 @@ int main() {
   CHECK(hipMalloc(&w, host.size() * 2));
   CHECK(hipMalloc(&sink, 4096));
   CHECK(hipMemcpy(w, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+  printf("clock probe: back-to-back v_mfma_f32_16x16x32_bf16, operands in registers, 2048 blocks\n");
+  clock_probe<1>("  1 wave per SIMD ", sink);
+  clock_probe<2>("  2 waves per SIMD", sink);
+  clock_probe<4>("  4 waves per SIMD", sink);
+  clock_probe<1>("  1 wave per SIMD (again, warm)", sink);
   printf("1024 blocks x 4 waves x 32 rows, K=256 bf16x3, 64 chunks of 32 features (one Wi GEMM of ModernBERT-xsmall)\n");
 #define CASES(V, NAME)                                                                        \
   run<V, 0, false, false, false>(NAME "  registers only (no LDS reads)     ", w, sink, n_chunks, blocks); \

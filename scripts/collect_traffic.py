@@ -2,7 +2,10 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate passes, TCC slots) into per-launch HBM
 traffic of each kernel kind bench.py names.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 128-byte requests of wide coalesced streams as 64 bytes, so reads are doubled
-(/opt/skills/guides/MI355X_MICROARCH.md, section HBM).  Usage: collect_traffic.py <fetch_dir> <write_dir> <precision> <out.json>"""
+(/opt/skills/guides/MI355X_MICROARCH.md, section HBM).
+Usage: collect_traffic.py <fetch_dir> <write_dir> <workload key> <out.json>
+The workload key is what bench.py prints as roofline.traffic_key minus the kernel kind:
+"<model>|<pairs>x<seq_len> or varlen|<kernel set>"."""
 import csv
 import glob
 import json
@@ -12,13 +15,19 @@ import sys
 from collections import defaultdict
 
 KIND = [
+    (r"rowgemm_kernel<\d+, [01], 4,", "fused_layer_attnout_mlp_qkv"),
     (r"rowgemm_kernel<\d+, 2, 3,", "fused_attnout_ln_wi_geglu"),
     (r"rowgemm_kernel<\d+, 0, 3,", "fused_mlpout_ln_qkv_rope"),
     (r"rowgemm_kernel<\d+, 0, [01],", "rowgemm_ln_qkv_rope"),
     (r"rowgemm_kernel<\d+, 1, 2,", "rowgemm_attn_out"),
     (r"rowgemm_kernel<\d+, 2, 0,", "rowgemm_ln_wi_geglu"),
     (r"kstream_gemm_kernel", "kstream_mlp_out"),
-    (r"attn_fp_kernel", "attn_fp"),
+    (r"attn_fp_kernel<\d+, \d+, \w+, \d+, 1,", "attn_local"),
+    (r"attn_fp_kernel", "attn_global"),
+    (r"panel_gemm_kernel<0,", "panel_residual"),  # alternates attention-out / MLP-out projection: split below
+    (r"panel_gemm_kernel<1,", "gemm_qk_rope"),
+    (r"panel_gemm_kernel<2,", "gemm_v_t"),
+    (r"panel_gemm_kernel<3,", "gemm_wi_geglu"),
     (r"attn_kernel", "attn"),
     (r"gemm_kernel<3,", "gemm_wi_geglu"),
     (r"gemm_kernel<2,", "gemm_residual"),
@@ -30,11 +39,15 @@ KIND = [
 def per_kernel(directory, counter):
     acc, cnt = defaultdict(float), defaultdict(set)
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] != counter:
-                continue
+        rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        residual_ids = {}  # the residual panel GEMM runs twice per layer, in this order: attention out, MLP out
+        for r in rows:
             for pat, kind in KIND:
                 if re.search(pat, r["Kernel_Name"]):
+                    if kind == "panel_residual":
+                        slot = residual_ids.setdefault(r["Dispatch_Id"], len(residual_ids))
+                        kind = "gemm_attn_out" if slot % 2 == 0 else "gemm_mlp_out"
                     acc[kind] += float(r["Counter_Value"])
                     cnt[kind].add(r["Dispatch_Id"])
                     break
@@ -48,11 +61,11 @@ out_path = sys.argv[4]
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for kind in sorted(set(fetch) | set(write)):
     f_kb, w_kb = fetch.get(kind, 0.0), write.get(kind, 0.0)
-    out[f"{kind}:{precision}"] = {
+    out[f"{kind}|{precision}"] = {
         "fetch_size_kib_raw": f_kb,
         "write_size_kib_raw": w_kb,
         "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0,
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; reads x2 (gfx950 correction)",
     }
-    print(kind, precision, f"fetch {f_kb/1024:.1f} MiB raw, write {w_kb/1024:.1f} MiB -> {out[f'{kind}:{precision}']['hbm_bytes_per_launch']/1e6:.1f} MB/launch")
+    print(kind, precision, f"fetch {f_kb/1024:.1f} MiB raw, write {w_kb/1024:.1f} MiB -> {out[f'{kind}|{precision}']['hbm_bytes_per_launch']/1e6:.1f} MB/launch")
 json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)

@@ -8,6 +8,7 @@ import io
 import json
 import os
 import pstats
+import resource
 import sys
 import time
 
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("--chars", type=int, default=470)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--preprocess-batch", type=int, default=None, help="explicit preprocess batch (default: the pipeline granule)")
     ap.add_argument("--profile", action="store_true")
     args = ap.parse_args()
 
@@ -58,20 +60,25 @@ def main():
 
     def call():
         return model.process(question, contexts, threshold=0.1, batch_size=args.batch_size, sentence_splitter=period_splitter,
-                             show_progress=False)
+                             show_progress=False, preprocess_batch_size=args.preprocess_batch)
 
     call()
     torch.cuda.synchronize()
     best = None
     for _ in range(args.reps):
+        r0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         out = call()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        r1 = resource.getrusage(resource.RUSAGE_SELF)
+        usage = {"user_s": round(r1.ru_utime - r0.ru_utime, 4), "sys_s": round(r1.ru_stime - r0.ru_stime, 4),
+                 "minor_faults": r1.ru_minflt - r0.ru_minflt, "vol_ctx_switches": r1.ru_nvcsw - r0.ru_nvcsw,
+                 "invol_ctx_switches": r1.ru_nivcsw - r0.ru_nivcsw}
         if best is None or dt < best[0]:
-            best = (dt, out["timing"])
-    dt, timing = best
-    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "wall_s": dt, "contexts_per_s": args.contexts / dt,
+            best = (dt, out["timing"], usage)
+    dt, timing, usage = best
+    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "wall_s": dt, "contexts_per_s": args.contexts / dt, "rusage": usage,
                       "timing": {k: round(float(v), 5) for k, v in timing.items()}}))
     if args.profile:
         pr = cProfile.Profile()
