@@ -38,21 +38,42 @@ __device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return *reinterpret_c
 //   shader cycles / real time -> the clock the chip actually runs at under this MFMA load
 // The guide's 2.5 PFLOP/s dense bf16 peak is 1024 SIMDs x 1024 flop/cycle x 2.4 GHz; at the clock measured here the
 // ceiling of this part is 1024 x 1024 x f, which is what the TFLOP/s figures printed below should be read against.
-template <int WAVES_PER_SIMD>
+// MODE 0: one (a, b) register pair, accumulators wherever the compiler puts them; 1: accumulators forced into AGPRs
+// (inline-asm MFMA with "+a"); 2: eight distinct (a, b) pairs; 3: both.
+// NV: independent vector instructions issued after every MFMA (KIND 0: v_fma_f32, 1: v_accvgpr_read_b32 of a finished
+// accumulator, 2: ds_read_b128 + nothing waiting on it, 3: v_cvt_pk_bf16_f32) -- what one wave can issue in an MFMA's shadow.
+template <int WAVES_PER_SIMD, int MODE = 0, int NV = 0, int KIND = 0>
 __global__ __launch_bounds__(256 * WAVES_PER_SIMD > 1024 ? 1024 : 256 * WAVES_PER_SIMD) void clock_probe_kernel(
     int n_iters, unsigned long long* __restrict__ out, float* __restrict__ sink) {
   __shared__ u16 pad[48 * 1024];  // 96 KiB: one block per CU, so the block size sets the waves per SIMD
   const int lane = threadIdx.x & 63;
   pad[threadIdx.x] = (u16)lane;
-  bf16x8 a, b;
+  bf16x8 av[8], bv[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    a[i] = (__bf16)(0.001f * (float)(lane + i));
-    b[i] = (__bf16)(0.002f * (float)(lane ^ i));
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      av[j][i] = (__bf16)(0.001f * (float)(lane + i + j));
+      bv[j][i] = (__bf16)(0.002f * (float)((lane ^ i) + j));
+    }
+    asm volatile("" : "+v"(av[j]), "+v"(bv[j]));
   }
   f32x4 acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float fv[8], fc = 1.0001f, spare[4] = {1.f, 2.f, 3.f, 4.f};
+  f32x4 vres[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 pv[4], pc = f32x2{1.0001f, 0.9999f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pv[i] = f32x2{0.5f + (float)lane, 0.25f + (float)i};
+  unsigned pk[4] = {0, 0, 0, 0};
+  uint4 lv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  const unsigned lds_a = (unsigned)(uintptr_t)((__attribute__((address_space(3))) u16*)pad) + lane * 16u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fv[i] = 0.5f + (float)lane * 0.001f + (float)i;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+a"(spare[i]));
   __syncthreads();
   const unsigned long long c0 = __builtin_readcyclecounter();
   const unsigned long long t0 = wall_clock64();
@@ -60,11 +81,32 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD > 1024 ? 1024 : 256 * WAVES_PE
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        constexpr bool DISTINCT = (MODE & 2) != 0;
+        const bf16x8 a = av[DISTINCT ? i : 0], b = bv[DISTINCT ? (i + r) & 7 : 0];
+        if (MODE & 1)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+        else
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv[v & 7]) : "v"(fc));
+          else if (KIND == 1) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(fv[v & 7]) : "a"(spare[v & 3]));
+          else if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(lv[v & 1]) : "v"(lds_a));
+          else if (KIND == 3) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[v & 3]) : "v"(fv[v & 7]), "v"(fc));
+          else if (KIND == 4) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pv[v & 3]) : "v"(pc));
+          else if (KIND == 5) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(pk[v & 3]));
+          else if (KIND == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(fv[v & 7]));
+          else if (KIND == 7) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(fv[v & 7]) : "v"(fc));
+          else asm volatile("v_sub_f32 %0, %0, %1" : "+v"(fv[v & 7]) : "v"(fc));
+        }
+      }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   float total = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) total += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 8; ++i) total += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + fv[i];
+  total += (float)(pk[0] ^ pk[1] ^ pk[2] ^ pk[3]) + (float)(lv[0].x ^ lv[1].y) + vres[0][0] + vres[1][1] + pv[0][0] + pv[1][1] + pv[2][0] + pv[3][1];
   const unsigned long long c1 = __builtin_readcyclecounter();
   const unsigned long long t1 = wall_clock64();
   if (total == 123.456f) sink[threadIdx.x] = total + (float)pad[(threadIdx.x * 7) & 1023];
@@ -74,7 +116,7 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD > 1024 ? 1024 : 256 * WAVES_PE
   }
 }
 
-template <int WAVES_PER_SIMD>
+template <int WAVES_PER_SIMD, int MODE = 0, int NV = 0, int KIND = 0>
 static double clock_probe(const char* label, float* sink) {
   const int blocks = 256 * 8, n_iters = 4096;  // 8 blocks per CU queued behind each other
   const int threads = 256 * WAVES_PER_SIMD > 1024 ? 1024 : 256 * WAVES_PER_SIMD;
@@ -83,9 +125,9 @@ static double clock_probe(const char* label, float* sink) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((clock_probe_kernel<WAVES_PER_SIMD>), dim3(blocks), dim3(threads), 0, 0, n_iters, out, sink);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((clock_probe_kernel<WAVES_PER_SIMD, MODE, NV, KIND>), dim3(blocks), dim3(threads), 0, 0, n_iters, out, sink);
   CHECK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL((clock_probe_kernel<WAVES_PER_SIMD>), dim3(blocks), dim3(threads), 0, 0, n_iters, out, sink);
+  hipLaunchKernelGGL((clock_probe_kernel<WAVES_PER_SIMD, MODE, NV, KIND>), dim3(blocks), dim3(threads), 0, 0, n_iters, out, sink);
   CHECK(hipEventRecord(e1, 0));
   CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -525,6 +567,33 @@ int main() {
   clock_probe<2>("  2 waves per SIMD", sink);
   clock_probe<4>("  4 waves per SIMD", sink);
   clock_probe<1>("  1 wave per SIMD (again, warm)", sink);
+  clock_probe<1, 1>("  1 wave per SIMD, AGPR accumulators", sink);
+  clock_probe<1, 2>("  1 wave per SIMD, 8 distinct (a, b)", sink);
+  clock_probe<1, 3>("  1 wave per SIMD, AGPR acc + distinct", sink);
+  clock_probe<2, 3>("  2 waves per SIMD, AGPR acc + distinct", sink);
+  printf("one wave per SIMD, AGPR accumulators, N vector instructions after every MFMA:\n");
+  clock_probe<1, 1, 1, 0>("  1 v_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 2, 0>("  2 v_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 3, 0>("  3 v_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 4, 0>("  4 v_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 6, 0>("  6 v_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 8, 0>("  8 v_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 2, 1>("  2 v_accvgpr_read / MFMA", sink);
+  clock_probe<1, 1, 4, 1>("  4 v_accvgpr_read / MFMA", sink);
+  clock_probe<1, 1, 2, 3>("  2 v_cvt_pk_bf16_f32 / MFMA", sink);
+  clock_probe<1, 1, 4, 3>("  4 v_cvt_pk_bf16_f32 / MFMA", sink);
+  clock_probe<1, 1, 1, 2>("  1 ds_read_b128 / MFMA", sink);
+  clock_probe<1, 1, 2, 2>("  2 ds_read_b128 / MFMA", sink);
+  // (an MFMA with C in AGPRs and D in VGPRs does not assemble: one acc_cd bit selects the class of both)
+  clock_probe<1, 1, 2, 4>("  2 v_pk_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 4, 4>("  4 v_pk_fma_f32 / MFMA", sink);
+  clock_probe<1, 1, 4, 5>("  4 v_and_b32 (literal) / MFMA", sink);
+  clock_probe<1, 1, 2, 6>("  2 v_exp_f32 / MFMA", sink);
+  clock_probe<1, 1, 4, 6>("  4 v_exp_f32 / MFMA", sink);
+  clock_probe<1, 1, 4, 7>("  4 v_mul_f32 / MFMA", sink);
+  clock_probe<1, 1, 4, 8>("  4 v_sub_f32 / MFMA", sink);
+  clock_probe<2, 1, 4, 0>("  2 waves/SIMD: 4 v_fma_f32 / MFMA", sink);
+  clock_probe<2, 1, 8, 0>("  2 waves/SIMD: 8 v_fma_f32 / MFMA", sink);
   printf("1024 blocks x 4 waves x 32 rows, K=256 bf16x3, 64 chunks of 32 features (one Wi GEMM of ModernBERT-xsmall)\n");
 #define CASES(V, NAME)                                                                        \
   run<V, 0, false, false, false>(NAME "  registers only (no LDS reads)     ", w, sink, n_chunks, blocks); \

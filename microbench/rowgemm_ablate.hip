@@ -112,6 +112,10 @@ int main() {
     for (int i = 0; i < R; ++i) pos[i] = i % 512;
     CHECK(hipMemcpy(d_pos, pos.data(), R * 4, hipMemcpyHostToDevice));
   }
+#ifdef OPK_TIMING
+  CHECK(hipMalloc(&p.dbg, (size_t)(R / 128) * 16 * 8));
+  CHECK(hipMemset(p.dbg, 0, (size_t)(R / 128) * 16 * 8));
+#endif
   p.ln_w_mlp = d_ln;
   p.wi_pk = d_wi;
   p.wo2_ks = d_wo2;
@@ -156,6 +160,30 @@ int main() {
     best = ms < best ? ms : best;
     sum += ms;
   }
+#ifdef OPK_TIMING
+  {
+    // cycle stamps of wave 0 of every block: 0 start, 1 after the attention-output projection, 2 after residual +
+    // LayerNorm (MLP loop starts), 3 after the MLP, 4 after residual + LayerNorm, 5 end; [8] = cycles in the MLP
+    // loop's end-of-stage wait + barrier
+    const int blocks = R / 128;
+    std::vector<unsigned long long> t((size_t)blocks * 16);
+    CHECK(hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost));
+    double seg[5] = {0, 0, 0, 0, 0}, wait = 0, wait2 = 0, wait1 = 0, total = 0;
+    int n = 0;
+    for (int b = 0; b < blocks; ++b) {
+      const unsigned long long* s = &t[(size_t)b * 16];
+      const int last = s[5] ? 5 : 4;
+      for (int i = 0; i < last; ++i) seg[i] += (double)(s[i + 1] - s[i]);
+      wait += (double)s[8];
+      wait2 += (double)s[9];
+      wait1 += (double)s[10];
+      total += (double)(s[last] - s[0]);
+      ++n;
+    }
+    printf("  cycles per block (wave 0): attn-out %.0f | residual+LN %.0f | MLP %.0f (of which stage wait+barrier %.0f) | residual+LN %.0f | q/k/v %.0f (vmcnt wait %.0f, barrier %.0f) | total %.0f\n",
+           seg[0] / n, seg[1] / n, seg[2] / n, wait / n, seg[3] / n, seg[4] / n, wait1 / n, wait2 / n, total / n);
+  }
+#endif
   CHECK(hipGetLastError());
   printf("%-22s terms=%d  avg %.1f us  best %.1f us\n", ABL_NAME, ABL_T, sum / reps * 1e3f, best * 1e3f);
   return 0;

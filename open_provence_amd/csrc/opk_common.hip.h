@@ -116,8 +116,11 @@ __device__ __forceinline__ float gelu_erf(float x) {
   q = fmaf(q, ax, -1.1507878304e+00f);
   q = fmaf(q, ax, -1.0000376701e+00f);
   const float he = __builtin_amdgcn_exp2f(q);
-  // max(x, 0) as med3(x, 0, +inf): one instruction (fmaxf adds a NaN-quieting v_max x,x in front)
-  return fmaf(-he, ax, __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()));
+  // max(x, 0) in ONE instruction: fmaxf and med3(x, 0, +inf) both come out of the compiler as a NaN-quieting
+  // v_max x, x followed by v_max 0, x
+  float relu;
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
+  return fmaf(-he, ax, relu);
 }
 
 // rowgemm_kernel epilogues: q/k/v projection (RoPE, fragment-packed q, k, v^T), GeGLU (fragment-packed h), or no chunk

@@ -69,6 +69,8 @@ struct PanelParams {
   const u16* a_fp;   // fragment-packed activations [r_pad/16][n_ksteps][2 planes][512]
   const u16* wp;     // packed weights [n_tiles][n_ksteps][2 planes][16][512]
   int n_ksteps;      // K / 32
+  int n_tiles;       // output panels (N / 256; PE_GEGLU: I / 128)
+  int row_group;     // row blocks per XCD-local group (see the block map in panel_gemm_kernel)
   int r_pad;
   int hidden;        // H
   int ld_out;        // PE_RESIDUAL: H   PE_GEGLU: I
@@ -83,6 +85,13 @@ struct PanelParams {
 
 // T = term mask (left = the fragment-packed activation, right = the weight panel); OLO bit 0: o0 (q / v^T / h) gets a
 // lo plane, bit 1: o1 (k) does.
+//
+// Block -> (row block, output panel), XCD-aware: the grid is one-dimensional, ceil(row blocks / 8) * 8 * n_tiles
+// blocks.  Block b is dispatched to XCD b % 8 (observed placement; a speed assumption only), so with
+//   row block = (b / 8 / n_tiles) * 8 + b % 8,   panel = (b / 8) % n_tiles
+// the n_tiles blocks that read the same 128 activation rows follow each other on ONE XCD and share that XCD's L2:
+// the activation planes leave HBM once instead of once per panel (measured on the base model, H = 768, I = 1152:
+// the Wi GEMM fetched 5.4 GB per launch for 1.0 GB of operands with the row-block-major grid).
 template <int EPI, int T, int OLO>
 __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
   constexpr int NF = 16;
@@ -100,8 +109,13 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
   const int g = lane >> 4;
-  const int m0 = blockIdx.x * ROW_BM + wave * 32;
-  const int tile = blockIdx.y;
+  const int xcd_slot = blockIdx.x >> 3;
+  const int group_blocks = p.row_group * p.n_tiles;
+  const int in_group = xcd_slot % group_blocks;
+  const int row_block = ((xcd_slot / group_blocks) * p.row_group + in_group % p.row_group) * 8 + (blockIdx.x & 7);
+  if (row_block * ROW_BM >= p.r_pad) return;  // the grid is rounded up to whole groups
+  const int m0 = row_block * ROW_BM + wave * 32;
+  const int tile = in_group / p.row_group;
   const int nks = p.n_ksteps;
   const u16* wtile = p.wp + (size_t)tile * nks * SLAB_SRC;
 

@@ -27,6 +27,9 @@ namespace opk {
 // ----------------------------------------------------------------------------------------------
 
 struct RowGemmParams {
+#ifdef OPK_TIMING
+  unsigned long long* dbg;  // [blocks][16] cycle stamps of wave 0 (microbench/rowgemm_ablate.hip only)
+#endif
   const float* x_in;  // RP_SPLIT: fp32 [r_pad][K]
   const float* ln_w;  // LayerNorm weight in front of the chunk loop (RP_KSTREAM, RP_MLP)
   float eps;
@@ -323,6 +326,23 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   const int l15 = lane & 15;
   const int g = lane >> 4;
   const int m0 = blockIdx.x * (WAVES * 16 * MF) + wave * (16 * MF);
+#ifdef OPK_TIMING
+  unsigned long long opk_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, opk_wait = 0, opk_wait2 = 0, opk_wait1 = 0;
+#define OPK_STAMP(i) opk_ts[i] = __builtin_readcyclecounter()
+#define OPK_DUMP()                                                                              \
+  do {                                                                                          \
+    if (threadIdx.x == 0) {                                                                     \
+      for (int i_ = 0; i_ < 8; ++i_) p.dbg[(size_t)blockIdx.x * 16 + i_] = opk_ts[i_];          \
+      p.dbg[(size_t)blockIdx.x * 16 + 8] = opk_wait;                                            \
+      p.dbg[(size_t)blockIdx.x * 16 + 9] = opk_wait2;                                           \
+      p.dbg[(size_t)blockIdx.x * 16 + 10] = opk_wait1;                                          \
+    }                                                                                           \
+  } while (0)
+  OPK_STAMP(0);
+#else
+#define OPK_STAMP(i)
+#define OPK_DUMP()
+#endif
 
   // ---- weight streaming: global -> LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction) --
   // Stage layout = [ks][plane][frag][512] = a sequence of 1 KiB pieces; wave w copies pieces w, w+4, ...
@@ -345,6 +365,36 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     }
   };
   bf16x8 a_hi[MF][KS], a_lo[MF][KS];
+  // RE_QKV: RoPE rows of this lane's tokens, cos/sin [pos][8g + 4j .. +3] for half-head j.  Two-wave kernels fetch the
+  // half-head of the chunk whose (deferred) epilogue runs in an iteration at the top of that iteration (the partner wave
+  // covers the latency).  The one-wave-per-SIMD layer kernel (RP_MLP) has nobody to cover it -- the loads sat behind a
+  // full s_waitcnt vmcnt(0) in front of each epilogue, ~1000 cycles per chunk -- so it fetches both half-heads once,
+  // while the LayerNorm in front of the chunk loop runs (ROPE_PRELOAD).
+  constexpr bool ROPE_PRELOAD = EPI == RE_QKV && PRO == RP_MLP;
+  const float* rope_c_row[MF];
+  const float* rope_s_row[MF];
+  f32x4 rope_c[MF], rope_s[MF];
+  f32x4 rope_cc[MF][2], rope_ss[MF][2];
+  auto rope_rows = [&]() {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int pos = p.row_pos[m0 + mf * 16 + l15];
+      pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+      rope_c_row[mf] = p.rope_cos + (size_t)pos * ROPE_HALF + g * 8;
+      rope_s_row[mf] = p.rope_sin + (size_t)pos * ROPE_HALF + g * 8;
+      rope_c[mf] = rope_s[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto rope_preload = [&]() {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        rope_cc[mf][j] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + j * 4);
+        rope_ss[mf][j] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + j * 4);
+      }
+  };
+  if (ROPE_PRELOAD) rope_rows();  // the position index load flies during phase 1
   // LDS byte address of this lane's 16 bytes in piece 0 of each stage (the hand-placed fragment reads add immediates)
   uint32_t lds_stage[2];
   lds_stage[0] = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) u16*)&sW[0][0]) + (uint32_t)lane * 16u;
@@ -385,60 +435,131 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     for (int nf = 0; nf < NF1; ++nf)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stage_slab(0, 0);
-    load_a1(0);
+    // RP_MLP (one wave per SIMD, nobody to hide a load behind): everything phase 1 reads from HBM is requested up
+    // front -- all K1 / 32 = KS fragment pairs of A1 (into a_hi / a_lo, which only the LayerNorm below overwrites) and
+    // the residual rows x of row fragment 0 -- and the weight slabs come two k-steps per LDS stage (half the block
+    // barriers, each DMA issued two k-steps ahead of its use).  Measured per 128-row block before / after: phase 1
+    // 26k -> 12k cycles (8.3k are MFMAs), residual + LayerNorm 29k -> 11k (eight serialized HBM round trips gone).
+    float4 xq0[(PRO == RP_MLP) ? NF1 : 1];
+    if constexpr (PRO == RP_MLP) {
+      static_assert(PLANES1 == 1, "whole-layer kernel: single-plane attention output weight");
+      constexpr int PAIR_PIECES = 2 * NF1 / WAVES;  // DMA instructions per wave per stage (two k-steps)
+      static_assert(2 * NF1 * 512 <= STAGE_ALLOC, "two slabs per LDS stage");
+      auto stage_pair = [&](int j, int stage) {
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      asm volatile("" : "+v"(an_hi[mf]));
-      asm volatile("" : "+v"(an_lo[mf]));
-    }
-    __syncthreads();
-    auto slab_step = [&](int ks1, auto cur_tag) {
-      constexpr int cur = decltype(cur_tag)::value;
-      const int kn = ks1 + 1 < nks1 ? ks1 + 1 : ks1;
-      stage_slab(kn, cur ^ 1);
-      bf16x8 c_hi[MF], c_lo[MF];
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        c_hi[mf] = an_hi[mf];
-        c_lo[mf] = an_lo[mf];
-      }
-      load_a1(kn);
-      __builtin_amdgcn_sched_barrier(0);
-      // two weight fragments at a time, the three product terms issued term-major over their 2 x MF accumulators:
-      // no MFMA reads the accumulator the previous one wrote (a dependent pair stalls the pipe)
-#pragma unroll
-      for (int nf = 0; nf < NF1; nf += 2) {
-        bf16x8 wh[2], wl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
-          wl[j] = W_LO1 ? lds_frag(&sW[cur][(NF1 + nf + j) * 512 + lane * 8]) : wh[j];
+        for (int u = 0; u < PAIR_PIECES; ++u) {
+          const int piece = wave + WAVES * u;  // [k-step 2j | 2j+1][nf]
+          const u16* src = p.w1p + (size_t)(2 * j + piece / NF1) * SLAB_SRC + (piece % NF1) * 512;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
+                                           (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
         }
+      };
 #pragma unroll
-        for (int term = 0; term < 3; ++term) {
-          if ((term == 0 && !W_LO1) || (term == 1 && !A_LO1)) continue;
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-              acc1[nf + j][mf] = mfma16(term == 0 ? wl[j] : wh[j], term == 1 ? c_lo[mf] : c_hi[mf], acc1[nf + j][mf]);
+        for (int mf = 0; mf < MF; ++mf) {
+          a_hi[mf][ks] = *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks * 1024);
+          a_lo[mf][ks] = A_LO1 ? *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks * 1024 + 512) : a_hi[mf][ks];
         }
+      stage_pair(0, 0);
+      {
+        const float* xrow = p.x_io + (size_t)(m0 + l15) * K + g * 8;
+#pragma unroll
+        for (int nf = 0; nf < NF1; ++nf) xq0[nf] = *reinterpret_cast<const float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
       }
       __syncthreads();
-    };
-#ifdef OPK_ABL_NO_PHASE1
-    for (int k0 = 0; k0 < 0; k0 += 2) {
-#else
-    for (int k0 = 0; k0 < nks1; k0 += 2) {  // even number of k-steps (checked on the host)
-#endif
-      slab_step(k0, std::integral_constant<int, 0>{});
-      slab_step(k0 + 1, std::integral_constant<int, 1>{});
+      static_for<KS / 2>([&](auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        constexpr int cur = j & 1;
+        if constexpr (j + 1 < KS / 2) stage_pair(j + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // one fragment stream per stage (fragment reads placed by hand, two steps ahead -- see frag_stream2): step
+        // (kk, nf / 2) = the two weight fragments nf, nf + 1 of k-step 2j + kk against both row fragments
+        struct P1Off {
+          static constexpr int at(int st, int jj) { return (2 * st + jj) * 1024; }
+        };
+        frag_stream2<NF1, 2, P1Off>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+          constexpr int st = decltype(step_tag)::value;
+          constexpr int ks = 2 * j + st / (NF1 / 2), nf = (st % (NF1 / 2)) * 2;
+          if (A_LO1) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, a_lo[mf][ks], acc1[nf][mf]);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, a_lo[mf][ks], acc1[nf + 1][mf]);
+          }
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, a_hi[mf][ks], acc1[nf][mf]);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, a_hi[mf][ks], acc1[nf + 1][mf]);
+        });
+        __syncthreads();
+      });
+    } else {
+      stage_slab(0, 0);
+      load_a1(0);
+  #pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        asm volatile("" : "+v"(an_hi[mf]));
+        asm volatile("" : "+v"(an_lo[mf]));
+      }
+      __syncthreads();
+      auto slab_step = [&](int ks1, auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
+        const int kn = ks1 + 1 < nks1 ? ks1 + 1 : ks1;
+        stage_slab(kn, cur ^ 1);
+        bf16x8 c_hi[MF], c_lo[MF];
+  #pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          c_hi[mf] = an_hi[mf];
+          c_lo[mf] = an_lo[mf];
+        }
+        load_a1(kn);
+        __builtin_amdgcn_sched_barrier(0);
+        // two weight fragments at a time, the three product terms issued term-major over their 2 x MF accumulators:
+        // no MFMA reads the accumulator the previous one wrote (a dependent pair stalls the pipe)
+  #pragma unroll
+        for (int nf = 0; nf < NF1; nf += 2) {
+          bf16x8 wh[2], wl[2];
+  #pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
+            wl[j] = W_LO1 ? lds_frag(&sW[cur][(NF1 + nf + j) * 512 + lane * 8]) : wh[j];
+          }
+  #pragma unroll
+          for (int term = 0; term < 3; ++term) {
+            if ((term == 0 && !W_LO1) || (term == 1 && !A_LO1)) continue;
+  #pragma unroll
+            for (int j = 0; j < 2; ++j)
+  #pragma unroll
+              for (int mf = 0; mf < MF; ++mf)
+                acc1[nf + j][mf] = mfma16(term == 0 ? wl[j] : wh[j], term == 1 ? c_lo[mf] : c_hi[mf], acc1[nf + j][mf]);
+          }
+        }
+        __syncthreads();
+      };
+  #ifdef OPK_ABL_NO_PHASE1
+      for (int k0 = 0; k0 < 0; k0 += 2) {
+  #else
+      for (int k0 = 0; k0 < nks1; k0 += 2) {  // even number of k-steps (checked on the host)
+  #endif
+        slab_step(k0, std::integral_constant<int, 0>{});
+        slab_step(k0 + 1, std::integral_constant<int, 1>{});
+      }
     }
+    OPK_STAMP(1);
     // ---- transition: residual add, (store the new hidden state,) LayerNorm, split -> fragments -------------------
     // LOAD: acc1 += x rows from memory; STORE: write the rows back; then LayerNorm with `lnw` into a_hi / a_lo.
     auto residual_ln = [&](auto load_tag, auto store_tag, auto lo_tag, const float* __restrict__ lnw) {
       constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value, LO = decltype(lo_tag)::value;
+      // RP_MLP: row fragment 0 of x was requested at the top of the kernel, fragment 1 is requested here and arrives
+      // while fragment 0 is normalised
+      constexpr bool XPRE = LOAD && PRO == RP_MLP;
+      float4 xq1[(XPRE && MF > 1) ? NF1 : 1];
+      if (XPRE && MF > 1) {
+        const float* xrow1 = p.x_io + (size_t)(m0 + 16 + l15) * K + g * 8;
+#pragma unroll
+        for (int nf = 0; nf < NF1; ++nf) xq1[nf] = *reinterpret_cast<const float4*>(xrow1 + 32 * (nf >> 1) + 4 * (nf & 1));
+      }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         float* xrow = p.x_io + (size_t)(m0 + mf * 16 + l15) * K + g * 8;
@@ -448,7 +569,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
           float4 r4 = make_float4(acc1[nf][mf][0], acc1[nf][mf][1], acc1[nf][mf][2], acc1[nf][mf][3]);
           if (LOAD) {
-            const float4 x4 = *px;
+            const float4 x4 = XPRE ? (mf == 0 ? xq0[nf] : xq1[(XPRE && MF > 1) ? nf : 0]) : *px;
             r4.x += x4.x;
             r4.y += x4.y;
             r4.z += x4.z;
@@ -458,7 +579,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           if (STORE) *px = r4;
           sum += (r4.x + r4.y) + (r4.z + r4.w);
           // keep the scheduler from hoisting all 16 row loads (64 more registers) on top of the accumulators
-          if ((LOAD || STORE) && (nf & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          if (((LOAD && !XPRE) || STORE) && (nf & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         if (lnw == nullptr) continue;  // RE_NONE: the residual stream is all the last layer leaves behind
         sum += __shfl_xor(sum, 16, 64);
@@ -528,6 +649,15 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       auto stage_unit = [&](int t, int stage) { static_for<UNIT_DMA>([&](auto u) { stage_piece(u, t, stage); }); };
       stage_unit(0, 0);  // flies while the LayerNorm below runs
       residual_ln(yes_, no_, std::integral_constant<bool, A_LOW>{}, p.ln_w_mlp);
+      // The lo fragments of the normalised rows live in AGPRs from here on (an MFMA takes its A / B operands from
+      // either file): the 256 architectural VGPRs were short by about that much, and the compiler's own answer was to
+      // park fragments in AGPRs and move them back in front of each use -- ~8 issue cycles per v_accvgpr move.
+      if (A_LOW && MF == 2) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(a_lo[mf][ks]));
+      }
 
       f32x4 acc_b[2][MF];  // accumulators of the pair's second chunk: [input | gate] fragment x row fragment
       uint2 hold_hi[MF], hold_lo[MF];
@@ -546,6 +676,17 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       constexpr int VPS = (NV + KS - 1) / KS;
       auto geglu_slice = [&](const f32x4 (&av)[2][MF], float (&gv)[MF][4], auto slice_tag, auto&& pack) {
         constexpr int sl = decltype(slice_tag)::value;
+#ifdef OPK_ABL_NO_MLP_VALU
+        // ablation: no GeGLU / split / pack; the accumulators stay live (in AGPRs) and h is opaque to the compiler
+        static_for<VPS>([&](auto j_tag) {
+          constexpr int i = sl * VPS + decltype(j_tag)::value;
+          if constexpr (i < NV) {
+            asm volatile("" ::"a"(av[0][i >> 2][i & 3]), "a"(av[1][i >> 2][i & 3]));
+            if constexpr ((i & 3) == 3) pack(std::integral_constant<int, (i >> 2)>{});
+          }
+        });
+        return;
+#endif
         static_for<VPS>([&](auto j_tag) {
           constexpr int i = sl * VPS + decltype(j_tag)::value;
           if constexpr (i < NV) {
@@ -560,6 +701,10 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       };
       auto pack_h = [&](auto mf_tag) {  // second half of a pair -> the pair's h fragment of this row fragment
         constexpr int mf = decltype(mf_tag)::value;
+#ifdef OPK_ABL_NO_MLP_VALU
+        asm volatile("" : "+v"(h_hi[mf]), "+v"(h_lo[mf]));
+        return;
+#endif
         uint2 h2, l2;
         split4<H_LO>(g_prev[mf], h2, l2);
         h_hi[mf] = as_frag(make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y));
@@ -567,6 +712,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       };
       auto pack_hold = [&](auto mf_tag) {
         constexpr int mf = decltype(mf_tag)::value;
+#ifdef OPK_ABL_NO_MLP_VALU
+        return;
+#endif
         split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
       };
       auto chunk_step = [&](f32x4 (&acc)[2][MF], auto ks_tag, const bf16x8& w0, const bf16x8& w1) {
@@ -616,7 +764,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         constexpr int NS = Off::NS;
         // The next stage's DMA instructions are spread over the first steps of the stream, one per step: issued in
         // one burst at the top they cost this (only) wave of the SIMD their full issue time with no MFMA in flight.
-        f32x4 na[2][MF], nb[2][MF];  // written by their first k-step (C operand = 0)
+        // na: chunk 2t, written by its first k-step (C operand = 0).  Chunk 2t+1 accumulates straight into acc_b: the
+        // GeGLU of chunk 2t-1 (the last reader of acc_b's old contents) is over after the first KS steps.
+        f32x4 na[2][MF];
         frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int s = decltype(step_tag)::value;
 #ifndef OPK_ABL_NO_DMA
@@ -629,23 +779,25 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
             slab_pair(std::integral_constant<int, 2 * (s - KS)>{}, w0, w1);
             geglu_slice(na, g_cur, std::integral_constant<int, s - KS>{}, pack_hold);
           } else {  // chunk 2t+1 (t = 0: with the GeGLU of chunk 0)
-            chunk_step(nb, std::integral_constant<int, s - KS - NS>{}, w0, w1);
+            chunk_step(acc_b, std::integral_constant<int, s - KS - NS>{}, w0, w1);
             if constexpr (!SLAB) geglu_slice(na, g_cur, std::integral_constant<int, s - KS>{}, pack_hold);
           }
           interleave_step();
         });
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          acc_b[0][mf] = nb[0][mf];
-          acc_b[1][mf] = nb[1][mf];
-        }
+#ifdef OPK_TIMING
+        const unsigned long long opk_w0 = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (no other VMEM in this loop)
 #ifndef OPK_ABL_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
+#ifdef OPK_TIMING
+        opk_wait += __builtin_readcyclecounter() - opk_w0;
+#endif
       };
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // stage 0 has landed
+      OPK_STAMP(2);
       macro(0, 0, no_);
       for (int t = 1; t < n_pairs; ++t) macro(t, t & 1, yes_);  // n_pairs is even (checked on the host): the tail reads stage 0
       {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
@@ -658,12 +810,17 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         });
       }
       __builtin_amdgcn_s_barrier();  // every wave is done with the ring: the chunk loop may reuse stage 0
+      OPK_STAMP(3);
       if constexpr (EPI == RE_NONE) {
         residual_ln(no_, yes_, no_, nullptr);  // acc1 = x + o Wo^T + h Wo^T: the layer's output
+        OPK_STAMP(4);
+        OPK_DUMP();
         return;
       } else {
         stage_chunk(0, 0);
+        if (ROPE_PRELOAD) rope_preload();
         residual_ln(no_, yes_, std::integral_constant<bool, A_LO>{}, p.ln_w);
+        OPK_STAMP(4);
       }
     }
   } else {
@@ -700,21 +857,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         a_lo[mf][ks] = f.v;
       }
   }
-  // RE_QKV: RoPE rows of this lane's tokens: cos/sin [pos][8g + 4j .. +3] for the half-head j of the chunk whose
-  // (deferred) epilogue runs in this iteration are fetched at the top of the iteration, before the DMA is issued.
-  const float* rope_c_row[MF];
-  const float* rope_s_row[MF];
-  f32x4 rope_c[MF], rope_s[MF];
-  if (EPI == RE_QKV) {
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      int pos = p.row_pos[m0 + mf * 16 + l15];
-      pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
-      rope_c_row[mf] = p.rope_cos + (size_t)pos * ROPE_HALF + g * 8;
-      rope_s_row[mf] = p.rope_sin + (size_t)pos * ROPE_HALF + g * 8;
-      rope_c[mf] = rope_s[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
+  if (EPI == RE_QKV && !ROPE_PRELOAD) rope_rows();
   __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
 
   // ---- stream the weight chunks ---------------------------------------------------------------
@@ -732,6 +875,13 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   // epilogue costs its instruction count either way, but interleaved it no longer adds a serial VALU-only phase.
   constexpr bool O0_LO = (OLO & 1) != 0, O1_LO = (OLO & 2) != 0, O2_LO = (OLO & 4) != 0;
   constexpr bool QK_LO = O0_LO || O1_LO;
+  // The epilogue is cut in two.  epilogue() is pure register work (RoPE / GeGLU, hi/lo split, packing) and leaves what
+  // has to be written in st_v / st_p; epilogue_store() issues the stores and runs AFTER the chunk's MFMA stream.  The
+  // hand-placed fragment reads are volatile asm: a store cannot move across them, so stores in front of the stream pin
+  // every instruction that feeds them in front of it too -- the storing half of the iterations ran its whole epilogue
+  // (~110 vector instructions) before its first MFMA instead of between them.
+  uint4 st_v[2][4];  // [row fragment (q / k / h) or weight fragment (v^T)][store]
+  u16* st_p[2];
   auto epilogue = [&](int cc, auto parity_tag, auto sw_tag, const f32x4 (&av)[2][MF]) {
     constexpr int PP = decltype(parity_tag)::value;
     constexpr bool sw = decltype(sw_tag)::value;  // q/k chunk ("swapped" MFMA orientation) or v chunk
@@ -757,14 +907,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           hold_lo[mf] = l2;
         } else {
           const size_t rb = (size_t)((m0 >> 4) + mf);
-          const size_t off = ((rb * (size_t)(p.ld_out >> 5) + (size_t)(cc >> 1)) * 2) * 512 + lane * 8;
-#ifdef OPK_ABL_NO_STORE
-          asm volatile("" ::"v"(hold_hi[mf].x), "v"(hold_hi[mf].y), "v"(h2.x), "v"(h2.y), "v"(off));
-          if (O0_LO) asm volatile("" ::"v"(hold_lo[mf].x), "v"(hold_lo[mf].y), "v"(l2.x), "v"(l2.y));
-#else
-          *reinterpret_cast<uint4*>(p.o0_hi + off) = make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y);
-          if (O0_LO) *reinterpret_cast<uint4*>(p.o0_hi + off + 512) = make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y);
-#endif
+          st_p[mf] = p.o0_hi + ((rb * (size_t)(p.ld_out >> 5) + (size_t)(cc >> 1)) * 2) * 512 + lane * 8;
+          st_v[mf][0] = make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y);
+          if (O0_LO) st_v[mf][1] = make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y);
         }
       }
     } else {  // RE_QKV: fragment-packed q, k (pieces [row/16][H/32][plane]) and v^T (pieces [head][row/32][plane][4])
@@ -795,12 +940,12 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           } else {
             const size_t rb = (size_t)((m0 >> 4) + mf);
             const size_t kb = (size_t)(cq >> 1) * 2;  // k-step of d in [0, 32); d + 32 is the next one
-            const size_t off = ((rb * (size_t)(p.hidden >> 5) + kb) * 2) * 512 + lane * 8;
-            *reinterpret_cast<uint4*>(out + off) = make_uint4(qk_hold[mf][0].x, qk_hold[mf][0].y, h0.x, h0.y);
-            *reinterpret_cast<uint4*>(out + off + 1024) = make_uint4(qk_hold[mf][2].x, qk_hold[mf][2].y, h1.x, h1.y);
-            if (QK_LO && (O0_LO == O1_LO || (is_q ? O0_LO : O1_LO))) {  // q and k may differ: wave-uniform select
-              *reinterpret_cast<uint4*>(out + off + 512) = make_uint4(qk_hold[mf][1].x, qk_hold[mf][1].y, l0.x, l0.y);
-              *reinterpret_cast<uint4*>(out + off + 1536) = make_uint4(qk_hold[mf][3].x, qk_hold[mf][3].y, l1.x, l1.y);
+            st_p[mf] = out + ((rb * (size_t)(p.hidden >> 5) + kb) * 2) * 512 + lane * 8;
+            st_v[mf][0] = make_uint4(qk_hold[mf][0].x, qk_hold[mf][0].y, h0.x, h0.y);
+            st_v[mf][1] = make_uint4(qk_hold[mf][2].x, qk_hold[mf][2].y, h1.x, h1.y);
+            if (QK_LO) {
+              st_v[mf][2] = make_uint4(qk_hold[mf][1].x, qk_hold[mf][1].y, l0.x, l0.y);
+              st_v[mf][3] = make_uint4(qk_hold[mf][3].x, qk_hold[mf][3].y, l1.x, l1.y);
             }
           }
         }
@@ -814,7 +959,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
           const size_t n = (size_t)((cv & 1) * 2 + nf);
-          const size_t off = (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + n) * 512 + lane * 8;
+          const int half = MF == 2 ? 0 : ((m0 >> 4) & 1) * 4;
+          st_p[nf] = p.o2_hi + (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + n) * 512 + lane * 8 + half;
           const float v0[4] = {av[nf][0][0], av[nf][0][1], av[nf][0][2], av[nf][0][3]};
           uint2 h0, l0;
           split4<O2_LO>(v0, h0, l0);
@@ -822,12 +968,56 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
             const float v1[4] = {av[nf][MF - 1][0], av[nf][MF - 1][1], av[nf][MF - 1][2], av[nf][MF - 1][3]};
             uint2 h1, l1;
             split4<O2_LO>(v1, h1, l1);
-            *reinterpret_cast<uint4*>(p.o2_hi + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            if (O2_LO) *reinterpret_cast<uint4*>(p.o2_hi + off + 2048) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            st_v[nf][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            if (O2_LO) st_v[nf][1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
           } else {
-            const int half = ((m0 >> 4) & 1) * 4;
-            *reinterpret_cast<uint2*>(p.o2_hi + off + half) = h0;
-            if (O2_LO) *reinterpret_cast<uint2*>(p.o2_hi + off + 2048 + half) = l0;
+            st_v[nf][0] = make_uint4(h0.x, h0.y, 0u, 0u);
+            if (O2_LO) st_v[nf][1] = make_uint4(l0.x, l0.y, 0u, 0u);
+          }
+        }
+      }
+    }
+  };
+  // the stores of epilogue(cc, parity, sw): same conditions, same order as the counted wait below expects
+  auto epilogue_store = [&](int cc, auto parity_tag, auto sw_tag) {
+    constexpr int PP = decltype(parity_tag)::value;
+    constexpr bool sw = decltype(sw_tag)::value;
+    if (EPI == RE_GEGLU) {
+      if (PP == 1) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+#ifdef OPK_ABL_NO_STORE
+          asm volatile("" ::"v"(st_v[mf][0]), "v"(st_p[mf]));
+          if (O0_LO) asm volatile("" ::"v"(st_v[mf][1]));
+#else
+          *reinterpret_cast<uint4*>(st_p[mf]) = st_v[mf][0];
+          if (O0_LO) *reinterpret_cast<uint4*>(st_p[mf] + 512) = st_v[mf][1];
+#endif
+        }
+      }
+    } else if (EPI == RE_QKV) {
+      if (sw) {
+        if (PP == 1) {
+          const bool is_q = cc < p.hidden / ROW_CHUNK;
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            *reinterpret_cast<uint4*>(st_p[mf]) = st_v[mf][0];
+            *reinterpret_cast<uint4*>(st_p[mf] + 1024) = st_v[mf][1];
+            if (QK_LO && (O0_LO == O1_LO || (is_q ? O0_LO : O1_LO))) {  // q and k may differ: wave-uniform select
+              *reinterpret_cast<uint4*>(st_p[mf] + 512) = st_v[mf][2];
+              *reinterpret_cast<uint4*>(st_p[mf] + 1536) = st_v[mf][3];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          if (MF == 2) {
+            *reinterpret_cast<uint4*>(st_p[nf]) = st_v[nf][0];
+            if (O2_LO) *reinterpret_cast<uint4*>(st_p[nf] + 2048) = st_v[nf][1];
+          } else {
+            *reinterpret_cast<uint2*>(st_p[nf]) = make_uint2(st_v[nf][0].x, st_v[nf][0].y);
+            if (O2_LO) *reinterpret_cast<uint2*>(st_p[nf] + 2048) = make_uint2(st_v[nf][1].x, st_v[nf][1].y);
           }
         }
       }
@@ -856,8 +1046,13 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     if (EPI == RE_QKV && SWP && !FIRST) {  // RoPE rows for the half-head (j = cur ^ 1) of the chunk finished last
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        rope_c[mf] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + (cur ^ 1) * 4);
-        rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + (cur ^ 1) * 4);
+        if (ROPE_PRELOAD) {
+          rope_c[mf] = rope_cc[mf][cur ^ 1];
+          rope_s[mf] = rope_ss[mf][cur ^ 1];
+        } else {
+          rope_c[mf] = *reinterpret_cast<const f32x4*>(rope_c_row[mf] + (cur ^ 1) * 4);
+          rope_s[mf] = *reinterpret_cast<const f32x4*>(rope_s_row[mf] + (cur ^ 1) * 4);
+        }
       }
     }
 #ifndef OPK_ABL_NO_DMA
@@ -878,6 +1073,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
     rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP)>(lds_stage[cur], a_hi, a_lo, acc);
+#if !defined(OPK_ABL_NO_EPILOGUE)
+    if (!FIRST) epilogue_store(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag);
+#endif
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -908,13 +1106,23 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         : EPI == RE_GEGLU ? (PPREV == 1 ? MF * (1 + (O0_LO ? 1 : 0)) : 0)
         : EPI == RE_QKV ? (SWP ? (PPREV == 1 ? MF * (2 + ((O0_LO && O1_LO) ? 2 : 0)) : 0) : 2 * (1 + (O2_LO ? 1 : 0)))
                         : 0;
+#ifdef OPK_TIMING
+    const unsigned long long opk_w0 = __builtin_readcyclecounter();
+#endif
 #if defined(OPK_ABL_NO_STORE) || defined(OPK_ABL_NO_EPILOGUE) || defined(OPK_STRICT_VMCNT)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
 #endif
+#ifdef OPK_TIMING
+    const unsigned long long opk_w1 = __builtin_readcyclecounter();
+    opk_wait1 += opk_w1 - opk_w0;
+#endif
 #ifndef OPK_ABL_NO_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
+#ifdef OPK_TIMING
+    opk_wait2 += __builtin_readcyclecounter() - opk_w1;
 #endif
   };
   // Even chunk counts on both sides of the q/k -> v boundary (checked on the host).  The first pair is peeled so
@@ -938,9 +1146,15 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       iteration(c0 + 1, odd, no, no, no);
     }
     epilogue(p.n_chunks - 1, odd, no, acc_prev);
+    epilogue_store(p.n_chunks - 1, odd, no);
   } else {
     epilogue(p.n_chunks - 1, odd, yes, acc_prev);
+    epilogue_store(p.n_chunks - 1, odd, yes);
   }
+  OPK_STAMP(5);
+  OPK_DUMP();
+#undef OPK_STAMP
+#undef OPK_DUMP
 }
 
 // ----------------------------------------------------------------------------------------------

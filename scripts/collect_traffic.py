@@ -2,7 +2,11 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate passes, TCC slots) into per-launch HBM
 traffic of each kernel kind bench.py names.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 128-byte requests of wide coalesced streams as 64 bytes, so reads are doubled
-(/opt/skills/guides/MI355X_MICROARCH.md, section HBM).
+(/opt/skills/guides/MI355X_MICROARCH.md, section HBM).  The guide leaves WRITE_SIZE uncalibrated; on this code's 16-byte
+per-lane stores it matches known byte counts (the attention kernel writes o as hi + lo planes, 2 x tokens x H x 2 B =
+134.2 MB at 256 x 512 tokens of xsmall, H = 256: WRITE_SIZE says 134.2 MB; the q / k / v^T planes of the first-layer
+projection: 402.7 MB known, 402.7 MB reported), so writes are taken as reported.  FETCH_SIZE counts L2 misses served by
+the Infinity Cache as well as by HBM: re-fetched weight panels show up in it although they never leave the die.
 Usage: collect_traffic.py <fetch_dir> <write_dir> <workload key> <out.json>
 The workload key is what bench.py prints as roofline.traffic_key minus the kernel kind:
 "<model>|<pairs>x<seq_len> or varlen|<kernel set>"."""
@@ -65,7 +69,7 @@ for kind in sorted(set(fetch) | set(write)):
         "fetch_size_kib_raw": f_kb,
         "write_size_kib_raw": w_kb,
         "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0,
-        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; reads x2 (gfx950 correction)",
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; reads x2 (gfx950 correction), writes as reported (they match known store byte counts)",
     }
     print(kind, precision, f"fetch {f_kb/1024:.1f} MiB raw, write {w_kb/1024:.1f} MiB -> {out[f'{kind}|{precision}']['hbm_bytes_per_launch']/1e6:.1f} MB/launch")
 json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Copy what scripts/rocprof_pass.sh left under gpurun_out/prof_<tag>/ into profiles/ (tracked): the rocprofv3
+kernel-stats CSV, the text summary of the stats + PMC passes, the bench line printed under rocprofv3, and the
+per-launch HBM traffic merged into profiles/pmc_traffic.json (the file bench.py reads roofline.traffic from).
+Usage: scripts/publish_profiles.py <tag> [<tag> ...]"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROFILES = os.path.join(ROOT, "profiles")
+traffic_path = os.path.join(PROFILES, "pmc_traffic.json")
+traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+for tag in sys.argv[1:]:
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(PROFILES, f"{tag}_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "summary.txt"), os.path.join(PROFILES, f"{tag}_rocprofv3_summary.txt"))
+    for line in open(os.path.join(src, "bench_under_rocprof.log")):
+        if line.startswith("{") and '"roofline"' in line:
+            json.dump(json.loads(line), open(os.path.join(PROFILES, f"{tag}_bench_under_rocprofv3.json"), "w"), indent=1)
+    part = os.path.join(src, "pmc_traffic.json")
+    if os.path.exists(part):
+        traffic.update(json.load(open(part)))
+    print("published", tag)
+json.dump(traffic, open(traffic_path, "w"), indent=1, sort_keys=True)
