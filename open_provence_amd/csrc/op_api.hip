@@ -373,7 +373,12 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.H = H;
       ap.r_pad = r_pad;
       ap.window = window;
-      const dim3 grid((unsigned)(is_global ? plan.items_g : plan.items_l), (unsigned)h->nh);
+      ap.n_items = is_global ? plan.items_g : plan.items_l;
+      ap.n_heads = h->nh;
+      ap.xcd_group = h->panel_path ? 1 : 0;  // XCD-aware block map: see attn_fp_kernel
+      const unsigned item_span = 8u * opk::ATT_ITEM_GROUP;
+      const dim3 grid((ap.xcd_group ? ((unsigned)ap.n_items + item_span - 1) / item_span * item_span : (unsigned)ap.n_items) *
+                      (unsigned)h->nh);
       if (!opl::launch_attn(st, ap, is_global ? plan.waves_g : 4, is_global ? 2 : 1, h->pi, zero_p_lo, grid))
         return fail(h, OP_ERR_UNSUPPORTED, "internal: no attention kernel for this configuration");
     } else {
