@@ -255,23 +255,31 @@ def main() -> None:
     for n in set(row_lengths):
         idx = np.arange(n)
         pairs_local += row_lengths.count(n) * float((np.minimum(idx + w, n - 1) - np.maximum(idx - w, 0) + 1).sum())
-    flops_per_forward = {  # algorithmic FLOPs of each kernel kind over one forward of this rank's batch
-        "gemm_qk_rope": 2.0 * total_tokens * H * 2 * H * n_layers,
-        "gemm_v_t": 2.0 * total_tokens * H * H * n_layers,
-        "gemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
-        "gemm_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,
-        "gemm_mlp_out": 2.0 * total_tokens * I * H * n_layers,
-        "fused_attnout_ln_wi_geglu": 2.0 * total_tokens * (H * H + H * 2 * I) * n_layers,
-        "fused_mlpout_ln_qkv_rope": 2.0 * total_tokens * (I * H + H * 3 * H) * (n_layers - 1),
-        "kstream_mlp_out": 2.0 * total_tokens * I * H,
+    # algorithmic FLOPs of each kernel kind over one forward of this rank's batch, by contraction family (the policy's
+    # term masks say how many bf16 MFMA products each family evaluates per algorithmic product)
+    T = float(total_tokens)
+    fam_flops = {
+        "gemm_qk_rope": {"wqkv": 2.0 * T * H * 2 * H * n_layers},
+        "gemm_v_t": {"wqkv": 2.0 * T * H * H * n_layers},
+        "gemm_attn_out": {"attn_out": 2.0 * T * H * H * n_layers},
+        "gemm_wi_geglu": {"wi": 2.0 * T * H * 2 * I * n_layers},
+        "gemm_mlp_out": {"mlp_out": 2.0 * T * I * H * n_layers},
+        "fused_attnout_ln_wi_geglu": {"attn_out": 2.0 * T * H * H * n_layers, "wi": 2.0 * T * H * 2 * I * n_layers},
+        "fused_mlpout_ln_qkv_rope": {"mlp_out": 2.0 * T * I * H * (n_layers - 1), "wqkv": 2.0 * T * H * 3 * H * (n_layers - 1)},
+        "kstream_mlp_out": {"mlp_out": 2.0 * T * I * H},
         # whole-layer kernel: attention output projection + MLP in every layer, + the next layer's q/k/v in all but the last
-        "fused_layer_attnout_mlp_qkv": 2.0 * total_tokens * ((H * H + 3 * H * I) * n_layers + 3 * H * H * (n_layers - 1)),
-        "rowgemm_ln_qkv_rope": 2.0 * total_tokens * H * 3 * H * n_layers,
-        "rowgemm_attn_out": 2.0 * total_tokens * H * H * n_layers,
-        "rowgemm_ln_wi_geglu": 2.0 * total_tokens * H * 2 * I * n_layers,
-        "attn_global": 4.0 * H * pairs_global * n_global,
-        "attn_local": 4.0 * H * pairs_local * (n_layers - n_global),
+        "fused_layer_attnout_mlp_qkv": {"attn_out": 2.0 * T * H * H * n_layers, "wi": 2.0 * T * H * 2 * I * n_layers,
+                                        "mlp_out": 2.0 * T * I * H * n_layers, "wqkv": 2.0 * T * H * 3 * H * (n_layers - 1)},
+        "rowgemm_ln_qkv_rope": {"wqkv": 2.0 * T * H * 3 * H * n_layers},
+        "rowgemm_attn_out": {"attn_out": 2.0 * T * H * H * n_layers},
+        "rowgemm_ln_wi_geglu": {"wi": 2.0 * T * H * 2 * I * n_layers},
+        "attn_global": {"qk": 2.0 * H * pairs_global * n_global, "pv": 2.0 * H * pairs_global * n_global},
+        "attn_local": {"qk": 2.0 * H * pairs_local * (n_layers - n_global), "pv": 2.0 * H * pairs_local * (n_layers - n_global)},
     }
+    flops_per_forward = {kind: sum(parts.values()) for kind, parts in fam_flops.items()}
+    terms = policy["terms"]
+    executed_per_forward = {kind: sum(f * (1 + (terms[fam] & 1) + ((terms[fam] >> 1) & 1)) for fam, f in parts.items())
+                            for kind, parts in fam_flops.items()}
     roofline = None
     if dominant in flops_per_forward:
         entry = profile[dominant]
@@ -298,6 +306,9 @@ def main() -> None:
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
             "traffic": traffic,
             "traffic_key": traffic_key,
+            # MFMA products actually issued (algorithmic flops x the policy's term count per family) against the same
+            # peak: how busy the matrix pipe is, as opposed to `frac` = useful work / peak
+            "mfma_executed_frac": executed_per_forward[dominant] / launches_per_forward / (entry["avg_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
             "avg_launch_ms": entry["avg_ms"],
             "algorithmic_flops_per_launch": flops_per_launch,
             "whole_forward_tflops": whole_tflops,
