@@ -462,12 +462,17 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           a_lo[mf][ks] = A_LO1 ? *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks * 1024 + 512) : a_hi[mf][ks];
         }
       stage_pair(0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // the residual rows are requested last and are not waited for here
       {
         const float* xrow = p.x_io + (size_t)(m0 + l15) * K + g * 8;
 #pragma unroll
         for (int nf = 0; nf < NF1; ++nf) xq0[nf] = *reinterpret_cast<const float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
       }
-      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      // vmcnt retires in order: everything but the NF1 residual-row loads (the A operand and this wave's share of the
+      // first weight stage) has landed; then all waves meet
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF1) : "memory");
+      __builtin_amdgcn_s_barrier();
       static_for<KS / 2>([&](auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         constexpr int cur = j & 1;
