@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD > 1024 ? 1024 : 256 * WAVES_PE
           else if (KIND == 5) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(pk[v & 3]));
           else if (KIND == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(fv[v & 7]));
           else if (KIND == 7) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(fv[v & 7]) : "v"(fc));
-          else asm volatile("v_sub_f32 %0, %0, %1" : "+v"(fv[v & 7]) : "v"(fc));
+          else if (KIND == 8) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(fv[v & 7]) : "v"(fc));
+          else if (KIND == 9) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv[0]) : "v"(fc));  // ONE dependent chain
+          else if (KIND == 10) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv[v & 1]) : "v"(fc));  // two chains
+          else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[0]) : "v"(fv[(v + 1) & 7]), "v"(fc));
         }
       }
   }
@@ -592,6 +595,11 @@ int main() {
   clock_probe<1, 1, 4, 6>("  4 v_exp_f32 / MFMA", sink);
   clock_probe<1, 1, 4, 7>("  4 v_mul_f32 / MFMA", sink);
   clock_probe<1, 1, 4, 8>("  4 v_sub_f32 / MFMA", sink);
+  clock_probe<1, 1, 2, 9>("  2 DEPENDENT v_fma_f32 / MFMA (one chain)", sink);
+  clock_probe<1, 1, 3, 9>("  3 DEPENDENT v_fma_f32 / MFMA (one chain)", sink);
+  clock_probe<1, 1, 4, 9>("  4 DEPENDENT v_fma_f32 / MFMA (one chain)", sink);
+  clock_probe<1, 1, 4, 10>("  4 v_fma_f32 / MFMA in two chains", sink);
+  clock_probe<2, 1, 4, 9>("  2 waves/SIMD: 4 DEPENDENT v_fma_f32 / MFMA", sink);
   clock_probe<2, 1, 4, 0>("  2 waves/SIMD: 4 v_fma_f32 / MFMA", sink);
   clock_probe<2, 1, 8, 0>("  2 waves/SIMD: 8 v_fma_f32 / MFMA", sink);
   printf("1024 blocks x 4 waves x 32 rows, K=256 bf16x3, 64 chunks of 32 features (one Wi GEMM of ModernBERT-xsmall)\n");

@@ -108,19 +108,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 // FMA, one med3 -- the VALU work next to the MFMAs is what these epilogues cost, instruction for instruction.  No
 // cancellation on either side of zero.  Max |gelu - exact| = 6.4e-7 over [-12, 12] evaluated in fp32 (offline, against
 // fp64 erf); the library erff costs ~3x the instructions.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float ax = fabsf(x);
-  float q = fmaf(-4.7330930829e-04f, ax, 7.0845573209e-03f);
-  q = fmaf(q, ax, -5.1827382296e-02f);
-  q = fmaf(q, ax, -4.5999243855e-01f);
-  q = fmaf(q, ax, -1.1507878304e+00f);
-  q = fmaf(q, ax, -1.0000376701e+00f);
-  const float he = __builtin_amdgcn_exp2f(q);
+// The evaluation in stages (the one-wave-per-SIMD layer kernel runs stage k of ALL values of a chunk in one step of
+// its MFMA stream: a vector instruction that depends on the previous one costs the wave 8 issue cycles, an independent
+// one 4.5 -- microbench/mfma_loop.hip): q after stage 0..4, he after 5, gelu after 6.
+__device__ __forceinline__ float gelu_erf_poly(float q, float ax, int stage) {
+  switch (stage) {
+    case 0: return fmaf(-4.7330930829e-04f, ax, 7.0845573209e-03f);
+    case 1: return fmaf(q, ax, -5.1827382296e-02f);
+    case 2: return fmaf(q, ax, -4.5999243855e-01f);
+    case 3: return fmaf(q, ax, -1.1507878304e+00f);
+    default: return fmaf(q, ax, -1.0000376701e+00f);
+  }
+}
+__device__ __forceinline__ float gelu_erf_finish(float he, float x) {
   // max(x, 0) in ONE instruction: fmaxf and med3(x, 0, +inf) both come out of the compiler as a NaN-quieting
   // v_max x, x followed by v_max 0, x
   float relu;
   asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
-  return fmaf(-he, ax, relu);
+  return fmaf(-he, fabsf(x), relu);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x);
+  float q = gelu_erf_poly(0.f, ax, 0);
+#pragma unroll
+  for (int k = 1; k < 5; ++k) q = gelu_erf_poly(q, ax, k);
+  return gelu_erf_finish(__builtin_amdgcn_exp2f(q), x);
 }
 
 // rowgemm_kernel epilogues: q/k/v projection (RoPE, fragment-packed q, k, v^T), GeGLU (fragment-packed h), or no chunk

@@ -668,6 +668,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       uint2 hold_hi[MF], hold_lo[MF];
       bf16x8 h_hi[MF], h_lo[MF];
       float g_prev[MF][4], g_cur[MF][4];  // GeGLU values of the chunk finished last / of this pair's first chunk
+      float gx[MF * 4], gq[MF * 4];       // GeGLU in flight: inputs and the running polynomial / exponential / result
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         hold_hi[mf] = hold_lo[mf] = make_uint2(0u, 0u);
@@ -692,17 +693,41 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         });
         return;
 #endif
+#if defined(OPK_ABL_NO_GELU) || defined(OPK_ABL_NO_EPILOGUE)
         static_for<VPS>([&](auto j_tag) {
           constexpr int i = sl * VPS + decltype(j_tag)::value;
           if constexpr (i < NV) {
-#if defined(OPK_ABL_NO_GELU) || defined(OPK_ABL_NO_EPILOGUE)
             gv[i >> 2][i & 3] = av[0][i >> 2][i & 3] * av[1][i >> 2][i & 3];
-#else
-            gv[i >> 2][i & 3] = gelu_erf(av[0][i >> 2][i & 3]) * av[1][i >> 2][i & 3];
-#endif
             if constexpr ((i & 3) == 3) pack(std::integral_constant<int, (i >> 2)>{});
           }
         });
+#else
+        // Stage-major: slice sl advances ALL NV values of the chunk by 8 / KS stages of gelu(input) * gate (five
+        // polynomial FMAs, exp2, the final FMA, the product with the gate + split / pack), so consecutive vector
+        // instructions belong to different values: no instruction waits for the one issued just before it.
+        constexpr int STAGES_PER_SLICE = 8 / KS;
+        static_assert(KS == 8 || KS == 4, "eight GeGLU stages over the k-steps of a chunk");
+        static_for<STAGES_PER_SLICE>([&](auto u_tag) {
+          constexpr int st = sl * STAGES_PER_SLICE + decltype(u_tag)::value;
+          static_for<NV>([&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            constexpr int mf = i >> 2, r = i & 3;
+            if constexpr (st == 0) {
+              gx[i] = av[0][mf][r];
+              gq[i] = gelu_erf_poly(0.f, fabsf(gx[i]), 0);
+            } else if constexpr (st < 5) {
+              gq[i] = gelu_erf_poly(gq[i], fabsf(gx[i]), st);
+            } else if constexpr (st == 5) {
+              gq[i] = __builtin_amdgcn_exp2f(gq[i]);
+            } else if constexpr (st == 6) {
+              gq[i] = gelu_erf_finish(gq[i], gx[i]);
+            } else {
+              gv[mf][r] = gq[i] * av[1][mf][r];
+            }
+          });
+          if constexpr (st == 7) static_for<MF>([&](auto mf_tag) { pack(mf_tag); });
+        });
+#endif
       };
       auto pack_h = [&](auto mf_tag) {  // second half of a pair -> the pair's h fragment of this row fragment
         constexpr int mf = decltype(mf_tag)::value;
