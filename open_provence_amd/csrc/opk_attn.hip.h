@@ -339,8 +339,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
         split4<O_LO>(v0, h0, l0);
         split4<O_LO>(v1, h1, l1);
         u16* dst = p.o_fp + (((q_rb + qf) * kbn + head * 2 + half) * 2) * 512 + lane * 8;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        if (O_LO) *reinterpret_cast<uint4*>(dst + 512) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        store_stream16(dst, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        if (O_LO) store_stream16(dst + 512, make_uint4(l0.x, l0.y, l1.x, l1.y));
       }
     }
   }

@@ -80,6 +80,11 @@ __device__ __forceinline__ bf16x8 as_frag(uint4 u) {
   f.u = u;
   return f.v;
 }
+__device__ __forceinline__ uint4 as_u4(bf16x8 v) {
+  FragU f;
+  f.v = v;
+  return f.u;
+}
 // Load the fragment as an ext-vector type: an LDS load typed as HIP's uint4 class makes hipcc (ROCm 7.2) treat it
 // as possibly aliasing an in-flight global_load_lds DMA and drain the DMA (s_waitcnt vmcnt(0)) in front of it.
 __device__ __forceinline__ bf16x8 lds_frag(const u16* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -100,6 +105,28 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// Stores of tensors that the launch writing them never reads back (q / k / v^T / o / h pieces, the residual stream's
+// write-back) are non-temporal (global_store ... nt).  As ordinary stores they displace the next block's operands from
+// the XCD's L2: in the whole-layer kernel the phase that starts a block (operand fetch + attention-output projection)
+// took 37 k cycles behind the previous block's 393 KB of plain q / k / v^T stores, 28 k behind nt stores, 26 k with the
+// residual write-back nt as well (microbench/rowgemm_ablate.hip -DOPK_TIMING).  -DOPK_PLAIN_STORES restores plain stores.
+__device__ __forceinline__ void store_stream16(void* dst, const uint4& v) {
+#ifdef OPK_PLAIN_STORES
+  *reinterpret_cast<uint4*>(dst) = v;
+#else
+  typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(dst));
+#endif
+}
+__device__ __forceinline__ void store_stream16(float* dst, const float4& v) {
+#ifdef OPK_PLAIN_STORES
+  *reinterpret_cast<float4*>(dst) = v;
+#else
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(dst));
+#endif
 }
 
 // GELU (exact-erf form) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |x| he(|x|),  he(a) = erfc(a / sqrt 2) / 2,

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
         bf16x8 hi, lo;
         pack8<O0_LO>(v, hi, lo);
         u16* dst = p.o0 + ((rb * kb_out + (size_t)(tile * 4 + s)) * 2) * 512 + lane * 8;
-        *reinterpret_cast<bf16x8*>(dst) = hi;
-        if (O0_LO) *reinterpret_cast<bf16x8*>(dst + 512) = lo;
+        store_stream16(dst, as_u4(hi));
+        if (O0_LO) store_stream16(dst + 512, as_u4(lo));
       }
     }
   } else if (EPI == PE_QK) {
@@ -264,11 +264,11 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
         pack8<(O0_LO || O1_LO)>(lo_half, h0, l0);
         pack8<(O0_LO || O1_LO)>(hi_half, h1, l1);
         u16* dst = out + ((rb * kb_out + (size_t)((tq * 4 + hh) * 2)) * 2) * 512 + lane * 8;
-        *reinterpret_cast<bf16x8*>(dst) = h0;
-        *reinterpret_cast<bf16x8*>(dst + 1024) = h1;
+        store_stream16(dst, as_u4(h0));
+        store_stream16(dst + 1024, as_u4(h1));
         if ((O0_LO || O1_LO) && (O0_LO == O1_LO || (is_q ? O0_LO : O1_LO))) {
-          *reinterpret_cast<bf16x8*>(dst + 512) = l0;
-          *reinterpret_cast<bf16x8*>(dst + 1536) = l1;
+          store_stream16(dst + 512, as_u4(l0));
+          store_stream16(dst + 1536, as_u4(l1));
         }
       }
     }
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
       bf16x8 hi, lo;
       pack8<O0_LO>(v, hi, lo);
       u16* dst = p.o0 + (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + (size_t)(nf & 3)) * 512 + lane * 8;
-      *reinterpret_cast<bf16x8*>(dst) = hi;
-      if (O0_LO) *reinterpret_cast<bf16x8*>(dst + 2048) = lo;
+      store_stream16(dst, as_u4(hi));
+      if (O0_LO) store_stream16(dst + 2048, as_u4(lo));
     }
   }
 }

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
             r4.w += x4.w;
             acc1[nf][mf] = f32x4{r4.x, r4.y, r4.z, r4.w};
           }
-          if (STORE) *px = r4;
+          if (STORE) store_stream16(reinterpret_cast<float*>(px), r4);
           sum += (r4.x + r4.y) + (r4.z + r4.w);
           // keep the scheduler from hoisting all 16 row loads (64 more registers) on top of the accumulators
           if (((LOAD && !XPRE) || STORE) && (nf & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     }
   };
   // the stores of epilogue(cc, parity, sw): same conditions, same order as the counted wait below expects
+  auto st16 = [&](u16* dst, const uint4& v) { store_stream16(dst, v); };  // see store_stream16
   auto epilogue_store = [&](int cc, auto parity_tag, auto sw_tag) {
     constexpr int PP = decltype(parity_tag)::value;
     constexpr bool sw = decltype(sw_tag)::value;
@@ -1020,8 +1021,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           asm volatile("" ::"v"(st_v[mf][0]), "v"(st_p[mf]));
           if (O0_LO) asm volatile("" ::"v"(st_v[mf][1]));
 #else
-          *reinterpret_cast<uint4*>(st_p[mf]) = st_v[mf][0];
-          if (O0_LO) *reinterpret_cast<uint4*>(st_p[mf] + 512) = st_v[mf][1];
+          st16(st_p[mf], st_v[mf][0]);
+          if (O0_LO) st16(st_p[mf] + 512, st_v[mf][1]);
 #endif
         }
       }
@@ -1031,11 +1032,11 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           const bool is_q = cc < p.hidden / ROW_CHUNK;
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) {
-            *reinterpret_cast<uint4*>(st_p[mf]) = st_v[mf][0];
-            *reinterpret_cast<uint4*>(st_p[mf] + 1024) = st_v[mf][1];
+            st16(st_p[mf], st_v[mf][0]);
+            st16(st_p[mf] + 1024, st_v[mf][1]);
             if (QK_LO && (O0_LO == O1_LO || (is_q ? O0_LO : O1_LO))) {  // q and k may differ: wave-uniform select
-              *reinterpret_cast<uint4*>(st_p[mf] + 512) = st_v[mf][2];
-              *reinterpret_cast<uint4*>(st_p[mf] + 1536) = st_v[mf][3];
+              st16(st_p[mf] + 512, st_v[mf][2]);
+              st16(st_p[mf] + 1536, st_v[mf][3]);
             }
           }
         }
@@ -1043,8 +1044,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
           if (MF == 2) {
-            *reinterpret_cast<uint4*>(st_p[nf]) = st_v[nf][0];
-            if (O2_LO) *reinterpret_cast<uint4*>(st_p[nf] + 2048) = st_v[nf][1];
+            st16(st_p[nf], st_v[nf][0]);
+            if (O2_LO) st16(st_p[nf] + 2048, st_v[nf][1]);
           } else {
             *reinterpret_cast<uint2*>(st_p[nf]) = make_uint2(st_v[nf][0].x, st_v[nf][0].y);
             if (O2_LO) *reinterpret_cast<uint2*>(st_p[nf] + 2048) = make_uint2(st_v[nf][1].x, st_v[nf][1].y);
