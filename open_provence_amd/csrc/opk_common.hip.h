@@ -129,6 +129,24 @@ __device__ __forceinline__ void store_stream16(float* dst, const float4& v) {
 #endif
 }
 
+// The matching loads for operands a launch reads exactly once (activation fragments, residual rows): global_load ... nt.
+__device__ __forceinline__ bf16x8 load_stream_frag(const u16* src) {
+#ifdef OPK_PLAIN_LOADS
+  return *reinterpret_cast<const bf16x8*>(src);
+#else
+  return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src));
+#endif
+}
+__device__ __forceinline__ float4 load_stream_f4(const float* src) {
+#ifdef OPK_PLAIN_LOADS
+  return *reinterpret_cast<const float4*>(src);
+#else
+  typedef float f32x4_ntl __attribute__((ext_vector_type(4)));
+  const f32x4_ntl v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ntl*>(src));
+  return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+
 // GELU (exact-erf form) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |x| he(|x|),  he(a) = erfc(a / sqrt 2) / 2,
 // with he(a) = 2^q(a), q a degree-5 polynomial (weighted minimax fit of log2 he on [0, 10], weight a he(a); leading
 // coefficient negative, so q -> -inf and he -> 0 for large |x|).  Eight instructions: five FMAs, one v_exp_f32, one

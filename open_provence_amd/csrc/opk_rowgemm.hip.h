@@ -458,15 +458,15 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-          a_hi[mf][ks] = *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks * 1024);
-          a_lo[mf][ks] = A_LO1 ? *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks * 1024 + 512) : a_hi[mf][ks];
+          a_hi[mf][ks] = load_stream_frag(a_base0 + mf * a_block + (size_t)ks * 1024);
+          a_lo[mf][ks] = A_LO1 ? load_stream_frag(a_base0 + mf * a_block + (size_t)ks * 1024 + 512) : a_hi[mf][ks];
         }
       stage_pair(0, 0);
       __builtin_amdgcn_sched_barrier(0);  // the residual rows are requested last and are not waited for here
       {
         const float* xrow = p.x_io + (size_t)(m0 + l15) * K + g * 8;
 #pragma unroll
-        for (int nf = 0; nf < NF1; ++nf) xq0[nf] = *reinterpret_cast<const float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
+        for (int nf = 0; nf < NF1; ++nf) xq0[nf] = load_stream_f4(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
       }
       __builtin_amdgcn_sched_barrier(0);
       // vmcnt retires in order: everything but the NF1 residual-row loads (the A operand and this wave's share of the
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       if (XPRE && MF > 1) {
         const float* xrow1 = p.x_io + (size_t)(m0 + 16 + l15) * K + g * 8;
 #pragma unroll
-        for (int nf = 0; nf < NF1; ++nf) xq1[nf] = *reinterpret_cast<const float4*>(xrow1 + 32 * (nf >> 1) + 4 * (nf & 1));
+        for (int nf = 0; nf < NF1; ++nf) xq1[nf] = load_stream_f4(xrow1 + 32 * (nf >> 1) + 4 * (nf & 1));
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
