@@ -113,8 +113,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const u16* src = p.q_fp + (((q_rb + qf) * kbn + head * 2 + ks) * 2) * 512 + lane * 8;
-      qf_hi[qf][ks] = *reinterpret_cast<const bf16x8*>(src);
-      qf_lo[qf][ks] = Q_LO ? *reinterpret_cast<const bf16x8*>(src + 512) : qf_hi[qf][ks];
+      qf_hi[qf][ks] = load_stream_frag(src);
+      qf_lo[qf][ks] = Q_LO ? load_stream_frag(src + 512) : qf_hi[qf][ks];
     }
 #pragma unroll
   for (int qf = 0; qf < 2; ++qf)

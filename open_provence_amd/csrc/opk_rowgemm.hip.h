@@ -426,8 +426,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     auto load_a1 = [&](int ks1) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        an_hi[mf] = *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks1 * 1024);
-        an_lo[mf] = A_LO1 ? *reinterpret_cast<const bf16x8*>(a_base0 + mf * a_block + (size_t)ks1 * 1024 + 512) : an_hi[mf];
+        an_hi[mf] = load_stream_frag(a_base0 + mf * a_block + (size_t)ks1 * 1024);
+        an_lo[mf] = A_LO1 ? load_stream_frag(a_base0 + mf * a_block + (size_t)ks1 * 1024 + 512) : an_hi[mf];
       }
     };
     f32x4 acc1[NF1][MF];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
           float4 r4 = make_float4(acc1[nf][mf][0], acc1[nf][mf][1], acc1[nf][mf][2], acc1[nf][mf][3]);
           if (LOAD) {
-            const float4 x4 = XPRE ? (mf == 0 ? xq0[nf] : xq1[(XPRE && MF > 1) ? nf : 0]) : *px;
+            const float4 x4 = XPRE ? (mf == 0 ? xq0[nf] : xq1[(XPRE && MF > 1) ? nf : 0]) : load_stream_f4(reinterpret_cast<const float*>(px));
             r4.x += x4.x;
             r4.y += x4.y;
             r4.z += x4.z;
@@ -864,8 +864,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       const size_t row = (size_t)(m0 + mf * 16 + l15);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const float4 f0 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8);
-        const float4 f1 = *reinterpret_cast<const float4*>(p.x_in + row * K + ks * 32 + g * 8 + 4);
+        const float4 f0 = load_stream_f4(p.x_in + row * K + ks * 32 + g * 8);
+        const float4 f1 = load_stream_f4(p.x_in + row * K + ks * 32 + g * 8 + 4);
         const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
         pack8<A_LO>(v, a_hi[mf][ks], a_lo[mf][ks]);
       }
@@ -1335,12 +1335,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void kstream_gemm_kernel(KStreamPara
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       float4* px = reinterpret_cast<float4*>(xrow + 32 * (nf >> 1) + 4 * (nf & 1));
-      float4 r4 = *px;
+      float4 r4 = load_stream_f4(reinterpret_cast<const float*>(px));
       r4.x += acc[nf][mf][0];
       r4.y += acc[nf][mf][1];
       r4.z += acc[nf][mf][2];
       r4.w += acc[nf][mf][3];
-      *px = r4;
+      store_stream16(reinterpret_cast<float*>(px), r4);
     }
   }
 }
