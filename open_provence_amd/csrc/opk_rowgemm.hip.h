@@ -204,19 +204,23 @@ struct MlpStreamOff {
 // One weight chunk (32 output features x K) against this wave's 32 rows: 2 x 2 accumulators, K/32 k-steps of
 // 4 MFMAs per product term, weight fragments two k-steps deep in registers (see above).  `lds_addr` = LDS byte
 // address of this lane's 16 bytes in piece 0 of stage 0; STAGE_BYTES = compile-time offset of the stage to read.
-template <int KS, int MF, int T, bool SWAPPED, int STAGE_BYTES, bool PIN_AGPR = false>
+template <int KS, int MF, int T, bool SWAPPED, int STAGE_BYTES, bool PIN_AGPR = false, int DEPTH = 1>
 __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16x8 (&a_hi)[MF][KS],
                                                    const bf16x8 (&a_lo)[MF][KS], f32x4 (&acc)[2][MF]) {
   constexpr bool W_LO = (T & T_RIGHT_LO) != 0, A_LO = (T & T_LEFT_LO) != 0;
   constexpr int PLANES = W_LO ? 2 : 1;
   constexpr int STEP_DS = 2 * PLANES;  // fragment reads per k-step
-  bf16x8 wh[2][2], wl[2][2];           // [register set][fragment]
-  auto read_step = [&](auto ks_tag, auto set_tag, auto pinned_tag) {
+  // DEPTH k-steps of fragment reads stay in flight behind the one being multiplied, in DEPTH + 1 rotating register
+  // sets.  DEPTH = 1 everywhere: 2 measured no faster in the one-wave-per-SIMD layer kernel (48.0 k vs 49.1 k cycles
+  // for its q / k / v^T loop) -- the loop is not waiting for LDS.
+  constexpr int SETS = DEPTH + 1;
+  bf16x8 wh[SETS][2], wl[SETS][2];  // [register set][fragment]
+  auto read_step = [&](auto ks_tag, auto pinned_tag) {
     constexpr int ks = decltype(ks_tag)::value;
-    constexpr int S = decltype(set_tag)::value;
+    constexpr int S = ks % SETS;
     constexpr bool PINNED = decltype(pinned_tag)::value;
     constexpr int base = STAGE_BYTES + (ks * PLANES) * 2048;
-    // the first read of the group is ordered behind every MFMA of the k-step two before it (and ahead of the next's)
+    // the first read of the group is ordered behind every MFMA of the k-step whose set it re-uses (and ahead of the next's)
     if (!PINNED) wh[S][0] = lds_read_frag<base>(lds_addr);
     else if (MF == 2) wh[S][0] = lds_read_frag_after<base, PIN_AGPR>(lds_addr, acc[0][0], acc[0][MF - 1], acc[1][0], acc[1][MF - 1]);
     else wh[S][0] = lds_read_frag_after<base, PIN_AGPR>(lds_addr, acc[0][0], acc[1][0]);
@@ -226,14 +230,9 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16
       wl[S][1] = lds_read_frag<base + 2048 + 1024>(lds_addr);
     }
   };
-  auto wait_step = [&](auto set_tag, auto last_tag) {
-    constexpr int S = decltype(set_tag)::value;
-    constexpr int N = decltype(last_tag)::value ? 0 : STEP_DS;  // the next k-step's reads may stay in flight
-    if (W_LO) lds_wait4<N>(wh[S][0], wh[S][1], wl[S][0], wl[S][1]);
-    else lds_wait2<N>(wh[S][0], wh[S][1]);
-  };
-  auto mfma_step = [&](int ks, auto set_tag) {
-    constexpr int S = decltype(set_tag)::value;
+  auto mfma_step = [&](auto ks_tag) {
+    constexpr int ks = decltype(ks_tag)::value;
+    constexpr int S = ks % SETS;
     // The product terms are issued term-major over the four accumulators: an accumulator is touched every
     // fourth MFMA, so no MFMA waits for the result of the previous one.
 #pragma unroll
@@ -250,39 +249,18 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16
       }
     }
   };
-  static_assert(KS == 4 || KS == 8, "k-steps are unrolled by hand below");
-  const std::integral_constant<int, 0> s0{};
-  const std::integral_constant<int, 1> s1{};
   const std::true_type yes{};
   const std::false_type no{};
-#define OPK_KS(n) std::integral_constant<int, n>{}
-  read_step(OPK_KS(0), s0, no);
-  read_step(OPK_KS(1), s1, no);
-  wait_step(s0, no);
-  mfma_step(0, s0);
-  read_step(OPK_KS(2), s0, yes);
-  wait_step(s1, no);
-  mfma_step(1, s1);
-  read_step(OPK_KS(3), s1, yes);
-  wait_step(s0, no);
-  mfma_step(2, s0);
-  if (KS == 8) {
-    read_step(OPK_KS(4 % KS), s0, yes);
-    wait_step(s1, no);
-    mfma_step(3, s1);
-    read_step(OPK_KS(5 % KS), s1, yes);
-    wait_step(s0, no);
-    mfma_step(4 % KS, s0);
-    read_step(OPK_KS(6 % KS), s0, yes);
-    wait_step(s1, no);
-    mfma_step(5 % KS, s1);
-    read_step(OPK_KS(7 % KS), s1, yes);
-    wait_step(s0, no);
-    mfma_step(6 % KS, s0);
-  }
-  wait_step(s1, yes);
-  mfma_step(KS - 1, s1);
-#undef OPK_KS
+  static_for<(SETS < KS ? SETS : KS)>([&](auto t) { read_step(t, no); });
+  static_for<KS>([&](auto t) {
+    constexpr int ks = decltype(t)::value;
+    constexpr int S = ks % SETS;
+    constexpr int ahead = (KS - 1 - ks) < DEPTH ? (KS - 1 - ks) : DEPTH;  // k-steps whose reads may stay in flight
+    if (W_LO) lds_wait4<STEP_DS * ahead>(wh[S][0], wh[S][1], wl[S][0], wl[S][1]);
+    else lds_wait2<STEP_DS * ahead>(wh[S][0], wh[S][1]);
+    mfma_step(t);
+    if constexpr (ks + SETS < KS) read_step(std::integral_constant<int, ks + SETS>{}, yes);
+  });
 }
 
 // T2 = term mask of the chunk loop's GEMM (left = this block's rows, right = the streamed weight), T1 = term mask of
