@@ -139,6 +139,9 @@ def main() -> None:
     parser.add_argument("--no-long", action="store_true", help="skip the seq_len 2048 sub-record")
     parser.add_argument("--varlen", action="store_true",
                         help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
+    parser.add_argument("--exercise-gather", action="store_true",
+                        help="test hook: run the N > 1 code path (process group, ShardPlan, gather, MAX all-reduce) on a "
+                        "one-rank RCCL group, so that it is executed on hardware even where only one GPU is granted")
     args = parser.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,10 +156,12 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    grouped = world > 1 or args.exercise_gather
+    if grouped:
         import torch.distributed as dist  # type: ignore[no-redef]
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     dims = named_dims(args.model)
@@ -178,7 +183,7 @@ def main() -> None:
         n_pairs_rank = len(rows)
     else:
         rows_all = synth_pair_batch(dims, args.pairs * world, args.seq_len, seed=1234)
-        if world > 1:
+        if grouped:
             from open_provence_amd.sharding import ShardPlan
 
             plan = ShardPlan([len(r) for r in rows_all], world, width=1, num_labels=dims.num_labels)
@@ -200,7 +205,7 @@ def main() -> None:
         return prune, rank_logits
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -217,7 +222,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -233,8 +238,7 @@ def main() -> None:
     encoder.profile_enable(False)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -373,7 +377,7 @@ def main() -> None:
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dims, state, args.seq_len)
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

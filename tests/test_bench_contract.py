@@ -33,3 +33,21 @@ def test_bench_json_line_contract():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_on_a_one_rank_group():
+    """The N > 1 branch of bench.py (RCCL process group, ShardPlan partition, gather inside the timed step, MAX
+    all-reduce of the elapsed time) executed on hardware with a one-rank group: same contract, same value formula."""
+
+    proc = subprocess.run(
+        [sys.executable, str(REPO_ROOT / "bench.py"), "--pairs", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+         "--no-long", "--exercise-gather"],
+        capture_output=True, text=True, timeout=600,
+    )
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == 1 and line["config"]["outputs_finite"] is True and line["value"] > 0
