@@ -265,6 +265,7 @@ def main() -> None:
     fam_flops = {
         "gemm_qk_rope": {"wqkv": 2.0 * T * H * 2 * H * n_layers},
         "gemm_v_t": {"wqkv": 2.0 * T * H * H * n_layers},
+        "gemm_qkv_rope": {"wqkv": 2.0 * T * H * 3 * H * n_layers},
         "gemm_attn_out": {"attn_out": 2.0 * T * H * H * n_layers},
         "gemm_wi_geglu": {"wi": 2.0 * T * H * 2 * I * n_layers},
         "gemm_mlp_out": {"mlp_out": 2.0 * T * I * H * n_layers},

@@ -48,6 +48,7 @@ enum ProfileKind {
   PK_FUSED_MLP_OUT_QKV,
   PK_CLEAR_LO,
   PK_FUSED_LAYER,
+  PK_GEMM_QKV_ROPE,
   PK_COUNT
 };
 const char* kProfileNames[PK_COUNT] = {"rowmap",        "embed_ln",      "layer_norm",    "gemm_qk_rope", "gemm_v_t",
@@ -55,7 +56,7 @@ const char* kProfileNames[PK_COUNT] = {"rowmap",        "embed_ln",      "layer_
                                        "gemm_mlp_out",  "final_ln_prune", "rank_head",    "capture",
                                        "rowgemm_ln_qkv_rope", "rowgemm_attn_out", "rowgemm_ln_wi_geglu",
                                        "kstream_mlp_out", "fused_attnout_ln_wi_geglu", "fused_mlpout_ln_qkv_rope",
-                                       "clear_lo_planes", "fused_layer_attnout_mlp_qkv"};
+                                       "clear_lo_planes", "fused_layer_attnout_mlp_qkv", "gemm_qkv_rope"};
 
 struct LayerWeights {
   float* attn_norm = nullptr;  // absent on layer 0
@@ -559,7 +560,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         const unsigned per_xcd = ((unsigned)(r_pad / ROW_BM) + 7) / 8;  // row blocks each XCD owns
         const unsigned groups = (per_xcd + q.row_group - 1) / q.row_group;
         const dim3 grid(8u * groups * (unsigned)q.row_group * (unsigned)n_tiles);  // XCD-aware block map: see panel_gemm_kernel
-        if (!opl::launch_panel(st, q, epi, h->pi, grid)) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
+        if (epi == 102 ? !opl::launch_panel_qkv(st, q, h->pi, grid) : !opl::launch_panel(st, q, epi, h->pi, grid)) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
         return L.end();
       };
       // layer 0: attn_norm is Identity -> plain split
@@ -577,10 +578,16 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       pp.wp = lw.wqkv_pk;
       pp.o0 = ws.q_hi;
       pp.o1 = ws.k_hi;
-      OP_TRY(panel(PK_GEMM_QK_ROPE, PE_QK, pp, 2 * H / 256));
-      pp.wp = lw.wqkv_pk + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
-      pp.o0 = ws.vt_hi;
-      OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
+      if (!(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION)) {  // q, k, v^T in one launch
+        pp.o2 = ws.vt_hi;
+        pp.n_qk_tiles = 2 * H / 256;
+        OP_TRY(panel(PK_GEMM_QKV_ROPE, 102, pp, 3 * H / 256));
+      } else {
+        OP_TRY(panel(PK_GEMM_QK_ROPE, PE_QK, pp, 2 * H / 256));
+        pp.wp = lw.wqkv_pk + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
+        pp.o0 = ws.vt_hi;
+        OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
+      }
       OP_TRY(clear_qkv());
       OP_TRY(attention(is_global));
       pp.a_fp = ws.o_hi;

@@ -55,5 +55,7 @@ bool launch_row_layer_fused(hipStream_t st, const opk::RowGemmParams& p, int ks,
 // zero_p_lo (pi == 0 only): the policy has no lo(p) x hi(v) term.
 bool launch_attn(hipStream_t st, const opk::AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid);
 bool launch_panel(hipStream_t st, const opk::PanelParams& p, int epi, int pi, dim3 grid);
+// q, k and v^T panels of one layer in one launch (p.n_tiles = 3 H / 256, p.n_qk_tiles = 2 H / 256, p.o2 = v^T)
+bool launch_panel_qkv(hipStream_t st, const opk::PanelParams& p, int pi, dim3 grid);
 
 }  // namespace opl

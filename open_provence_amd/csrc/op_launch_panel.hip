@@ -26,7 +26,23 @@ bool launch_pi(hipStream_t st, const PanelParams& p, int epi, dim3 grid) {
   return true;
 }
 
+template <int PI>
+void launch_qkv_pi(hipStream_t st, const PanelParams& p, dim3 grid) {
+  constexpr Policy P = kPolicies[PI];
+  hipLaunchKernelGGL((panel_qkv_kernel<P.wqkv, (P.qk & 3), ((P.pv & 2) ? 1 : 0)>), grid, dim3(256), 0, st, p);
+}
+
 }  // namespace
+
+bool launch_panel_qkv(hipStream_t st, const PanelParams& p, int pi, dim3 grid) {
+  static_assert(N_POLICIES == 3, "extend the switch below");
+  switch (pi) {
+    case 0: launch_qkv_pi<0>(st, p, grid); return true;
+    case 1: launch_qkv_pi<1>(st, p, grid); return true;
+    case 2: launch_qkv_pi<2>(st, p, grid); return true;
+    default: return false;
+  }
+}
 
 bool launch_panel(hipStream_t st, const PanelParams& p, int epi, int pi, dim3 grid) {
   static_assert(N_POLICIES == 3, "extend the switch below");

@@ -77,6 +77,8 @@ struct PanelParams {
   float* x;          // PE_RESIDUAL
   u16* o0;           // PE_QK: q   PE_V: v^T   PE_GEGLU: h   (fragment-packed, hi/lo planes interleaved per piece)
   u16* o1;           // PE_QK: k
+  u16* o2;           // fused q / k / v launch: v^T (panels n_qk_tiles .. n_tiles - 1)
+  int n_qk_tiles;    // fused q / k / v launch: panels of q and k (= 2 H / 256)
   const int32_t* row_pos;
   const float* rope_cos;
   const float* rope_sin;
@@ -92,8 +94,13 @@ struct PanelParams {
 // the n_tiles blocks that read the same 128 activation rows follow each other on ONE XCD and share that XCD's L2:
 // the activation planes leave HBM once instead of once per panel (measured on the base model, H = 768, I = 1152:
 // the Wi GEMM fetched 5.4 GB per launch for 1.0 GB of operands with the row-block-major grid).
+constexpr int panel_stage_elems(int T) { return 16 * (((T & T_RIGHT_LO) != 0) ? 2 : 1) * 512; }
+
+// One block's panel: rows [row_block * 128, +128) x panel `wtile_index` of the packed weights; `tile` is the panel's index
+// inside its own output tensor (q / k panels count from 0, so do the v^T panels of the fused launch).
 template <int EPI, int T, int OLO>
-__global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
+__device__ __forceinline__ void panel_block(const PanelParams& p, int row_block, int wtile_index, int tile, u16* __restrict__ o0,
+                                            u16 (&sW)[2][panel_stage_elems(T)]) {
   constexpr int NF = 16;
   constexpr bool W_LO = (T & T_RIGHT_LO) != 0, A_LO = (T & T_LEFT_LO) != 0;
   constexpr bool O0_LO = (OLO & 1) != 0, O1_LO = (OLO & 2) != 0;
@@ -102,22 +109,16 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
   constexpr int SLAB_SRC = NF * 2 * 512;     // elements per k-step in the packed weights (both planes)
   constexpr int WAVE_PIECES = (NF * PLANES) / 4;
   constexpr bool SWAPPED = (EPI != PE_V);    // weights as the MFMA row operand, except for v^T
-  __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE];
+  static_assert(STAGE == panel_stage_elems(T), "stage size");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
   const int g = lane >> 4;
-  const int xcd_slot = blockIdx.x >> 3;
-  const int group_blocks = p.row_group * p.n_tiles;
-  const int in_group = xcd_slot % group_blocks;
-  const int row_block = ((xcd_slot / group_blocks) * p.row_group + in_group % p.row_group) * 8 + (blockIdx.x & 7);
-  if (row_block * ROW_BM >= p.r_pad) return;  // the grid is rounded up to whole groups
   const int m0 = row_block * ROW_BM + wave * 32;
-  const int tile = in_group / p.row_group;
   const int nks = p.n_ksteps;
-  const u16* wtile = p.wp + (size_t)tile * nks * SLAB_SRC;
+  const u16* wtile = p.wp + (size_t)wtile_index * nks * SLAB_SRC;
 
   auto stage_slab = [&](int ks, int stage) {
     const u16* src = wtile + (size_t)ks * SLAB_SRC;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
         }
         bf16x8 hi, lo;
         pack8<O0_LO>(v, hi, lo);
-        u16* dst = p.o0 + ((rb * kb_out + (size_t)(tile * 4 + s)) * 2) * 512 + lane * 8;
+        u16* dst = o0 + ((rb * kb_out + (size_t)(tile * 4 + s)) * 2) * 512 + lane * 8;
         store_stream16(dst, as_u4(hi));
         if (O0_LO) store_stream16(dst + 512, as_u4(lo));
       }
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
     const int per = p.hidden / 256;
     const bool is_q = tile < per;
     const int tq = is_q ? tile : tile - per;
-    u16* out = is_q ? p.o0 : p.o1;
+    u16* out = is_q ? o0 : p.o1;
     // head_dim^-0.5 * log2(e): the fragment-packed attention kernel exponentiates with exp2
     const float qscale = is_q ? 0.125f * 1.44269504088896340736f : 1.0f;
     const int kb_out = p.hidden >> 5;
@@ -282,11 +283,41 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
                           acc[nf][1][0], acc[nf][1][1], acc[nf][1][2], acc[nf][1][3]};
       bf16x8 hi, lo;
       pack8<O0_LO>(v, hi, lo);
-      u16* dst = p.o0 + (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + (size_t)(nf & 3)) * 512 + lane * 8;
+      u16* dst = o0 + (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + (size_t)(nf & 3)) * 512 + lane * 8;
       store_stream16(dst, as_u4(hi));
       if (O0_LO) store_stream16(dst + 2048, as_u4(lo));
     }
   }
+}
+
+// block -> (row block, panel) of the XCD-aware map described above; false when the block is grid padding
+__device__ __forceinline__ bool panel_block_map(const PanelParams& p, int& row_block, int& tile) {
+  const int xcd_slot = blockIdx.x >> 3;
+  const int group_blocks = p.row_group * p.n_tiles;
+  const int in_group = xcd_slot % group_blocks;
+  row_block = ((xcd_slot / group_blocks) * p.row_group + in_group % p.row_group) * 8 + (blockIdx.x & 7);
+  tile = in_group / p.row_group;
+  return row_block * ROW_BM < p.r_pad;  // the grid is rounded up to whole groups
+}
+
+template <int EPI, int T, int OLO>
+__global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
+  __shared__ __attribute__((aligned(16))) u16 sW[2][panel_stage_elems(T)];
+  int row_block, tile;
+  if (!panel_block_map(p, row_block, tile)) return;
+  panel_block<EPI, T, OLO>(p, row_block, tile, tile, p.o0, sW);
+}
+
+// q, k and v^T of a layer in ONE launch: the three projections read the same normalised rows, so their panels sit side
+// by side in the XCD-local group (the rows are fetched once for all 3 H / 256 panels) and a launch is saved per layer.
+// The v^T panels use the un-swapped MFMA orientation: a block-uniform branch picks the instantiation.
+template <int T, int OLO_QK, int OLO_V>
+__global__ __launch_bounds__(256, 2) void panel_qkv_kernel(PanelParams p) {
+  __shared__ __attribute__((aligned(16))) u16 sW[2][panel_stage_elems(T)];
+  int row_block, tile;
+  if (!panel_block_map(p, row_block, tile)) return;
+  if (tile < p.n_qk_tiles) panel_block<PE_QK, T, OLO_QK>(p, row_block, tile, tile, p.o0, sW);
+  else panel_block<PE_V, T, OLO_V>(p, row_block, tile, tile - p.n_qk_tiles, p.o2, sW);
 }
 
 }  // namespace opk

@@ -28,6 +28,7 @@ KIND = [
     (r"kstream_gemm_kernel", "kstream_mlp_out"),
     (r"attn_fp_kernel<\d+, \d+, \w+, \d+, 1,", "attn_local"),
     (r"attn_fp_kernel", "attn_global"),
+    (r"panel_qkv_kernel", "gemm_qkv_rope"),
     (r"panel_gemm_kernel<0,", "panel_residual"),  # alternates attention-out / MLP-out projection: split below
     (r"panel_gemm_kernel<1,", "gemm_qk_rope"),
     (r"panel_gemm_kernel<2,", "gemm_v_t"),
