@@ -107,6 +107,110 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- hand-placed LDS fragment reads -------------------------------------------------------------------------
+// While a global_load_lds DMA is in flight hipcc (ROCm 7.2) cannot count lgkmcnt: every wait it inserts in front of
+// an MFMA is `s_waitcnt lgkmcnt(0)`, which also waits for the fragment reads issued just before it for the NEXT
+// k-step -- and left to itself it re-uses one register set and puts most ds_read_b128 directly in front of such a
+// wait (~40 % of every wave's cycles were spent there: SQ_WAIT_ANY in profiles/r02*).  So the weight-fragment reads
+// and their waits are inline asm (invisible to the compiler's scoreboard), ordered by data dependencies only:
+//   * volatile asm statements keep their program order among themselves (reads and waits);
+//   * a wait "rewrites" the fragment registers it guards, so the MFMAs that use them cannot move above it;
+//   * a read group "rewrites" one accumulator of the k-step before it, so it cannot sink below that step's MFMAs
+//     (nor can they sink below it): the reads of k-step ks + 1 are in flight during all MFMAs of k-step ks.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_frag(uint32_t lds_addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+// ordered behind the producers (and ahead of the consumers) of the accumulators it "rewrites".  IN_AGPR: the
+// one-wave-per-SIMD kernels (512-register budget) get their MFMA accumulators in AGPRs; a "v" constraint there makes
+// the compiler copy them to VGPRs and back around every read group.
+template <int OFF, bool IN_AGPR = false>
+__device__ __forceinline__ bf16x8 lds_read_frag_after(uint32_t lds_addr, f32x4& p0, f32x4& p1) {
+  bf16x8 v;
+  if constexpr (IN_AGPR) asm volatile("ds_read_b128 %0, %3 offset:%4" : "=v"(v), "+a"(p0), "+a"(p1) : "v"(lds_addr), "n"(OFF));
+  else asm volatile("ds_read_b128 %0, %3 offset:%4" : "=v"(v), "+v"(p0), "+v"(p1) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+template <int OFF, bool IN_AGPR = false>
+__device__ __forceinline__ bf16x8 lds_read_frag_after(uint32_t lds_addr, f32x4& p0, f32x4& p1, f32x4& p2, f32x4& p3) {
+  bf16x8 v;
+  if constexpr (IN_AGPR)
+    asm volatile("ds_read_b128 %0, %5 offset:%6" : "=v"(v), "+a"(p0), "+a"(p1), "+a"(p2), "+a"(p3) : "v"(lds_addr), "n"(OFF));
+  else
+    asm volatile("ds_read_b128 %0, %5 offset:%6" : "=v"(v), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait2(bf16x8& a, bf16x8& b) {  // at most N fragment reads still in flight
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// The same discipline for an arbitrary stream of NSTEPS steps that each consume TWO weight fragments (one weight
+// plane): the fragments of step s are at LDS byte offsets Off::at(s, 0 / 1) from `lds_addr` and are requested DEPTH
+// steps ahead into DEPTH + 1 rotating register sets; body(step, w0, w1) holds the step's MFMAs AND the slice of
+// vector work that is to run between them.  Here the order is fixed by scheduling fences instead of accumulator
+// pins (the one-wave-per-SIMD kernel keeps 128 accumulators in AGPRs; "+v" pins would drag them through VGPRs):
+// nothing crosses the fence after a step's body, the volatile read group and the next wait follow in program order.
+// frag_stream4: the same with FOUR fragments per step (both weight planes): body(step, w0, w1, w2, w3).
+template <int NSTEPS, int DEPTH, class Off, class Body>
+__device__ __forceinline__ void frag_stream4(uint32_t lds_addr, Body&& body) {
+  constexpr int SETS = DEPTH + 1;
+  bf16x8 w[SETS][4];
+  auto read_group = [&](auto step_tag) {
+    constexpr int s = decltype(step_tag)::value;
+    w[s % SETS][0] = lds_read_frag<Off::at(s, 0)>(lds_addr);
+    w[s % SETS][1] = lds_read_frag<Off::at(s, 1)>(lds_addr);
+    w[s % SETS][2] = lds_read_frag<Off::at(s, 2)>(lds_addr);
+    w[s % SETS][3] = lds_read_frag<Off::at(s, 3)>(lds_addr);
+  };
+  static_for<(DEPTH + 1 < NSTEPS ? DEPTH + 1 : NSTEPS)>([&](auto t) { read_group(t); });
+  static_for<NSTEPS>([&](auto t) {
+    constexpr int s = decltype(t)::value;
+    constexpr int set = s % SETS;
+    constexpr int ahead = (NSTEPS - 1 - s) < DEPTH ? (NSTEPS - 1 - s) : DEPTH;
+    lds_wait4<4 * ahead>(w[set][0], w[set][1], w[set][2], w[set][3]);
+    body(t, w[set][0], w[set][1], w[set][2], w[set][3]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (s + DEPTH + 1 < NSTEPS) read_group(std::integral_constant<int, s + DEPTH + 1>{});
+  });
+}
+
+template <int NSTEPS, int DEPTH, class Off, class Body>
+__device__ __forceinline__ void frag_stream2(uint32_t lds_addr, Body&& body) {
+  constexpr int SETS = DEPTH + 1;
+  bf16x8 w[SETS][2];
+  auto read_group = [&](auto step_tag) {
+    constexpr int s = decltype(step_tag)::value;
+    w[s % SETS][0] = lds_read_frag<Off::at(s, 0)>(lds_addr);
+    w[s % SETS][1] = lds_read_frag<Off::at(s, 1)>(lds_addr);
+  };
+  static_for<(DEPTH + 1 < NSTEPS ? DEPTH + 1 : NSTEPS)>([&](auto t) { read_group(t); });
+  static_for<NSTEPS>([&](auto t) {
+    constexpr int s = decltype(t)::value;
+    constexpr int set = s % SETS;
+    constexpr int ahead = (NSTEPS - 1 - s) < DEPTH ? (NSTEPS - 1 - s) : DEPTH;  // read groups that may stay in flight
+    lds_wait2<2 * ahead>(w[set][0], w[set][1]);
+    body(t, w[set][0], w[set][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (s + DEPTH + 1 < NSTEPS) read_group(std::integral_constant<int, s + DEPTH + 1>{});
+  });
+}
+
 // Stores of tensors that the launch writing them never reads back (q / k / v^T / o / h pieces, the residual stream's
 // write-back) are non-temporal (global_store ... nt).  As ordinary stores they displace the next block's operands from
 // the XCD's L2: in the whole-layer kernel the phase that starts a block (operand fetch + attention-output projection)

@@ -119,6 +119,9 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
   const int m0 = row_block * ROW_BM + wave * 32;
   const int nks = p.n_ksteps;
   const u16* wtile = p.wp + (size_t)wtile_index * nks * SLAB_SRC;
+  uint32_t lds_stage[2];  // LDS byte address of this lane's 16 bytes in fragment 0 of each stage
+  lds_stage[0] = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) u16*)&sW[0][0]) + (uint32_t)lane * 16u;
+  lds_stage[1] = lds_stage[0] + (uint32_t)(STAGE * 2);
 
   auto stage_slab = [&](int ks, int stage) {
     const u16* src = wtile + (size_t)ks * SLAB_SRC;
@@ -167,26 +170,36 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
     }
     load_a(kn);
     __builtin_amdgcn_sched_barrier(0);
+    // The slab's fragments as one hand-placed stream (frag_stream2 / 4 in opk_common.hip.h): step = fragments (nf, nf + 1)
+    // [+ their lo planes], read two steps ahead with counted waits.  Left to the compiler, every pair of reads was followed
+    // by s_waitcnt lgkmcnt(0) in front of its 8 MFMAs -- the LDS latency eight times per k-step.
+    auto mfmas = [&](auto step_tag, const bf16x8& wh0, const bf16x8& wh1, const bf16x8& wl0, const bf16x8& wl1) {
+      constexpr int nf = 2 * decltype(step_tag)::value;
 #pragma unroll
-    for (int nf = 0; nf < NF; nf += 2) {  // term-major over 2 fragments x 2 row blocks: no dependent MFMA pairs
-      bf16x8 wh[2], wl[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        wh[j] = lds_frag(&sW[cur][(nf + j) * 512 + lane * 8]);
-        wl[j] = W_LO ? lds_frag(&sW[cur][(NF + nf + j) * 512 + lane * 8]) : wh[j];
-      }
-#pragma unroll
-      for (int term = 0; term < 3; ++term) {
+      for (int term = 0; term < 3; ++term) {  // term-major over 2 fragments x 2 row blocks: no dependent MFMA pairs
         if ((term == 0 && !W_LO) || (term == 1 && !A_LO)) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int mf = 0; mf < 2; ++mf) {
-            const bf16x8 w = term == 0 ? wl[j] : wh[j];
+            const bf16x8 w = term == 0 ? (j ? wl1 : wl0) : (j ? wh1 : wh0);
             const bf16x8 a = term == 1 ? a_lo[mf] : a_hi[mf];
             acc[nf + j][mf] = SWAPPED ? mfma16(w, a, acc[nf + j][mf]) : mfma16(a, w, acc[nf + j][mf]);
           }
       }
+    };
+    if constexpr (W_LO) {
+      struct Off4 {
+        static constexpr int at(int st, int j) { return (((j >> 1) ? NF : 0) + 2 * st + (j & 1)) * 1024; }
+      };
+      frag_stream4<NF / 2, 2, Off4>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1, bf16x8& w2, bf16x8& w3) {
+        mfmas(step_tag, w0, w1, w2, w3);
+      });
+    } else {
+      struct Off2 {
+        static constexpr int at(int st, int j) { return (2 * st + j) * 1024; }
+      };
+      frag_stream2<NF / 2, 2, Off2>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) { mfmas(step_tag, w0, w1, w0, w1); });
     }
     __syncthreads();
   };
