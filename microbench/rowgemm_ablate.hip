@@ -182,6 +182,22 @@ int main() {
     }
     printf("  cycles per block (wave 0): attn-out %.0f | residual+LN %.0f | MLP %.0f (of which stage wait+barrier %.0f) | residual+LN %.0f | q/k/v %.0f (vmcnt wait %.0f, barrier %.0f) | total %.0f\n",
            seg[0] / n, seg[1] / n, seg[2] / n, wait / n, seg[3] / n, seg[4] / n, wait1 / n, wait2 / n, total / n);
+    // extra stamps of the whole-layer kernel's LayerNorm phases ([11] row fragment 0 of the first LayerNorm done,
+    // [12] same for the second, [13] second LayerNorm's arithmetic done, [14] its DMA / RoPE wait done)
+    double x[4] = {0, 0, 0, 0};
+    int nx = 0;
+    for (int b = 0; b < blocks; ++b) {
+      const unsigned long long* s = &t[(size_t)b * 16];
+      if (!s[11] || !s[12]) continue;
+      x[0] += (double)(s[11] - s[1]);
+      x[1] += (double)(s[12] - s[3]);
+      x[2] += (double)(s[13] - s[3]);
+      x[3] += (double)(s[14] - s[3]);
+      ++nx;
+    }
+    if (nx)
+      printf("  LayerNorm 1: row fragment 0 done at +%.0f | LayerNorm 2: fragment 0 +%.0f, arithmetic +%.0f, DMA/RoPE wait +%.0f (then the row stores)\n",
+             x[0] / nx, x[1] / nx, x[2] / nx, x[3] / nx);
   }
 #endif
   CHECK(hipGetLastError());

@@ -65,6 +65,44 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = SPLIT ? pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)) : 0u;
 }
 
+// Packed fp32 arithmetic (two lanes of a 64-bit register pair per instruction).  Measured with one wave per SIMD
+// (microbench/mfma32_probe.hip): in a vector-only phase a v_pk_fma_f32 issues at the rate of a v_fma_f32 (4.9 cycles,
+// twice the arithmetic); beside an MFMA stream it costs ~4x a scalar FMA.  So: explicit, and only in the LayerNorm
+// phases of the whole-layer kernel.  Written as asm so that neither the contraction nor the vectorizer settings of an
+// instantiation decide which instructions a row's arithmetic is made of.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// (hi, lo) split of a pair with the remainder computed by one packed subtraction
+template <bool SPLIT>
+__device__ __forceinline__ void split2_pk(f32x2 v, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(v.x, v.y);
+  if (SPLIT) {
+    const f32x2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const f32x2 r = pk_sub(v, hf);
+    lo = pack_bf16x2(r.x, r.y);
+  } else {
+    lo = 0u;
+  }
+}
+
 template <bool SPLIT>
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
   split2<SPLIT>(v[0], v[1], hi.x, lo.x);

@@ -11,6 +11,12 @@
 //   OPK_ABL_NO_BARRIER   no block barrier per chunk        OPK_ABL_NO_STORE   epilogue stores dropped
 //   OPK_ABL_NO_GELU      GELU replaced by the identity     OPK_ABL_NO_DMA     no weight DMA inside the loop
 //   OPK_ABL_NO_EPILOGUE  the deferred epilogue is skipped  OPK_ABL_NO_PHASE1  phase 1 (x += A1 W1^T) skipped
+#ifndef OPK_PREFETCH
+#define OPK_PREFETCH 1  // whole-layer kernel: operands touched ahead (bit 0: o, bit 1: x), 0 = off; see macro()
+#endif
+#ifndef OPK_PF_STRIDE
+#define OPK_PF_STRIDE 256
+#endif
 namespace opk {
 
 // ----------------------------------------------------------------------------------------------
@@ -219,6 +225,16 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   constexpr int STAGE_ALLOC = STAGE_GEMM > MLP_UNIT ? STAGE_GEMM : MLP_UNIT;
   static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE_ALLOC];
+  // Whole-layer kernel: its two LayerNorm weight vectors (this layer's mlp_norm, the next layer's attn_norm) live in
+  // LDS.  Read from global memory inside the LayerNorm they were 32 L2 round trips per block issued just in time
+  // (the compiler cannot hoist them over the asm fences), each behind an in-order vmcnt wait that also waited for the
+  // write acknowledgements of the residual rows stored just before: 16 k of a block's 252 k cycles per LayerNorm.
+#ifdef OPK_LN_V1
+  constexpr bool LN_V2 = false;
+#else
+  constexpr bool LN_V2 = PRO == RP_MLP;
+#endif
+  __shared__ __attribute__((aligned(16))) float sLn[LN_V2 ? 2 * KS * 32 : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -226,8 +242,16 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   const int l15 = lane & 15;
   const int g = lane >> 4;
   const int m0 = blockIdx.x * (WAVES * 16 * MF) + wave * (16 * MF);
+  // requested before anything else, written to LDS in front of the first block barrier (index clamped, no branch:
+  // a load under a branch is drained at the join)
+  const int ln_i = tid < KS * 32 ? tid : KS * 32 - 1;
+  float ln_fill0 = 0.f, ln_fill1 = 0.f;
+  if constexpr (LN_V2) {
+    ln_fill0 = p.ln_w_mlp[ln_i];
+    if (EPI != RE_NONE) ln_fill1 = p.ln_w[ln_i];
+  }
 #ifdef OPK_TIMING
-  unsigned long long opk_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, opk_wait = 0, opk_wait2 = 0, opk_wait1 = 0;
+  unsigned long long opk_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, opk_wait = 0, opk_wait2 = 0, opk_wait1 = 0, opk_x[4] = {0, 0, 0, 0};
 #define OPK_STAMP(i) opk_ts[i] = __builtin_readcyclecounter()
 #define OPK_DUMP()                                                                              \
   do {                                                                                          \
@@ -236,6 +260,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       p.dbg[(size_t)blockIdx.x * 16 + 8] = opk_wait;                                            \
       p.dbg[(size_t)blockIdx.x * 16 + 9] = opk_wait2;                                           \
       p.dbg[(size_t)blockIdx.x * 16 + 10] = opk_wait1;                                          \
+      for (int i_ = 0; i_ < 4; ++i_) p.dbg[(size_t)blockIdx.x * 16 + 11 + i_] = opk_x[i_];     \
     }                                                                                           \
   } while (0)
   OPK_STAMP(0);
@@ -371,6 +396,11 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       __builtin_amdgcn_sched_barrier(0);
       // vmcnt retires in order: everything but the NF1 residual-row loads (the A operand and this wave's share of the
       // first weight stage) has landed; then all waves meet
+      if constexpr (LN_V2) {
+        sLn[ln_i] = ln_fill0;
+        sLn[KS * 32 + ln_i] = ln_fill1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw barrier below publishes them
+      }
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF1) : "memory");
       __builtin_amdgcn_s_barrier();
       static_for<KS / 2>([&](auto j_tag) {
@@ -513,6 +543,93 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         }
       }
     };
+    // ---- the same transition in the whole-layer kernel (one wave per SIMD: a vector-only phase runs at one
+    // instruction per ~4.9 cycles, 8 for the conversion / accumulator-move class and for an instruction that needs
+    // the result of the one before it).  The row's 64 values per lane are read from the accumulators once, sums run in
+    // four independent chains of packed instructions, the LayerNorm weights come from LDS (sLn, above) and the
+    // write-back of the rows is left to store_rows(): a store in the middle puts every later counted vmcnt wait behind
+    // its write acknowledgement.
+    auto layer_ln = [&](auto load_tag, auto lo_tag, int which) {
+      constexpr bool LOAD = decltype(load_tag)::value, LO = decltype(lo_tag)::value;
+      float4 xq1[(LOAD && MF > 1) ? NF1 : 1];
+      if (LOAD && MF > 1) {  // row fragment 1 of x arrives while fragment 0 is normalised
+        const float* xrow1 = p.x_io + (size_t)(m0 + 16 + l15) * K + g * 8;
+#pragma unroll
+        for (int nf = 0; nf < NF1; ++nf) xq1[nf] = load_stream_f4(xrow1 + 32 * (nf >> 1) + 4 * (nf & 1));
+      }
+      // this lane's columns 32 ks + 8 g .. + 7 of the weight vector.  The offset is made opaque HERE: otherwise the
+      // compiler hoists the second LayerNorm's 64 weight values above the MLP loop and spills them across it.
+      int ln_off = which * K + g * 8;
+      asm volatile("" : "+v"(ln_off));
+      const float* lsrc = &sLn[ln_off];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        f32x2 v[2 * NF1];
+#pragma unroll
+        for (int nf = 0; nf < NF1; ++nf) {
+          f32x4 a = acc1[nf][mf];
+          if (LOAD) {
+            // (scalar adds: with packed ones feeding the accumulators the register allocator permutes all 128 of them
+            // through scratch around the MLP loop)
+            const float4 x4 = mf == 0 ? xq0[nf] : xq1[(LOAD && MF > 1) ? nf : 0];
+            a = f32x4{a[0] + x4.x, a[1] + x4.y, a[2] + x4.z, a[3] + x4.w};
+            acc1[nf][mf] = a;
+          }
+          v[2 * nf] = f32x2{a[0], a[1]};
+          v[2 * nf + 1] = f32x2{a[2], a[3]};
+        }
+        f32x2 s4[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int i = 4; i < 2 * NF1; ++i) s4[i & 3] = pk_add(s4[i & 3], v[i]);
+        const f32x2 st = pk_add(pk_add(s4[0], s4[1]), pk_add(s4[2], s4[3]));
+        float sum = st.x + st.y;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / (float)K);
+        const f32x2 m2 = f32x2{mean, mean};
+        f32x2 q4[4];
+#pragma unroll
+        for (int i = 0; i < 2 * NF1; ++i) {
+          v[i] = pk_sub(v[i], m2);
+          q4[i & 3] = i < 4 ? pk_mul(v[i], v[i]) : pk_fma(v[i], v[i], q4[i & 3]);
+        }
+        const f32x2 qt = pk_add(pk_add(q4[0], q4[1]), pk_add(q4[2], q4[3]));
+        float q = qt.x + qt.y;
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / (float)K) + p.eps);
+        const f32x2 r2 = f32x2{rstd, rstd};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 w0 = *reinterpret_cast<const float4*>(lsrc + ks * 32);
+          const float4 w1 = *reinterpret_cast<const float4*>(lsrc + ks * 32 + 4);
+          const f32x2 lw[4] = {f32x2{w0.x, w0.y}, f32x2{w0.z, w0.w}, f32x2{w1.x, w1.y}, f32x2{w1.z, w1.w}};
+          uint32_t h[4], l[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) split2_pk<LO>(pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]), h[j], l[j]);
+          a_hi[mf][ks] = as_frag(make_uint4(h[0], h[1], h[2], h[3]));
+          a_lo[mf][ks] = as_frag(make_uint4(l[0], l[1], l[2], l[3]));
+          if constexpr (LO && LOAD && MF == 2) asm volatile("" : "+a"(a_lo[mf][ks]));  // parked where the MLP wants it (see below)
+        }
+#ifdef OPK_TIMING
+        if (mf == 0) opk_x[LOAD ? 0 : 1] = __builtin_readcyclecounter();
+#endif
+      }
+    };
+    // The residual rows as they stand in the accumulators, in one burst behind the LayerNorm's arithmetic.  Measured
+    // (stamps): the arithmetic takes 5.5 k cycles, the 32 stores 5.7 k to ISSUE -- every CU of the chip writes its
+    // 128 KB at the same moment -- and spread between the arithmetic instructions they cost more (LayerNorm phase
+    // 11.2 k as a burst, 15 - 17.7 k interleaved).
+    auto store_rows = [&]() {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        float* xrow = p.x_io + (size_t)(m0 + mf * 16 + l15) * K + g * 8;
+#pragma unroll
+        for (int nf = 0; nf < NF1; ++nf)
+          store_stream16(xrow + 32 * (nf >> 1) + 4 * (nf & 1),
+                         make_float4(acc1[nf][mf][0], acc1[nf][mf][1], acc1[nf][mf][2], acc1[nf][mf][3]));
+      }
+    };
     const std::true_type yes_{};
     const std::false_type no_{};
     if constexpr (PRO == RP_KSTREAM) {
@@ -553,7 +670,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       };
       auto stage_unit = [&](int t, int stage) { static_for<UNIT_DMA>([&](auto u) { stage_piece(u, t, stage); }); };
       stage_unit(0, 0);  // flies while the LayerNorm below runs
-      residual_ln(yes_, no_, std::integral_constant<bool, A_LOW>{}, p.ln_w_mlp);
+      if constexpr (LN_V2) layer_ln(yes_, std::integral_constant<bool, A_LOW>{}, 0);
+      else residual_ln(yes_, no_, std::integral_constant<bool, A_LOW>{}, p.ln_w_mlp);
       // The lo fragments of the normalised rows live in AGPRs from here on (an MFMA takes its A / B operands from
       // either file): the 256 architectural VGPRs were short by about that much, and the compiler's own answer was to
       // park fragments in AGPRs and move them back in front of each use -- ~8 issue cycles per v_accvgpr move.
@@ -697,6 +815,28 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         // na: chunk 2t, written by its first k-step (C operand = 0).  Chunk 2t+1 accumulates straight into acc_b: the
         // GeGLU of chunk 2t-1 (the last reader of acc_b's old contents) is over after the first KS steps.
         f32x4 na[2][MF];
+#if OPK_PREFETCH
+        // Every CU of the chip starts a tile at the same time and the operand fetch that opens it is a 64 MB burst
+        // (29 k of a tile's 245 k cycles, 8 k of them MFMAs) while HBM idles during the MLP.  So each macro-iteration
+        // touches one dword per 64 B of a slice of the attention output `o` of the tile OPK_PF_STRIDE blocks ahead
+        // (the block the dispatcher hands to this XCD a round later, as observed; used for speed only) -- one
+        // instruction per wave, the register is never read.  Measured same-box: that phase 29.0 k -> 23.8 k cycles,
+        // kernel -1.3 %; also touching the residual rows (bit 1) or touching only late gives nothing.
+        unsigned pf_dummy;
+        {
+          const int blk = (int)blockIdx.x + OPK_PF_STRIDE < (int)gridDim.x ? (int)blockIdx.x + OPK_PF_STRIDE : (int)blockIdx.x;
+          const size_t tile = (size_t)blk * (WAVES * 16 * MF);
+          const char* o_base = reinterpret_cast<const char*>(p.a1_fp + (tile >> 4) * (size_t)p.k1_steps * 2 * 512);
+          const char* x_base = reinterpret_cast<const char*>(p.x_io + tile * K);
+          constexpr int PER_WAVE = 16 * MF * K * 4;  // bytes of either operand per wave
+          constexpr int NI = PER_WAVE / 4096;        // instructions to touch it
+          const int t_eff = t;
+          const int j = OPK_PREFETCH == 3 ? (t_eff % (2 * NI)) : (t_eff % NI);
+          const bool use_x = OPK_PREFETCH == 2 || (OPK_PREFETCH == 3 && j >= NI);
+          const char* src = (use_x ? x_base : o_base) + (size_t)wave * PER_WAVE + (size_t)(j % NI) * 4096 + lane * 64;
+          asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(src));
+        }
+#endif
         frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int s = decltype(step_tag)::value;
 #ifndef OPK_ABL_NO_DMA
@@ -718,6 +858,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         const unsigned long long opk_w0 = __builtin_readcyclecounter();
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (no other VMEM in this loop)
+#if OPK_PREFETCH
+        asm volatile("" ::"v"(pf_dummy));
+#endif
 #ifndef OPK_ABL_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
@@ -749,7 +892,21 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       } else {
         stage_chunk(0, 0);
         if (ROPE_PRELOAD) rope_preload();
-        residual_ln(no_, yes_, std::integral_constant<bool, A_LO>{}, p.ln_w);
+        if constexpr (LN_V2) {
+          layer_ln(no_, std::integral_constant<bool, A_LO>{}, 1);
+#ifdef OPK_TIMING
+          opk_x[2] = __builtin_readcyclecounter();
+#endif
+          // chunk 0 and the RoPE rows have landed (they had the whole LayerNorm); only then the 2 x NF1 row stores,
+          // which nothing waits for before the end of the first chunk
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef OPK_TIMING
+          opk_x[3] = __builtin_readcyclecounter();
+#endif
+          store_rows();
+        } else {
+          residual_ln(no_, yes_, std::integral_constant<bool, A_LO>{}, p.ln_w);
+        }
         OPK_STAMP(4);
       }
     }
@@ -788,7 +945,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       }
   }
   if (EPI == RE_QKV && !ROPE_PRELOAD) rope_rows();
-  __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
+  if constexpr (LN_V2) __builtin_amdgcn_s_barrier();  // (this wave's share of chunk 0 was waited for above)
+  else __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
 
   // ---- stream the weight chunks ---------------------------------------------------------------
   uint2 hold_hi[MF], hold_lo[MF];  // RE_GEGLU: first half of a chunk pair
