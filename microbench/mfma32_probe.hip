@@ -140,13 +140,113 @@ static void probe(const char* label, float* sink) {
   CHECK(hipFree(out));
 }
 
+
+// Power probe: the MFMA stream alone, every SIMD of the chip busy (one or two waves per SIMD), operands either a few
+// constants (as above) or pseudo-random bf16 values, 16 distinct (a, b) register pairs in rotation.  Reports the shader
+// clock the chip holds (s_memtime / s_memrealtime) and the executed TFLOP/s: with random operands the matrix pipes
+// toggle and the power limit, not the issue rate, sets the throughput.
+template <int SHAPE, int WPS>
+__global__ __launch_bounds__(256 * WPS) void power_kernel(int n_iters, int random, unsigned long long* __restrict__ out, float* __restrict__ sink) {
+  __shared__ u16 pad[(WPS == 1 ? 48 : 16) * 1024];
+  const int lane = threadIdx.x & 63;
+  pad[threadIdx.x] = (u16)lane;
+  bf16x8 av[8], bv[8];
+  unsigned s = (blockIdx.x * 1024u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s = s * 1664525u + 1013904223u;
+      const float fa = random ? ((int)(s >> 9) / 8388608.0f - 0.5f) * 2.0f : 0.001f * (float)(lane + i + j);
+      s = s * 1664525u + 1013904223u;
+      const float fb = random ? ((int)(s >> 9) / 8388608.0f - 0.5f) * 0.125f : 0.002f * (float)((lane ^ i) + j);
+      av[j][i] = (__bf16)fa;
+      bv[j][i] = (__bf16)fb;
+    }
+    asm volatile("" : "+v"(av[j]), "+v"(bv[j]));
+  }
+  f32x4 acc16[8];
+  f32x16 acc32[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
+  __syncthreads();
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  const unsigned long long t0 = wall_clock64();
+  for (int it = 0; it < n_iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (SHAPE == 0) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[(2 * u) & 7]) : "v"(av[u & 7]), "v"(bv[(u >> 1) & 7]));
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[(2 * u + 1) & 7]) : "v"(av[(u + 3) & 7]), "v"(bv[(u >> 1) & 7]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc32[u & 3]) : "v"(av[u & 7]), "v"(bv[(u >> 1) & 7]));
+      }
+    }
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) total += acc16[i][0] + acc16[i][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) total += acc32[i][0] + acc32[i][15];
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  const unsigned long long t1 = wall_clock64();
+  if (total == 123.456f) sink[threadIdx.x] = total + (float)pad[(threadIdx.x * 7) & 1023];
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = t1 - t0;
+  }
+}
+
+template <int SHAPE, int WPS>
+static void power_probe(const char* label, int random, float* sink) {
+  const int blocks = 256 * 8, n_iters = 8192;
+  unsigned long long* out;
+  CHECK(hipMalloc(&out, (size_t)blocks * 2 * sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((power_kernel<SHAPE, WPS>), dim3(blocks), dim3(256 * WPS), 0, 0, n_iters, random, out, sink);
+  CHECK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL((power_kernel<SHAPE, WPS>), dim3(blocks), dim3(256 * WPS), 0, 0, n_iters, random, out, sink);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> host((size_t)blocks * 2);
+  CHECK(hipMemcpy(host.data(), out, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double cyc = 0.0, real = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    cyc += (double)host[2 * b];
+    real += (double)host[2 * b + 1];
+  }
+  const double flops = (double)blocks * 4 * WPS * (double)n_iters * 16 * 65536.0;
+  printf("%s  %d wave(s)/SIMD  %-18s %6.3f GHz shader clock  %7.1f TFLOP/s executed  (%.1f ms)\n",
+         SHAPE == 0 ? "16x16x32" : "32x32x16", WPS, label, cyc / real * 0.1, flops / ms * 1e-9, ms);
+  CHECK(hipFree(out));
+}
+
 #define BOTH(label, ...)               \
   probe<0, __VA_ARGS__>(label, sink);  \
   probe<1, __VA_ARGS__>(label, sink)
 
-int main() {
+int main(int argc, char** argv) {
   float* sink;
   CHECK(hipMalloc(&sink, 4096));
+  if (argc > 1) {  // "power": the data-dependent power limit of the matrix pipes
+    printf("MFMA stream alone on every SIMD, ~0.2 s per case:\n");
+    for (int random = 0; random < 2; ++random) {
+      const char* label = random ? "random operands" : "constant operands";
+      power_probe<0, 1>(label, random, sink);
+      power_probe<1, 1>(label, random, sink);
+      power_probe<0, 2>(label, random, sink);
+      power_probe<1, 2>(label, random, sink);
+    }
+    return 0;
+  }
   printf("one wave per SIMD, AGPR accumulators; unit = 65536 flop of MFMA work (32 pipe cycles)\n");
   BOTH("nothing else", 0);
   BOTH("2 v_fma", 2);

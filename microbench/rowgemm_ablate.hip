@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../open_provence_amd/csrc/opk_rowgemm.hip.h"
+#include "../open_provence_amd/csrc/opk_layer32.hip.h"
 
 #ifndef ABL_T
 #define ABL_T 1
@@ -46,14 +47,18 @@ int main() {
   const int R = 131072, H = 256, I = 1024, KS = 8;
   std::vector<u16> o((size_t)R * H * 2), wo((size_t)H * H * 2), wi((size_t)2 * I * H * 2);
   std::vector<float> x((size_t)R * H), lnw(H, 1.0f);
-  fill_bf16(o, 1, 1.0f);
-  fill_bf16(wo, 2, 0.06f);
-  fill_bf16(wi, 3, 0.06f);
+  // ABL_ZERO=1: all-zero operands (nothing toggles in the datapaths): how much of the run time is the power limit
+  const bool zero_data = getenv("ABL_ZERO") != nullptr;
+  if (!zero_data) {
+    fill_bf16(o, 1, 1.0f);
+    fill_bf16(wo, 2, 0.06f);
+    fill_bf16(wi, 3, 0.06f);
+  }
   {
     unsigned s = 77;
     for (auto& v : x) {
       s = s * 1664525u + 1013904223u;
-      v = ((int)(s >> 9) / 8388608.0f - 0.5f) * 4.0f;
+      v = zero_data ? 0.f : ((int)(s >> 9) / 8388608.0f - 0.5f) * 4.0f;
     }
   }
   u16 *d_o, *d_wo, *d_wi, *d_h;
@@ -90,8 +95,10 @@ int main() {
 #ifdef ABL_LAYER
   // whole-layer kernel: attention output projection + MLP (+ next q/k/v projection when ABL_LAYER == 2)
   std::vector<u16> wo2((size_t)H * I * 2), wqkv((size_t)3 * H * H * 2);
-  fill_bf16(wo2, 4, 0.03f);
-  fill_bf16(wqkv, 5, 0.06f);
+  if (!zero_data) {
+    fill_bf16(wo2, 4, 0.03f);
+    fill_bf16(wqkv, 5, 0.06f);
+  }
   u16 *d_wo2, *d_wqkv, *d_q, *d_k, *d_v;
   float *d_cos, *d_sin;
   int32_t* d_pos;
@@ -131,12 +138,40 @@ int main() {
   p.rope_cos = d_cos;
   p.rope_sin = d_sin;
   p.max_pos = 8192;
+#if ABL_LAYER == 32
+  // the same launch on the 32x32x16 shape (opk_layer32.hip.h); buffers are reused (its packs are hi planes only)
+  Layer32Params lp;
+  memset(&lp, 0, sizeof(lp));
+#ifdef OPK_TIMING
+  lp.dbg = p.dbg;
+#endif
+  lp.o_fp = d_o;
+  lp.x_io = d_x;
+  lp.ln_mlp = d_ln;
+  lp.ln_next = d_ln;
+  lp.eps = 1e-5f;
+  lp.wo_p = d_wo;
+  lp.wi_p = d_wi;
+  lp.wo2_p = d_wo2;
+  lp.wqkv_p = d_wqkv;
+  lp.n_pairs = I / 32;
+  lp.q_fp = d_q;
+  lp.k_fp = d_k;
+  lp.vt_fp = d_v;
+  lp.r_pad = R;
+  lp.row_pos = d_pos;
+  lp.rope_cos = d_cos;
+  lp.rope_sin = d_sin;
+  lp.max_pos = 8192;
+  auto launch = [&]() { hipLaunchKernelGGL((layer32_kernel<8, true, ABL_T != 0, 7>), dim3(R / 128), dim3(256), 0, 0, lp); };
+#else
   auto launch = [&]() {
     if (ABL_LAYER == 2)
       hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, ABL_T, ABL_T, 7, 4, 2, ABL_T, ABL_T>), dim3(R / 128), dim3(256), 0, 0, p);
     else
       hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, ABL_T, 0, 0, 4, 2, ABL_T, ABL_T>), dim3(R / 128), dim3(256), 0, 0, p);
   };
+#endif
 #else
   auto launch = [&]() {
     hipLaunchKernelGGL((rowgemm_kernel<KS, RE_GEGLU, RP_KSTREAM, ABL_T, ABL_T, 1, 4, 2>), dim3(R / 128), dim3(256), 0, 0, p);
@@ -168,7 +203,7 @@ int main() {
     const int blocks = R / 128;
     std::vector<unsigned long long> t((size_t)blocks * 16);
     CHECK(hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost));
-    double seg[5] = {0, 0, 0, 0, 0}, wait = 0, wait2 = 0, wait1 = 0, total = 0;
+    double seg[5] = {0, 0, 0, 0, 0}, wait = 0, wait2 = 0, wait1 = 0, total = 0, real = 0;
     int n = 0;
     for (int b = 0; b < blocks; ++b) {
       const unsigned long long* s = &t[(size_t)b * 16];
@@ -178,8 +213,10 @@ int main() {
       wait2 += (double)s[9];
       wait1 += (double)s[10];
       total += (double)(s[last] - s[0]);
+      real += (double)s[15];
       ++n;
     }
+    printf("  shader clock while the blocks ran: %.3f GHz (cycle stamps / 100 MHz counter)\n", total / real * 0.1);
     printf("  cycles per block (wave 0): attn-out %.0f | residual+LN %.0f | MLP %.0f (of which stage wait+barrier %.0f) | residual+LN %.0f | q/k/v %.0f (vmcnt wait %.0f, barrier %.0f) | total %.0f\n",
            seg[0] / n, seg[1] / n, seg[2] / n, wait / n, seg[3] / n, seg[4] / n, wait1 / n, wait2 / n, total / n);
     // extra stamps of the whole-layer kernel's LayerNorm phases ([11] row fragment 0 of the first LayerNorm done,

@@ -21,7 +21,8 @@ BUILD_DIR = PKG_DIR.parent / "build" / "hip"
 OUTPUT = PKG_DIR / "libopenprovence_hip.so"
 
 _COMMON = [CSRC / "opk_common.hip.h"]
-_INTERNAL = _COMMON + [CSRC / "op_internal.h", CSRC / "opk_attn.hip.h", CSRC / "opk_panel.hip.h", CSRC / "opk_rowgemm.hip.h"]
+_INTERNAL = _COMMON + [CSRC / "op_internal.h", CSRC / "opk_attn.hip.h", CSRC / "opk_panel.hip.h", CSRC / "opk_rowgemm.hip.h",
+                       CSRC / "opk_layer32.hip.h"]
 
 # (object name, source, extra defines, headers it depends on)
 UNITS = [
@@ -30,6 +31,7 @@ UNITS = [
     ("op_launch_row1", CSRC / "op_launch_row.hip", ["-DOPL_ROW_PART=1"], _INTERNAL),
     ("op_launch_row2", CSRC / "op_launch_row.hip", ["-DOPL_ROW_PART=2"], _INTERNAL),
     ("op_launch_row3", CSRC / "op_launch_row.hip", ["-DOPL_ROW_PART=3"], _INTERNAL),
+    ("op_launch_layer32", CSRC / "op_launch_layer32.hip", [], _INTERNAL),
     ("op_launch_attn", CSRC / "op_launch_attn.hip", [], _INTERNAL),
     ("op_launch_panel", CSRC / "op_launch_panel.hip", [], _INTERNAL),
 ]

@@ -69,6 +69,8 @@ struct LayerWeights {
   u16 *wqkv_pk = nullptr, *wi_pk = nullptr;
   u16* wo2_pk = nullptr;  // k-streamed layouts (output features permuted): MLP output projection ...
   u16* wo_ks = nullptr;   // ... and attention output projection (fused kernels)
+  // hi planes in the fragment order of the 32x32x16 whole-layer kernel (opk_layer32.hip.h), hidden = 256 only
+  u16 *wo_p32 = nullptr, *wi_p32 = nullptr, *wo2_p32 = nullptr, *wqkv_p32 = nullptr;
 };
 
 struct ProfileEvent {
@@ -475,6 +477,36 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       if (layer_fused) {
         // x += o Wo^T ; x += GeGLU(LN(x) Wi^T) Wo^T ; q, k, v^T of the NEXT layer -- one kernel, h stays on chip
         const bool with_qkv = li + 1 < h->N;
+        if ((h->cfg.flags & OP_FLAG_LAYER_M32) && lw.wo_p32 && opl::has_layer32(h->pi) && I % 64 == 0) {
+          // hidden = 256, on request: the same launch on the 32x32x16 MFMA shape (opk_layer32.hip.h) -- 6 % fewer
+          // cycles, but that shape draws more power per flop and the chip clocks lower under it
+          Layer32Params lp;
+          memset(&lp, 0, sizeof(lp));
+          const LayerWeights& nx = h->layers[with_qkv ? li + 1 : li];
+          lp.o_fp = ws.o_hi;
+          lp.x_io = ws.x;
+          lp.ln_mlp = lw.mlp_norm;
+          lp.ln_next = with_qkv ? nx.attn_norm : nullptr;
+          lp.eps = h->cfg.norm_eps;
+          lp.wo_p = lw.wo_p32;
+          lp.wi_p = lw.wi_p32;
+          lp.wo2_p = lw.wo2_p32;
+          lp.wqkv_p = nx.wqkv_p32;
+          lp.n_pairs = I / 32;
+          lp.q_fp = ws.q_hi;
+          lp.k_fp = ws.k_hi;
+          lp.vt_fp = ws.vt_hi;
+          lp.r_pad = r_pad;
+          lp.row_pos = ws.row_pos;
+          const int gl = h->cfg.layer_is_global[with_qkv ? li + 1 : li] ? 1 : 0;
+          lp.rope_cos = h->rope_cos[gl];
+          lp.rope_sin = h->rope_sin[gl];
+          lp.max_pos = h->max_pos;
+          OP_TRY(L.begin(PK_FUSED_LAYER));
+          if (!opl::launch_layer32(st, lp, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM))) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+          OP_TRY(L.end());
+          continue;
+        }
         RowGemmParams rl = qkv_params(with_qkv ? li + 1 : li);
         rl.a1_fp = ws.o_hi;
         rl.w1p = lw.wo_ks;
@@ -857,6 +889,12 @@ int op_create(const op_config* cfg, op_handle** out) {
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
+      if (h->row_path && H == 256) {
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo_p32, HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wi_p32, (size_t)2 * I * H));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo2_p32, (size_t)H * I));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_p32, 3 * HH));
+      }
     }
     h->missing.push_back(pre + "mlp_norm.weight");
     h->missing.push_back(pre + "attn.Wqkv.weight");
@@ -901,6 +939,8 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   enum Kind { F32_COPY, F32_TRANSPOSE, PLANES, PLANES_GEGLU };
   u16* dst_pk = nullptr;
   u16* dst_ks = nullptr;  // additional k-streamed packing (attention Wo)
+  u16* dst_p32 = nullptr; // additional packing for the 32x32x16 whole-layer kernel
+  int p32_mode = 0, p32_kmajor = 0;
   int pk_mode = -1;
   int family = -1;        // op_gemm_family of a GEMM weight
   Kind kind = F32_COPY;
@@ -944,15 +984,19 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     } else if (t == "attn.Wqkv.weight") {
       kind = PLANES; dst_hi = lw.wqkv_hi; dst_lo = lw.wqkv_lo; expect(3 * H, H);
       dst_pk = lw.wqkv_pk; pk_mode = RE_QKV; family = OP_FAM_WQKV;
+      dst_p32 = lw.wqkv_p32; p32_mode = L32_QKV; p32_kmajor = 0;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
       dst_pk = nullptr; pk_mode = 101; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
+      dst_p32 = lw.wo_p32; p32_mode = L32_RESID; p32_kmajor = 1;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
       dst_pk = lw.wi_pk; pk_mode = RE_GEGLU; family = OP_FAM_WI;
+      dst_p32 = lw.wi_p32; p32_mode = L32_GEGLU; p32_kmajor = 0;
     } else if (t == "mlp.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo2_hi; dst_lo = lw.wo2_lo; expect(H, I);
       dst_pk = lw.wo2_pk; pk_mode = 100; family = OP_FAM_MLP_OUT;  // k-streamed
+      dst_p32 = lw.wo2_p32; p32_mode = L32_RESID; p32_kmajor = 1;
     } else {
       return fail(h, OP_ERR_INVALID, "op_load_weight: unknown tensor name '%s'", name_c);
     }
@@ -1030,6 +1074,9 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
                          zero_lo, any_lo);
     if (dst_ks)
       hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_ks, zero_lo, any_lo);
+    if (dst_p32)  // the 32x32x16 whole-layer kernel's order (hi plane; that kernel runs only when the lo planes are zero)
+      hipLaunchKernelGGL(pack_layer32_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, p32_mode, p32_kmajor, H, I,
+                         dst_p32);
   }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(0);

@@ -8,6 +8,7 @@
 
 #include "opk_attn.hip.h"
 #include "opk_common.hip.h"
+#include "opk_layer32.hip.h"
 #include "opk_panel.hip.h"
 #include "opk_rowgemm.hip.h"
 
@@ -51,6 +52,9 @@ bool launch_kstream(hipStream_t st, const opk::KStreamParams& p, int nf, int pi,
 bool has_row_layer_fused(int pi);
 bool launch_row_layer_fused(hipStream_t st, const opk::RowGemmParams& p, int ks, int pi, bool with_qkv, unsigned grid,
                             bool waves8);
+// the same launch on the 32x32x16 shape (hidden = 256; kernel sets 1 and 2)
+bool has_layer32(int pi);
+bool launch_layer32(hipStream_t st, const opk::Layer32Params& p, int pi, bool with_qkv, unsigned grid);
 // waves x kt: (8, 2) and (4, 2) full attention / long and short sequences, (4, 1) sliding window.
 // zero_p_lo (pi == 0 only): the policy has no lo(p) x hi(v) term.
 bool launch_attn(hipStream_t st, const opk::AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid);

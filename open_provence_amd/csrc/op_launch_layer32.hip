@@ -1,0 +1,42 @@
+// op_launch_layer32.hip -- instantiations of the 32x32x16 whole-layer kernel (hidden = 256) for the kernel sets whose
+// weights are single-plane: "bf16 weights" (activation operands hi + lo) and "bf16" (single pass).
+#include "op_internal.h"
+
+namespace opl {
+using namespace opk;
+
+namespace {
+template <int PI>
+bool launch_pi(hipStream_t st, const Layer32Params& p, bool with_qkv, unsigned grid) {
+  constexpr Policy P = kPolicies[PI];
+  constexpr bool single_plane = ((P.wqkv | P.attn_out | P.wi | P.mlp_out) & 2) == 0;
+  constexpr bool uniform = (P.wqkv & 1) == (P.attn_out & 1) && (P.wi & 1) == (P.mlp_out & 1) && (P.wqkv & 1) == (P.wi & 1);
+  if constexpr (!single_plane || !uniform) {
+    return false;
+  } else {
+    constexpr bool ALO = (P.wi & 1) != 0;
+    if (with_qkv) hipLaunchKernelGGL((layer32_kernel<8, true, ALO, qkv_olo(P)>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layer32_kernel<8, false, ALO, 0>), dim3(grid), dim3(256), 0, st, p);
+    return true;
+  }
+}
+}  // namespace
+
+bool has_layer32(int pi) {
+  if (pi < 0 || pi >= N_POLICIES) return false;
+  const Policy& P = kPolicies[pi];
+  return ((P.wqkv | P.attn_out | P.wi | P.mlp_out) & 2) == 0 && (P.wqkv & 1) == (P.attn_out & 1) &&
+         (P.wi & 1) == (P.mlp_out & 1) && (P.wqkv & 1) == (P.wi & 1);
+}
+
+bool launch_layer32(hipStream_t st, const Layer32Params& p, int pi, bool with_qkv, unsigned grid) {
+  static_assert(N_POLICIES == 3, "extend the switch");
+  switch (pi) {
+    case 0: return launch_pi<0>(st, p, with_qkv, grid);
+    case 1: return launch_pi<1>(st, p, with_qkv, grid);
+    case 2: return launch_pi<2>(st, p, with_qkv, grid);
+    default: return false;
+  }
+}
+
+}  // namespace opl

@@ -189,6 +189,19 @@ __device__ __forceinline__ void lds_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
+// The same discipline for 16-byte fp32 reads (LayerNorm weights kept in LDS): issued by hand a step ahead and waited
+// for by count -- a compiler-placed read behind an in-flight DMA is always followed by s_waitcnt lgkmcnt(0).
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_f4(uint32_t lds_addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_f4(f32x4& a, f32x4& b) {  // at most N reads still in flight
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);

@@ -261,8 +261,10 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       p.dbg[(size_t)blockIdx.x * 16 + 9] = opk_wait2;                                           \
       p.dbg[(size_t)blockIdx.x * 16 + 10] = opk_wait1;                                          \
       for (int i_ = 0; i_ < 4; ++i_) p.dbg[(size_t)blockIdx.x * 16 + 11 + i_] = opk_x[i_];     \
+      p.dbg[(size_t)blockIdx.x * 16 + 15] = wall_clock64() - opk_rt0;                           \
     }                                                                                           \
   } while (0)
+  const unsigned long long opk_rt0 = wall_clock64();  // constant 100 MHz: shader clock = cycle stamps / this
   OPK_STAMP(0);
 #else
 #define OPK_STAMP(i)
@@ -559,9 +561,15 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       }
       // this lane's columns 32 ks + 8 g .. + 7 of the weight vector.  The offset is made opaque HERE: otherwise the
       // compiler hoists the second LayerNorm's 64 weight values above the MLP loop and spills them across it.
-      int ln_off = which * K + g * 8;
-      asm volatile("" : "+v"(ln_off));
-      const float* lsrc = &sLn[ln_off];
+      // (read a step ahead by hand, lds_read_f4: a compiler-placed LDS read behind the in-flight weight DMA is always
+      // followed by lgkmcnt(0))
+      const uint32_t ln_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)&sLn[0]) + (uint32_t)(which * K + g * 8) * 4u;
+      f32x4 wq[2][2];
+      auto ln_read = [&](auto ks_tag) {
+        constexpr int ks = decltype(ks_tag)::value;
+        wq[ks & 1][0] = lds_read_f4<ks * 128>(ln_addr);
+        wq[ks & 1][1] = lds_read_f4<ks * 128 + 16>(ln_addr);
+      };
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         f32x2 v[2 * NF1];
@@ -599,18 +607,22 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         q += __shfl_xor(q, 32, 64);
         const float rstd = 1.0f / sqrtf(q * (1.0f / (float)K) + p.eps);
         const f32x2 r2 = f32x2{rstd, rstd};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const float4 w0 = *reinterpret_cast<const float4*>(lsrc + ks * 32);
-          const float4 w1 = *reinterpret_cast<const float4*>(lsrc + ks * 32 + 4);
-          const f32x2 lw[4] = {f32x2{w0.x, w0.y}, f32x2{w0.z, w0.w}, f32x2{w1.x, w1.y}, f32x2{w1.z, w1.w}};
+        ln_read(std::integral_constant<int, 0>{});
+        if constexpr (KS > 1) ln_read(std::integral_constant<int, 1>{});
+        static_for<KS>([&](auto ks_tag) {
+          constexpr int ks = decltype(ks_tag)::value;
+          f32x4& w0 = wq[ks & 1][0];
+          f32x4& w1 = wq[ks & 1][1];
+          lds_wait_f4<(ks + 1 < KS ? 2 : 0)>(w0, w1);
+          const f32x2 lw[4] = {f32x2{w0[0], w0[1]}, f32x2{w0[2], w0[3]}, f32x2{w1[0], w1[1]}, f32x2{w1[2], w1[3]}};
           uint32_t h[4], l[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) split2_pk<LO>(pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]), h[j], l[j]);
           a_hi[mf][ks] = as_frag(make_uint4(h[0], h[1], h[2], h[3]));
           a_lo[mf][ks] = as_frag(make_uint4(l[0], l[1], l[2], l[3]));
           if constexpr (LO && LOAD && MF == 2) asm volatile("" : "+a"(a_lo[mf][ks]));  // parked where the MLP wants it (see below)
-        }
+          if constexpr (ks + 2 < KS) ln_read(std::integral_constant<int, ks + 2>{});
+        });
 #ifdef OPK_TIMING
         if (mf == 0) opk_x[LOAD ? 0 : 1] = __builtin_readcyclecounter();
 #endif
@@ -1177,7 +1189,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       // phase while its partner waits for the same port; the lever that pays is fewer epilogue instructions.
       constexpr int NT = term_count(T2);
       constexpr int N_MFMA = KS * 2 * MF * NT;
-      constexpr int VALU_PER_MFMA = NT == 3 ? 2 : (NT == 2 ? 3 : 5);
+      constexpr int VALU_PER_MFMA = NT == 3 ? 2 : (NT == 2 ? 3 : 5);  // (2 or 4 for NT == 2: no change, measured)
 #pragma unroll
       for (int i = 0; i < N_MFMA; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -613,17 +613,28 @@ def score_fragments(state: ContextState, use_best_reranker_score: bool) -> tuple
     for c in counts:
         offsets.append(offsets[-1] + c)
     last = len(counts)
+    reduce_f32, f32, intp = np.add.reduce, np.float32, np.intp
     for (_, raw), block in zip(ordered, state.blocks):
         probs = raw.pruning_probs
         n = len(probs)
+        fast = isinstance(probs, np.ndarray) and probs.dtype == np.float32  # mean_f32_slice, inlined (thousands of calls)
         for fragment, (start, end) in zip(block, raw.context_ranges):
             k = fragment.sentence_index
-            offset = offsets[k if k < last else last] if k > 0 else 0
-            start = max(0, start - offset)
-            end = max(start, end - offset)
-            end = min(end, n)
-            start = min(start, n)
-            per_fragment[fragment.global_index].append(1.0 if end <= start else mean_f32_slice(probs[start:end]))
+            if k > 0:
+                offset = offsets[k if k < last else last]
+                start = start - offset
+                end = end - offset
+            if start < 0:
+                start = 0
+            if end > n:
+                end = n
+            if end <= start:
+                value = 1.0
+            elif fast:
+                value = float(f32(reduce_f32(probs[start:end]) / intp(end - start)))
+            else:
+                value = mean_f32_slice(probs[start:end])
+            per_fragment[fragment.global_index].append(value)
         if raw.ranking_score is not None:
             if ranking is None:
                 ranking = raw.ranking_score

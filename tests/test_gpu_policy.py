@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 NO_POLICY_KERNELS = 16  # OP_FLAG_NO_POLICY_KERNELS
 NO_LAYER_FUSION = 32    # OP_FLAG_NO_LAYER_FUSION: two fused kernels per layer (the shape the all-terms set has too)
+LAYER_M32 = 128         # OP_FLAG_LAYER_M32: the whole-layer kernel on 32x32x16 MFMAs (hidden = 256)
 
 
 @pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
@@ -101,3 +102,42 @@ def test_whole_layer_kernel_matches_two_kernel_path(fixture):
     m = mask.bool().numpy()
     assert np.abs(outs["layer"][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3
     assert np.abs(outs["layer"][1] - ref.ranking_logits.numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize("fixture", ["g1_xsmall", "g7_xsmall_refinit", "g1m_meanpool"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_layer32_kernel_matches_the_default_kernel(fixture, precision):
+    """The opt-in 32x32x16 form of the whole-layer kernel (opk_layer32.hip.h: other weight packs, other register layout,
+    LayerNorm in packed arithmetic) evaluates the same terms: equal to the default kernel to fp32 noise, and (bf16x3 on a
+    bf16 checkpoint) within the 1e-3 bar of the oracle."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import pad_rows
+    from oracle.modernbert_oracle import oracle_forward
+
+    arrays, meta = load_golden(fixture)
+    dims = dims_from_meta(meta)
+    assert dims.hidden_size == 256
+    state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v
+             for k, v in state_from_fixture(arrays, meta).items()}
+    rows = rows_from_fixture(arrays)
+    outs = {}
+    for label, flags in (("m16", 0), ("m32", LAYER_M32)):
+        enc = HipEncoder(dims, device="cuda:0", precision=precision, flags=flags)
+        enc.load_state_dict(state)
+        enc.profile_enable(True)
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        assert "fused_layer_attnout_mlp_qkv" in set(enc.profile_read())
+        outs[label] = (prune.cpu().numpy(), rank.cpu().numpy())
+        enc.close()
+    scale = max(1.0, float(np.abs(outs["m16"][0]).max()))
+    tol = 3e-4 if precision == "bf16x3" else 5e-2  # single pass: each kernel's own bf16 rounding noise
+    assert np.abs(outs["m32"][0] - outs["m16"][0]).max() < tol * scale
+    assert np.abs(outs["m32"][1] - outs["m16"][1]).max() < tol * scale
+    if precision == "bf16x3":
+        ids, mask = pad_rows(rows)
+        ref = oracle_forward(state, dims, ids, mask)
+        m = mask.bool().numpy()
+        assert np.abs(outs["m32"][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3
+        assert np.abs(outs["m32"][1] - ref.ranking_logits.numpy()).max() < 1e-3
