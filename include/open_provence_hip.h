@@ -159,6 +159,15 @@ int op_forward_packed(op_handle* h, const int32_t* ids_dev, const int32_t* cu_se
                       float* prune_logits_dev, float* rank_logits_dev, float* keep_prob_dev,
                       void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
+/* Replaces: the per-fragment `float(block_probs[start:end].mean())` of the reference's post-processing
+ * (standalone.py:3075-3082), evaluated on the device on the keep-probabilities a forward left there:
+ *   seg_dev [n_seg, 2] int32  token ranges [start, end) into keep_prob_dev (clamped to [0, n_values))
+ *   out_dev [n_seg]    fp32   mean of the range in numpy's float32 pairwise order, bit for bit; 1.0 for
+ *                             an empty range (ref :3081)
+ * so that process() copies back 4 bytes per fragment instead of 4 per token.  Enqueued on hip_stream. */
+int op_segment_means(op_handle* h, const float* keep_prob_dev, int n_values, const int32_t* seg_dev, int n_seg,
+                     float* out_dev, void* hip_stream);
+
 /* Test hook.  Replaces: output_hidden_states=True of the reference forward (standalone.py:1689,
  * 1727).  When `hidden_dev` is non-NULL the next forwards also write the (num_layers+1) hidden
  * states, fp32 [num_layers+1, total_tokens, hidden]; entry num_layers is the post-final_norm

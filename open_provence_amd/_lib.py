@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "op_effective_policy",
     "op_workspace_bytes",
     "op_forward_packed",
+    "op_segment_means",
     "op_debug_capture_hidden",
     "op_profile_enable",
     "op_profile_read",
@@ -123,6 +124,8 @@ def load_library() -> ctypes.CDLL:
     lib.op_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, cs, vp]
     lib.op_effective_policy.restype = ci
     lib.op_effective_policy.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ci)]
+    lib.op_segment_means.restype = ci
+    lib.op_segment_means.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     lib.op_debug_capture_hidden.restype = ci
     lib.op_debug_capture_hidden.argtypes = [vp, vp]
     lib.op_profile_enable.restype = ci

@@ -1174,6 +1174,19 @@ int op_profile_enable(op_handle* h, int enabled) {
   return OP_OK;
 }
 
+int op_segment_means(op_handle* h, const float* keep_prob_dev, int n_values, const int32_t* seg_dev, int n_seg,
+                     float* out_dev, void* hip_stream) {
+  if (!h) return fail(nullptr, OP_ERR_INVALID, "op_segment_means: NULL handle");
+  if (n_seg < 0 || n_values < 0 || (n_seg > 0 && (!keep_prob_dev || !seg_dev || !out_dev)))
+    return fail(h, OP_ERR_INVALID, "op_segment_means: NULL buffer or negative count");
+  if (n_seg == 0) return OP_OK;
+  OP_HIP(h, hipSetDevice(h->cfg.device_id));
+  hipLaunchKernelGGL(segment_mean_kernel, dim3((unsigned)((n_seg + 127) / 128)), dim3(128), 0, (hipStream_t)hip_stream,
+                     keep_prob_dev, seg_dev, n_seg, n_values, out_dev);
+  OP_HIP(h, hipGetLastError());
+  return OP_OK;
+}
+
 int op_profile_reset(op_handle* h) {
   if (!h) return fail(nullptr, OP_ERR_INVALID, "op_profile_reset: NULL handle");
   int rc = drain_profile(h);

@@ -423,4 +423,81 @@ __global__ __launch_bounds__(256) void zero_odd_units_kernel(u16* __restrict__ b
   reinterpret_cast<uint4*>(base + (2 * pair + 1) * unit)[off] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Mean keep-probability of token ranges (one thread per range), bit for bit what the reference computes on the host
+// with numpy: float(block_probs[start:end].mean()) (standalone.py:3075-3082) = float32 PAIRWISE sum in numpy's order
+// (umath/loops_utils.h.src, @TYPE@_pairwise_sum: < 8 elements sequential; <= 128 elements eight running sums over
+// blocks of 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the remainder sequentially; longer ranges split
+// at n/2 rounded down to a multiple of 8), divided by the count in float64 and rounded back to float32.  An empty range
+// scores 1.0 (ref :3081).  process() then copies 4 bytes per FRAGMENT back instead of 4 per token and runs no numpy
+// reduction per fragment.  Explicit __fadd_rn: nothing here may be contracted or reassociated.
+// ----------------------------------------------------------------------------------------------
+__device__ inline float np_pairwise_leaf_f32(const float* a, int n) {  // n <= 128
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res = __fadd_rn(res, a[i]);
+    return res;
+  }
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+  }
+  float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                        __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+  for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+  return res;
+}
+// the recursion pairwise(a, n) = pairwise(a, n2) + pairwise(a + n2, n - n2) on an explicit stack (depth <= 24 covers any int)
+__device__ inline float np_pairwise_sum_f32(const float* a, int n) {
+  const float* fa[24];
+  int fn[24], fstage[24];
+  float fleft[24];
+  int sp = 0;
+  fa[0] = a; fn[0] = n; fstage[0] = 0; fleft[0] = 0.f;
+  float ret = 0.f;
+  while (sp >= 0) {
+    if (fn[sp] <= 128) {
+      ret = np_pairwise_leaf_f32(fa[sp], fn[sp]);
+      --sp;
+      continue;
+    }
+    int n2 = fn[sp] / 2;
+    n2 -= n2 % 8;
+    if (fstage[sp] == 0) {
+      fstage[sp] = 1;
+      fa[sp + 1] = fa[sp]; fn[sp + 1] = n2; fstage[sp + 1] = 0;
+      ++sp;
+    } else if (fstage[sp] == 1) {
+      fleft[sp] = ret;
+      fstage[sp] = 2;
+      fa[sp + 1] = fa[sp] + n2; fn[sp + 1] = fn[sp] - n2; fstage[sp + 1] = 0;
+      ++sp;
+    } else {
+      ret = __fadd_rn(fleft[sp], ret);
+      --sp;
+    }
+  }
+  return ret;
+}
+
+__global__ void segment_mean_kernel(const float* __restrict__ values, const int32_t* __restrict__ seg, int n_seg,
+                                    int n_values, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_seg) return;
+  int start = seg[2 * i], end = seg[2 * i + 1];
+  start = start < 0 ? 0 : start;
+  end = end > n_values ? n_values : end;
+  if (end <= start) {
+    out[i] = 1.0f;
+    return;
+  }
+  const float sum = np_pairwise_sum_f32(values + start, end - start);
+  out[i] = (float)((double)sum / (double)(end - start));
+}
+
 }  // namespace opk

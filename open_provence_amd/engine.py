@@ -197,6 +197,30 @@ class HipEncoder:
             self._workspace = ws
         return ws
 
+    def segment_means(self, values: torch.Tensor, segments: torch.Tensor) -> torch.Tensor:
+        """``values[T]`` fp32 and ``segments[S, 2]`` int32 (token ranges ``[start, end)``) on this device ->
+        ``[S]`` fp32: ``values[start:end].mean()`` in numpy's float32 pairwise order, bit for bit; 1.0 for an empty
+        range (the reference's per-fragment score, standalone.py:3075-3082).  Asynchronous on the current stream."""
+
+        if values.dtype != torch.float32 or segments.dtype != torch.int32:
+            raise TypeError("values must be fp32 and segments int32")
+        if values.device != self.device or segments.device != self.device:
+            raise ValueError(f"values / segments must live on {self.device}")
+        if not values.is_contiguous() or not segments.is_contiguous() or segments.ndim != 2 or segments.shape[1] != 2:
+            raise ValueError("values must be contiguous and segments a contiguous [S, 2] tensor")
+        n_seg = int(segments.shape[0])
+        out = torch.empty(n_seg, dtype=torch.float32, device=self.device)
+        if n_seg == 0:
+            return out
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            code = self.lib.op_segment_means(
+                self._handle, ctypes.c_void_p(values.data_ptr()), int(values.numel()), ctypes.c_void_p(segments.data_ptr()),
+                n_seg, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream),
+            )
+        _lib.check(self.lib, self._handle, code, "op_segment_means")
+        return out
+
     def forward_packed(
         self,
         ids: torch.Tensor,

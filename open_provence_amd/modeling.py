@@ -80,6 +80,9 @@ class ProcessPerformanceTrace:
         return {name: float(getattr(self, name)) for name in self.__dataclass_fields__}
 
 
+_NO_PROBS = np.zeros(0, dtype=np.float32)
+
+
 class OpenProvenceOutput(dict):
     """Forward result usable both as a Mapping and through attributes, exposing the reference's fields:
     ``logits`` (= ``ranking_logits``), ``ranking_logits``, ``pruning_logits``, ``loss``, ``hidden_states``."""
@@ -563,15 +566,20 @@ class OpenProvenceModel:
                 "cu": torch.empty(cap_r, dtype=torch.int32).pin_memory(),
                 "keep": torch.empty(cap_t, dtype=torch.float32).pin_memory(),
                 "rank": torch.empty(cap_r * nl, dtype=torch.float32).pin_memory(),
+                "seg": torch.empty(2 * cap_t, dtype=torch.int32).pin_memory(),  # a fragment has at least one token
             }
-            for name in ("ids", "cu", "keep", "rank"):
+            for name in ("ids", "cu", "keep", "rank", "seg"):
                 pool[name + "_np"] = pool[name].numpy()
             pools[slot] = pool
         return pool
 
-    def _launch_rows(self, rows: list[list[int]]) -> dict[str, Any]:
+    def _launch_rows(self, rows: list[list[int]], segments: list[list[tuple[int, int]]] | None = None) -> dict[str, Any]:
         """Enqueue one forward on the current stream: pinned H2D of the packed ids, the forward (keep-probability from
-        the head kernel), pinned D2H of keep-probabilities + ranking logits, one event.  Nothing here waits for the GPU."""
+        the head kernel), pinned D2H of keep-probabilities + ranking logits, one event.  Nothing here waits for the GPU.
+
+        With ``segments`` (per row, token ranges within the row) the keep-probabilities stay on the device: their mean
+        over every range is taken there (``op_segment_means``: numpy's float32 pairwise order, bit for bit) and only
+        4 bytes per range come back."""
 
         ids_np, cu_np, max_len = pack_rows(rows)
         self.encoder.check_ids(ids_np)
@@ -584,19 +592,53 @@ class OpenProvenceModel:
         ids_dev = pool["ids"][:total].to(dev, non_blocking=True)
         cu_dev = pool["cu"][: n_rows + 1].to(dev, non_blocking=True)
         keep_dev = torch.empty(total, dtype=torch.float32, device=dev)
+        seg_counts = None
+        seg_dev = means_dev = None
+        n_seg = 0
+        if segments is not None:
+            seg_counts = [len(s) for s in segments]
+            n_seg = sum(seg_counts)
+            if 2 * n_seg > pool["seg"].numel():
+                segments = seg_counts = None  # (cannot happen for non-empty fragments; fall back to the token payload)
+        if segments is not None:
+            flat = pool["seg_np"][: 2 * n_seg]
+            pos = 0
+            for i, segs in enumerate(segments):
+                base = int(cu_np[i])
+                for start, end in segs:
+                    flat[pos] = base + start
+                    flat[pos + 1] = base + end if end > start else base + start
+                    pos += 2
+            seg_dev = pool["seg"][: 2 * n_seg].to(dev, non_blocking=True).view(n_seg, 2)
         _, rank_dev = self.encoder.forward_packed(ids_dev, cu_dev, cu_np, max_len, keep_prob=keep_dev)
-        pool["keep"][:total].copy_(keep_dev, non_blocking=True)
+        if segments is not None:
+            means_dev = self.encoder.segment_means(keep_dev, seg_dev)
+            pool["keep"][:n_seg].copy_(means_dev, non_blocking=True)
+        else:
+            pool["keep"][:total].copy_(keep_dev, non_blocking=True)
         pool["rank"][: n_rows * nl].copy_(rank_dev.reshape(-1), non_blocking=True)
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev))
-        return {"event": event, "pool": pool, "total": total, "rows": n_rows, "cu": cu_np, "alive": (ids_dev, cu_dev, keep_dev, rank_dev)}
+        return {"event": event, "pool": pool, "total": total, "rows": n_rows, "cu": cu_np, "seg_counts": seg_counts,
+                "alive": (ids_dev, cu_dev, keep_dev, rank_dev, seg_dev, means_dev)}
 
-    def _collect_rows(self, handle: dict[str, Any]) -> tuple[torch.Tensor, list[np.ndarray]]:
+    def _collect_rows(self, handle: dict[str, Any]) -> tuple[torch.Tensor, list[Any]]:
+        """-> (ranking logits, per row: its keep-probabilities, or -- launched with ``segments`` -- the list of its
+        range means as Python floats)."""
+
         handle["event"].synchronize()
         total, n_rows, nl, cu = handle["total"], handle["rows"], int(self.dims.num_labels), handle["cu"]
-        keep = handle["pool"]["keep_np"][:total].copy()  # the slot is reused two launches later
         rank = torch.from_numpy(handle["pool"]["rank_np"][: n_rows * nl].copy()).reshape(n_rows, nl)
+        counts = handle.get("seg_counts")
         handle["alive"] = None
+        if counts is not None:
+            means = handle["pool"]["keep_np"][: sum(counts)].tolist()  # float32 -> Python float, exact
+            out, pos = [], 0
+            for c in counts:
+                out.append(means[pos : pos + c])
+                pos += c
+            return rank, out
+        keep = handle["pool"]["keep_np"][:total].copy()  # the slot is reused two launches later
         return rank, [keep[cu[i] : cu[i + 1]] for i in range(n_rows)]
 
     def _predict_rows_local(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
@@ -994,8 +1036,16 @@ class OpenProvenceModel:
                 type_rows.append(type_ids)
                 ranges_per_job.append(ranges)
             if pipelined:
+                # the token range every fragment is averaged over is known now: the means are taken on the device
+                segments = [
+                    pl.fragment_token_ranges(
+                        states[(job["query_idx"], job["context_idx"])],
+                        states[(job["query_idx"], job["context_idx"])].blocks[job["block_idx"]], ranges_per_job[i], len(rows[i]),
+                    )
+                    for i, job in enumerate(chunk)
+                ]
                 t0 = perf_counter()
-                handle = self._launch_rows(rows)
+                handle = self._launch_rows(rows, segments)
                 elapsed += perf_counter() - t0
                 pending.append((handle, chunk, ranges_per_job, queries, states))
                 if len(pending) > 1:  # the previous chunk has had a whole launch + host stage to finish
@@ -1013,6 +1063,7 @@ class OpenProvenceModel:
         rank_scores = rank[:, 0] if rank.ndim == 2 and rank.shape[1] > 1 else rank.reshape(-1)
         scores = torch.sigmoid(rank_scores.to(torch.float32)).tolist()  # = _ranking_score row by row (ref :2913-2916)
         for i, job in enumerate(chunk):
+            reduced = isinstance(keeps[i], list)  # per-fragment means from the device (see _launch_rows)
             states[(job["query_idx"], job["context_idx"])].raw_blocks.append(
                 (
                     job["block_idx"],
@@ -1020,8 +1071,9 @@ class OpenProvenceModel:
                         query=queries[job["query_idx"]],
                         contexts=list(job["texts"]),
                         ranking_score=scores[i],
-                        pruning_probs=keeps[i],
+                        pruning_probs=_NO_PROBS if reduced else keeps[i],
                         context_ranges=ranges_per_job[i],
+                        fragment_means=keeps[i] if reduced else None,
                     ),
                 )
             )

@@ -46,6 +46,9 @@ class RawPrediction:
     ranking_score: float | None
     pruning_probs: np.ndarray
     context_ranges: list[tuple[int, int]]
+    # process() on the native forward: the per-fragment means of `pruning_probs` over `fragment_token_ranges`, already
+    # reduced on the device (op_segment_means: numpy's float32 pairwise order, bit for bit); pruning_probs is then empty
+    fragment_means: list[float] | None = None
 
 
 @dataclass
@@ -598,6 +601,35 @@ def mean_of_floats(values: Sequence[float]) -> float:
     return float(np.add.reduce(np.asarray(values, dtype=np.float64)) / np.intp(len(values)))
 
 
+def fragment_token_ranges(state: ContextState, block: Sequence[Any], ranges: Sequence[tuple[int, int]], n_tokens: int) -> list[tuple[int, int]]:
+    """The token range each fragment of a block is averaged over, within a row of ``n_tokens`` keep-probabilities:
+    the fragment's range shifted LEFT by the token count of the prefix (title) sentences that precede its sentence index
+    and clamped -- exactly the arithmetic of :func:`score_fragments` (ref :3075-3081).  ``end <= start`` = empty."""
+
+    counts = state.prefix_token_counts
+    out: list[tuple[int, int]] = []
+    if not counts:
+        for _, (start, end) in zip(block, ranges):
+            if start < 0:
+                start = 0
+            out.append((start, end if end <= n_tokens else n_tokens))
+        return out
+    offsets = [0]
+    for c in counts:
+        offsets.append(offsets[-1] + c)
+    last = len(counts)
+    for fragment, (start, end) in zip(block, ranges):
+        k = fragment.sentence_index
+        if k > 0:
+            offset = offsets[k if k < last else last]
+            start -= offset
+            end -= offset
+        if start < 0:
+            start = 0
+        out.append((start, end if end <= n_tokens else n_tokens))
+    return out
+
+
 def score_fragments(state: ContextState, use_best_reranker_score: bool) -> tuple[dict[int, list[float]], float | None]:
     """Mean keep-probability of every fragment in every block, and the context's rerank score.
 
@@ -615,6 +647,15 @@ def score_fragments(state: ContextState, use_best_reranker_score: bool) -> tuple
     last = len(counts)
     reduce_f32, f32, intp = np.add.reduce, np.float32, np.intp
     for (_, raw), block in zip(ordered, state.blocks):
+        if raw.fragment_means is not None:  # reduced on the device over fragment_token_ranges()
+            for fragment, value in zip(block, raw.fragment_means):
+                per_fragment[fragment.global_index].append(value)
+            if raw.ranking_score is not None:
+                if ranking is None:
+                    ranking = raw.ranking_score
+                elif use_best_reranker_score:
+                    ranking = max(ranking, raw.ranking_score)
+            continue
         probs = raw.pruning_probs
         n = len(probs)
         fast = isinstance(probs, np.ndarray) and probs.dtype == np.float32  # mean_f32_slice, inlined (thousands of calls)

@@ -549,3 +549,31 @@ def test_automodel_from_pretrained_lands_on_the_hip_class(tmp_path, monkeypatch)
         assert type(loaded).__name__ == klass.__name__ and type(loaded).__module__ == "open_provence_amd.modeling"
         got = loaded(input_ids=ids, attention_mask=mask)
         assert torch.equal(got.logits, want[key]) and torch.equal(got.ranking_logits, want.ranking_logits)
+
+
+def test_segment_means_equal_numpy_mean_bit_for_bit():
+    """op_segment_means (process(): per-fragment keep-probability means taken on the device) reproduces
+    ``float(values[start:end].mean())`` of numpy on float32 -- pairwise summation order, float64 division -- exactly,
+    for every range length up to a long row, and scores an empty range 1.0 (standalone.py:3075-3082)."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims
+
+    enc = HipEncoder(named_dims("xsmall"), device="cuda:0", precision="bf16x3")
+    rng = np.random.default_rng(11)
+    values = rng.random(20000, dtype=np.float32)
+    lengths = list(range(0, 700)) + [1000, 2047, 2048, 4097, 8192]
+    segs, start = [], 3
+    for n in lengths:
+        if start + n > values.shape[0]:
+            start = 1
+        segs.append((start, start + n))
+        start += max(1, n // 3)
+    segs += [(5, 5), (9, 4), (19990, 20000), (-3, 6), (19995, 20010)]
+    seg_np = np.asarray(segs, dtype=np.int32)
+    out = enc.segment_means(torch.from_numpy(values).to("cuda:0"), torch.from_numpy(seg_np).to("cuda:0")).cpu().numpy()
+    for (s, e), got in zip(segs, out):
+        s, e = max(0, s), min(e, values.shape[0])
+        want = 1.0 if e <= s else float(values[s:e].mean())
+        assert float(got) == want, (s, e, float(got), want)
+    enc.close()
