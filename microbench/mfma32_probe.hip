@@ -1,7 +1,7 @@
 // Microbenchmark (measurement aid, not product code): how much non-MFMA issue fits beside one wave's MFMA stream for
 // the two bf16 shapes of gfx950 -- v_mfma_f32_16x16x32_bf16 (4 passes, 16 cycles) and v_mfma_f32_32x32x16_bf16
 // (8 passes, 32 cycles, the same flop rate) -- with the accumulators in AGPRs, one wave per SIMD, and a fixed mix of
-// vector / accumulator-read / LDS instructions per unit of MFMA work (one unit = 32768 x 2 flop: two 16x16x32 or one
+// vector / accumulator-read / LDS instructions per unit of MFMA work (one unit = 32768 flop: two 16x16x32 or one
 // 32x32x16).  Also: vector-only throughput of scalar vs packed fp32 arithmetic (the LayerNorm phases).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o mfma32_probe mfma32_probe.hip && ./mfma32_probe
 #include <hip/hip_runtime.h>
@@ -223,7 +223,7 @@ static void power_probe(const char* label, int random, float* sink) {
     cyc += (double)host[2 * b];
     real += (double)host[2 * b + 1];
   }
-  const double flops = (double)blocks * 4 * WPS * (double)n_iters * 16 * 65536.0;
+  const double flops = (double)blocks * 4 * WPS * (double)n_iters * 16 * 32768.0;  // 16 units of 32768 flop per iteration
   printf("%s  %d wave(s)/SIMD  %-18s %6.3f GHz shader clock  %7.1f TFLOP/s executed  (%.1f ms)\n",
          SHAPE == 0 ? "16x16x32" : "32x32x16", WPS, label, cyc / real * 0.1, flops / ms * 1e-9, ms);
   CHECK(hipFree(out));
@@ -247,7 +247,7 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  printf("one wave per SIMD, AGPR accumulators; unit = 65536 flop of MFMA work (32 pipe cycles)\n");
+  printf("one wave per SIMD, AGPR accumulators; unit = 32768 flop of MFMA work (32 pipe cycles)\n");
   BOTH("nothing else", 0);
   BOTH("2 v_fma", 2);
   BOTH("4 v_fma", 4);

@@ -13,7 +13,7 @@ namespace opk {
 //   x += o Wo^T ; LayerNorm ; x += GeGLU(LN(x) Wi^T) Wo^T with h kept in registers ; LayerNorm ; next q / k / v^T
 // but every contraction runs on the 32x32x16 shape.  Why: the loops of this kernel are bound by how many non-MFMA
 // instructions one wave (one per SIMD, 512 registers) can issue beside its MFMA stream, and the budget is per MFMA
-// INSTRUCTION, not per flop -- measured (microbench/mfma32_probe.hip), beside 65536 flop of matrix work:
+// INSTRUCTION, not per flop -- measured (microbench/mfma32_probe.hip), beside 32768 flop of matrix work:
 //   two 16x16x32:  2 fma + 1 accumulator read + 0.5 LDS read   42.5 cycles      one 32x32x16:  35.0 (32 = pipe-bound)
 // The 32x32 shape needs its accumulators in AGPRs (the 512-register budget puts them there) and gives a wave ONE
 // 32-row fragment: lane = (row n = lane % 32, half h = lane / 32).
@@ -372,14 +372,6 @@ __global__ __launch_bounds__(256, 1) void layer32_kernel(Layer32Params p) {
   };
   auto macro = [&](int t, int cur, auto slab_tag) {
     constexpr bool WITH_SLAB = decltype(slab_tag)::value;  // false only for t = 0
-    // the attention output of the tile 256 blocks ahead is touched while HBM idles (see rowgemm_kernel's macro())
-    unsigned pf_dummy;
-    {
-      const int blk = (int)blockIdx.x + 256 < (int)gridDim.x ? (int)blockIdx.x + 256 : (int)blockIdx.x;
-      const char* o_next = reinterpret_cast<const char*>(p.o_fp + ((size_t)blk * 8) * NT * 2 * 512);
-      const char* src = o_next + (size_t)wave * (32 * H * 4) + (size_t)(t % 8) * 4096 + lane * 64;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(src));
-    }
     frag_stream2<(WITH_SLAB ? KS + 8 : KS), 2, MlpOff>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
       constexpr int s = decltype(step_tag)::value;
       if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
@@ -404,7 +396,6 @@ __global__ __launch_bounds__(256, 1) void layer32_kernel(Layer32Params p) {
       }
       interleave(0);
     });
-    asm volatile("" ::"v"(pf_dummy));
   };
   auto end_of_stage = [&]() {
 #ifdef OPK_TIMING

@@ -12,7 +12,7 @@
 //   OPK_ABL_NO_GELU      GELU replaced by the identity     OPK_ABL_NO_DMA     no weight DMA inside the loop
 //   OPK_ABL_NO_EPILOGUE  the deferred epilogue is skipped  OPK_ABL_NO_PHASE1  phase 1 (x += A1 W1^T) skipped
 #ifndef OPK_PREFETCH
-#define OPK_PREFETCH 1  // whole-layer kernel: operands touched ahead (bit 0: o, bit 1: x), 0 = off; see macro()
+#define OPK_PREFETCH 0  // whole-layer kernel: operands touched ahead (bit 0: o, bit 1: x), 0 = off; see macro()
 #endif
 #ifndef OPK_PF_STRIDE
 #define OPK_PF_STRIDE 256
@@ -828,12 +828,14 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         // GeGLU of chunk 2t-1 (the last reader of acc_b's old contents) is over after the first KS steps.
         f32x4 na[2][MF];
 #if OPK_PREFETCH
-        // Every CU of the chip starts a tile at the same time and the operand fetch that opens it is a 64 MB burst
-        // (29 k of a tile's 245 k cycles, 8 k of them MFMAs) while HBM idles during the MLP.  So each macro-iteration
-        // touches one dword per 64 B of a slice of the attention output `o` of the tile OPK_PF_STRIDE blocks ahead
-        // (the block the dispatcher hands to this XCD a round later, as observed; used for speed only) -- one
-        // instruction per wave, the register is never read.  Measured same-box: that phase 29.0 k -> 23.8 k cycles,
-        // kernel -1.3 %; also touching the residual rows (bit 1) or touching only late gives nothing.
+        // Experiment kept behind OPK_PREFETCH (default 0).  Every CU of the chip starts a tile at the same time and the
+        // operand fetch that opens it is a 64 MB burst (29 k of a tile's 245 k cycles, 8 k of them MFMAs) while HBM
+        // idles during the MLP; so each macro-iteration can touch one dword per 64 B of a slice of the attention
+        // output `o` (bit 0) / the residual rows (bit 1) of the tile OPK_PF_STRIDE blocks ahead (the block the
+        // dispatcher hands to this XCD a round later, as observed).  Measured: the isolated launch gains 1.3 % (fetch
+        // phase 29.0 k -> 23.8 k cycles), the whole forward LOSES 0.9 % (same-box A/B, three alternations): an XCD's
+        // 4 MB of L2 cannot hold the 8 MB its CUs touch per round, FETCH_SIZE of the launch doubles (352 -> 714 MB),
+        // and in the sustained run that traffic costs more of the power budget than the shorter phase returns.
         unsigned pf_dummy;
         {
           const int blk = (int)blockIdx.x + OPK_PF_STRIDE < (int)gridDim.x ? (int)blockIdx.x + OPK_PF_STRIDE : (int)blockIdx.x;
@@ -884,7 +886,13 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       __builtin_amdgcn_s_barrier();  // stage 0 has landed
       OPK_STAMP(2);
       macro(0, 0, no_);
-      for (int t = 1; t < n_pairs; ++t) macro(t, t & 1, yes_);  // n_pairs is even (checked on the host): the tail reads stage 0
+      {  // n_pairs is even (checked on the host): at least one more iteration, and the tail reads stage 0.  Written as
+        // do-while: around a loop that may run zero times the compiler parks accumulator values in scratch.
+        int t = 1;
+        do {
+          macro(t, t & 1, yes_);
+        } while (++t < n_pairs);
+      }
       {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
         static_for<KS>([&](auto sl) { geglu_slice(acc_b, g_prev, sl, pack_h); });
         struct TailOff {

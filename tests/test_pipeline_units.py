@@ -311,3 +311,46 @@ def test_fast_means_are_bit_identical_to_numpy_mean():
         n = int(rng.integers(1, 12))
         values = [float(v) for v in rng.random(n)]
         assert mean_of_floats(values) == float(np.mean(values))
+
+
+def test_device_side_fragment_means_path_equals_the_token_path():
+    """process() on the native forward hands ``score_fragments`` per-fragment means reduced on the device over
+    ``fragment_token_ranges`` (op_segment_means); the ranges must be exactly the ones the token path averages over
+    (ref :3075-3081), including the title-offset shift, clamping and empty ranges."""
+
+    import numpy as np
+
+    from open_provence_amd.pipeline import ContextState, RawPrediction, fragment_token_ranges, score_fragments
+
+    rng = np.random.default_rng(3)
+    for prefix_counts in ([], [4], [3, 5]):
+        n_prefix = len(prefix_counts)
+        blocks, raws_tokens, raws_means = [], [], []
+        gidx = 0
+        for b in range(3):
+            n_tokens = int(rng.integers(20, 60))
+            probs = rng.random(n_tokens).astype(np.float32)
+            block, ranges = [], []
+            pos = 3
+            for s in range(int(rng.integers(2, 6))):
+                length = int(rng.integers(0, 12))
+                sent = n_prefix + len(block) if rng.random() < 0.8 else int(rng.integers(0, n_prefix + 1))
+                block.append(_FragmentRecord(f"s{gidx}", sent, 0, gidx, n_prefix + 1 + gidx, [1]))
+                start = pos + sum(prefix_counts) if n_prefix and sent >= n_prefix else pos
+                ranges.append((start, start + length + (40 if s == 0 and b == 2 else 0)))  # one range runs off the row
+                pos += length
+                gidx += 1
+            blocks.append(block)
+            raws_tokens.append((b, RawPrediction("q", ["c"], 0.1 * b, probs, ranges)))
+        state = ContextState.__new__(ContextState)
+        state.blocks = blocks
+        state.prefix_token_counts = list(prefix_counts)
+        state.raw_blocks = raws_tokens
+        want, want_rank = score_fragments(state, True)
+        for (b, raw), block in zip(raws_tokens, blocks):
+            segs = fragment_token_ranges(state, block, raw.context_ranges, len(raw.pruning_probs))
+            means = [1.0 if e <= s else float(raw.pruning_probs[s:e].mean()) for s, e in segs]
+            raws_means.append((b, RawPrediction("q", ["c"], raw.ranking_score, np.zeros(0, np.float32), raw.context_ranges, means)))
+        state.raw_blocks = raws_means
+        got, got_rank = score_fragments(state, True)
+        assert dict(got) == dict(want) and got_rank == want_rank
