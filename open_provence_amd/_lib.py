@@ -24,6 +24,7 @@ OP_FLAG_FORCE_TILED, OP_FLAG_NO_SMALL_BLOCKS, OP_FLAG_ATT_WAVES_4, OP_FLAG_ATT_W
 OP_FLAG_NO_LAYER_FUSION = 32
 OP_FLAG_LAYER_8X16 = 64
 OP_FLAG_LAYER_M32 = 128
+OP_FLAG_NO_HEAD_FUSION = 256
 OP_POOL_CLS, OP_POOL_MEAN = 0, 1
 
 LIB_NAME = "libopenprovence_hip.so"

@@ -457,6 +457,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   // Kernel sets whose GEMM weights are single-plane run a whole layer (attention output projection, MLP, next q/k/v
   // projection) as ONE kernel with h kept on chip; the all-terms set keeps the two fused kernels per layer.
   const bool layer_fused = h->row_path && !h->emulate && opl::has_row_layer_fused(h->pi) && !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION);
+  const bool head_in_last_layer = layer_fused && h->cfg.pooling != OP_POOL_MEAN && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
+  bool head_done = false;
 
   for (int li = 0; li < h->N; ++li) {
     const LayerWeights& lw = h->layers[li];
@@ -516,6 +518,20 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         rl.wi_pk = lw.wi_pk;
         rl.wo2_ks = lw.wo2_pk;
         rl.n_pairs = I / 32;
+        if (!with_qkv && head_in_last_layer) {
+          // the last layer's rows go straight through final_norm + the pruning head (no write-back of x, no
+          // final_ln_prune launch); mean pooling and hidden-state capture need all normalised rows and keep the kernel
+          rl.fin_ln = h->final_norm;
+          rl.fin_pw = h->prune_w;
+          rl.fin_pb = h->prune_b;
+          rl.row_tok = ws.row_tok;
+          rl.row_seq = ws.row_seq;
+          rl.fin_prune = prune_out;
+          rl.fin_keep = keep_prob;
+          rl.fin_cls = ws.cls;
+          rl.fin_pre_norm = h->cfg.prune_pre_final_norm ? 1 : 0;
+          head_done = true;
+        }
         OP_TRY(L.begin(PK_FUSED_LAYER));
         if (!opl::launch_row_layer_fused(st, rl, H / 32, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM),
                                          (h->cfg.flags & OP_FLAG_LAYER_8X16) != 0 || (opl::kPolicies[h->pi].wi & 1) == 0))
@@ -729,12 +745,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   }
 
   const int mean_pool = h->cfg.pooling == OP_POOL_MEAN ? 1 : 0;
-  OP_TRY(L.begin(PK_FINAL_LN_PRUNE));
-  hipLaunchKernelGGL(final_ln_prune_kernel, dim3(row_blocks), dim3(256), 0, st, ws.x, h->final_norm, h->cfg.norm_eps, H,
-                     r_pad, ws.row_tok, ws.row_seq, ws.row_pos, h->prune_w, h->prune_b, prune_out, keep_prob,
-                     h->cfg.prune_pre_final_norm ? 1 : 0, mean_pool, ws.cls,
-                     h->capture ? h->capture + (size_t)h->N * total_tokens * H : nullptr);
-  OP_TRY(L.end());
+  if (!head_done) {
+    OP_TRY(L.begin(PK_FINAL_LN_PRUNE));
+    hipLaunchKernelGGL(final_ln_prune_kernel, dim3(row_blocks), dim3(256), 0, st, ws.x, h->final_norm, h->cfg.norm_eps, H,
+                       r_pad, ws.row_tok, ws.row_seq, ws.row_pos, h->prune_w, h->prune_b, prune_out, keep_prob,
+                       h->cfg.prune_pre_final_norm ? 1 : 0, mean_pool, ws.cls,
+                       h->capture ? h->capture + (size_t)h->N * total_tokens * H : nullptr);
+    OP_TRY(L.end());
+  }
   OP_TRY(L.begin(PK_RANK_HEAD));
   hipLaunchKernelGGL(rank_head_kernel, dim3((unsigned)ns), dim3(256), 0, st, ws.cls, ws.x, cu_dev, s0, ws.roff, mean_pool,
                      H, h->nl, h->dense_t, h->head_norm, h->cfg.norm_eps, h->cls_w, h->cls_b, rank_out);

@@ -28,6 +28,7 @@ _ENV_FLAGS = {
     "OPEN_PROVENCE_NO_LAYER_FUSION": _lib.OP_FLAG_NO_LAYER_FUSION,
     "OPEN_PROVENCE_LAYER_8X16": _lib.OP_FLAG_LAYER_8X16,
     "OPEN_PROVENCE_LAYER_M32": _lib.OP_FLAG_LAYER_M32,
+    "OPEN_PROVENCE_NO_HEAD_FUSION": _lib.OP_FLAG_NO_HEAD_FUSION,
 }
 
 

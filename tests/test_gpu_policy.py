@@ -141,3 +141,41 @@ def test_layer32_kernel_matches_the_default_kernel(fixture, precision):
         m = mask.bool().numpy()
         assert np.abs(outs["m32"][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3
         assert np.abs(outs["m32"][1] - ref.ranking_logits.numpy()).max() < 1e-3
+
+
+NO_HEAD_FUSION = 256  # OP_FLAG_NO_HEAD_FUSION: final_norm + pruning head as their own launch
+
+
+@pytest.mark.parametrize("fixture", ["g0b_hd64_refinit", "g0c_hd64_synth", "g1_xsmall", "g7_xsmall_refinit", "g12_prenorm_tf4"])
+def test_head_inside_the_last_layer_kernel(fixture):
+    """Without hidden-state capture and with CLS pooling the last whole-layer launch ends with final_norm + the pruning
+    head on the rows in its accumulators (no write-back of the residual stream, no final_ln_prune launch; the
+    transformers-4.x pre-norm convention of g12 included): same logits as the separate launch to fp32 noise, and
+    within the bar of the reference outputs."""
+
+    from open_provence_amd.engine import HipEncoder
+
+    arrays, meta = load_golden(fixture)
+    dims = dims_from_meta(meta)
+    state = state_from_fixture(arrays, meta)
+    rows = rows_from_fixture(arrays)
+    outs = {}
+    for label, flags in (("fused", 0), ("separate", NO_HEAD_FUSION)):
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x2", flags=flags,
+                         prune_pre_final_norm=bool(meta.get("prune_pre_final_norm", False)))
+        enc.load_state_dict(state)
+        enc.profile_enable(True)
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        kinds = set(enc.profile_read())
+        assert "fused_layer_attnout_mlp_qkv" in kinds
+        assert ("final_ln_prune" in kinds) == (label == "separate"), kinds
+        outs[label] = (prune.cpu().numpy(), rank.cpu().numpy())
+        enc.close()
+    scale = max(1.0, float(np.abs(outs["separate"][0]).max()))
+    assert np.abs(outs["fused"][0] - outs["separate"][0]).max() < 2e-5 * scale
+    assert np.abs(outs["fused"][1] - outs["separate"][1]).max() < 2e-5 * scale
+    # bf16 checkpoint + default policy against the reference outputs: the bar
+    rep = run_fixture_on_gpu(fixture, "bf16x3", capture=False)
+    if "refinit" in fixture:  # (the O(1)-weight fixtures need their fp32 lo planes: checked with capture in test_gpu_parity)
+        assert rep["prune_max_err"] < 1e-3 and rep["rank_max_err"] < 1e-3
