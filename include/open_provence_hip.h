@@ -79,7 +79,7 @@ enum op_flags {
   OP_FLAG_NO_POLICY_KERNELS = 16, /* always run the all-terms kernels with cleared lo operands (test hook)   */
   OP_FLAG_NO_LAYER_FUSION = 32,   /* two fused kernels per layer instead of the whole-layer kernel (A/B hook) */
   OP_FLAG_LAYER_8X16 = 64,        /* whole-layer kernel as 8 waves x 16 rows (two waves per SIMD) (A/B hook)   */
-  OP_FLAG_NO_HEAD_FUSION = 256,   /* final_norm + pruning head as their own launch also behind the whole-layer kernel (A/B hook) */
+  OP_FLAG_NO_HEAD_FUSION = 256,   /* embedding + LayerNorm and final_norm + pruning head as their own launches on the row path too (A/B hook) */
   OP_FLAG_LAYER_M32 = 128         /* whole-layer kernel on 32x32x16 MFMAs (hidden = 256): fewer cycles, more power per flop -- slower under the power limit (A/B hook) */
 };
 

@@ -337,14 +337,19 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     if (split) OP_HIP(h, hipMemsetAsync(ws.o_lo + tail_off, 0, tail_bytes, st));
   }
 
-  OP_TRY(L.begin(PK_EMBED_LN));
-  if (split)
-    hipLaunchKernelGGL((embed_ln_kernel<true>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
-                       h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
-  else
-    hipLaunchKernelGGL((embed_ln_kernel<false>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
-                       h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
-  OP_TRY(L.end());
+  // Row path without hidden-state capture: the layer-0 q / k / v kernel gathers and normalises the embeddings itself
+  // (RowGemmParams::emb_table) -- no embedding launch, the residual rows are written once and not read back.
+  const bool embed_in_qkv0 = h->row_path && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
+  if (!embed_in_qkv0) {
+    OP_TRY(L.begin(PK_EMBED_LN));
+    if (split)
+      hipLaunchKernelGGL((embed_ln_kernel<true>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
+                         h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
+    else
+      hipLaunchKernelGGL((embed_ln_kernel<false>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
+                         h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
+    OP_TRY(L.end());
+  }
 
   auto capture = [&](int index) -> int {
     if (!h->capture) return OP_OK;
@@ -469,6 +474,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       // ---- row-stationary path (hidden <= 256): three launches per layer ------------------------------
       if (li == 0) {  // layer 0 has no attn_norm: split x0 directly
         RowGemmParams rp = qkv_params(0);
+        if (embed_in_qkv0) {
+          rp.emb_table = h->emb;
+          rp.emb_ids = ids_dev;
+          rp.emb_vocab = h->V;
+          rp.row_tok = ws.row_tok;
+          rp.ln_w = h->emb_norm;
+          rp.x_io = ws.x;
+        }
         OP_TRY(L.begin(PK_ROW_QKV));
         if (!opl::launch_row_qkv0(st, rp, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
         OP_TRY(L.end());

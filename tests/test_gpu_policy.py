@@ -143,15 +143,16 @@ def test_layer32_kernel_matches_the_default_kernel(fixture, precision):
         assert np.abs(outs["m32"][1] - ref.ranking_logits.numpy()).max() < 1e-3
 
 
-NO_HEAD_FUSION = 256  # OP_FLAG_NO_HEAD_FUSION: final_norm + pruning head as their own launch
+NO_HEAD_FUSION = 256  # OP_FLAG_NO_HEAD_FUSION: embedding + LayerNorm and final_norm + pruning head as their own launches
 
 
 @pytest.mark.parametrize("fixture", ["g0b_hd64_refinit", "g0c_hd64_synth", "g1_xsmall", "g7_xsmall_refinit", "g12_prenorm_tf4"])
-def test_head_inside_the_last_layer_kernel(fixture):
-    """Without hidden-state capture and with CLS pooling the last whole-layer launch ends with final_norm + the pruning
-    head on the rows in its accumulators (no write-back of the residual stream, no final_ln_prune launch; the
-    transformers-4.x pre-norm convention of g12 included): same logits as the separate launch to fp32 noise, and
-    within the bar of the reference outputs."""
+def test_embedding_and_head_inside_the_first_and_last_kernels(fixture):
+    """Without hidden-state capture the layer-0 q / k / v kernel gathers and normalises the embeddings itself, and (CLS
+    pooling) the last whole-layer launch ends with final_norm + the pruning head on the rows in its accumulators (no
+    write-back of the residual stream, no embed_ln / final_ln_prune launches; the transformers-4.x pre-norm convention
+    of g12 included): same logits as the separate launches to fp32 noise carried through the layers, and within the
+    bar of the reference outputs."""
 
     from open_provence_amd.engine import HipEncoder
 
@@ -170,11 +171,12 @@ def test_head_inside_the_last_layer_kernel(fixture):
         kinds = set(enc.profile_read())
         assert "fused_layer_attnout_mlp_qkv" in kinds
         assert ("final_ln_prune" in kinds) == (label == "separate"), kinds
+        assert ("embed_ln" in kinds) == (label == "separate"), kinds
         outs[label] = (prune.cpu().numpy(), rank.cpu().numpy())
         enc.close()
     scale = max(1.0, float(np.abs(outs["separate"][0]).max()))
-    assert np.abs(outs["fused"][0] - outs["separate"][0]).max() < 2e-5 * scale
-    assert np.abs(outs["fused"][1] - outs["separate"][1]).max() < 2e-5 * scale
+    assert np.abs(outs["fused"][0] - outs["separate"][0]).max() < 3e-4 * scale
+    assert np.abs(outs["fused"][1] - outs["separate"][1]).max() < 3e-4 * scale
     # bf16 checkpoint + default policy against the reference outputs: the bar
     rep = run_fixture_on_gpu(fixture, "bf16x3", capture=False)
     if "refinit" in fixture:  # (the O(1)-weight fixtures need their fp32 lo planes: checked with capture in test_gpu_parity)
