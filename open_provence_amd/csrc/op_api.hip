@@ -329,12 +329,12 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   if (fp_layout) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
     const size_t tail_off = (size_t)(rows / 16) * (H / 32) * 2 * 512;
     const size_t tail_bytes = (size_t)((r_pad - rows) / 16) * (H / 32) * 2 * 512 * sizeof(u16);
-    OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
+    if (tail_bytes) OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));  // (a zero-byte node fails stream capture)
   } else {
     const size_t tail_off = (size_t)rows * H;
     const size_t tail_bytes = (size_t)(r_pad - rows) * H * sizeof(u16);
-    OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
-    if (split) OP_HIP(h, hipMemsetAsync(ws.o_lo + tail_off, 0, tail_bytes, st));
+    if (tail_bytes) OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
+    if (tail_bytes && split) OP_HIP(h, hipMemsetAsync(ws.o_lo + tail_off, 0, tail_bytes, st));
   }
 
   // Row path without hidden-state capture: the layer-0 q / k / v kernel gathers and normalises the embeddings itself
