@@ -103,9 +103,21 @@ class ShardPlan:
         ranking logits ``[B, nl]`` in the ORIGINAL row order: two index_select operations, no per-row loop."""
 
         flat = bucket.reshape(-1)
-        tok = flat[torch.from_numpy(self.token_index).to(flat.device)].reshape(-1, self.width)
-        rk = flat[torch.from_numpy(self.rank_index).to(flat.device)].reshape(len(self.lengths), self.num_labels)
+        tok_idx, rk_idx = self._device_indices(flat.device)
+        tok = flat[tok_idx].reshape(-1, self.width)
+        rk = flat[rk_idx].reshape(len(self.lengths), self.num_labels)
         return tok, rk
+
+    def _device_indices(self, device: torch.device) -> tuple[torch.Tensor, torch.Tensor]:
+        """The two index maps on ``device``, uploaded once per plan: at 8 ranks x 256 pairs x 512 tokens the token map
+        is 8 MB, and a pageable host-to-device copy of it inside every step would stall the root rank -- the rank whose
+        time the max-over-ranks measurement takes."""
+
+        cache = self.__dict__.setdefault("_index_cache", {})
+        key = str(device)
+        if key not in cache:
+            cache[key] = (torch.from_numpy(self.token_index).to(device), torch.from_numpy(self.rank_index).to(device))
+        return cache[key]
 
     def gather(
         self,
