@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256, 1) void layer32_kernel(Layer32Params p) {
       return s < KS ? (j * KS + s) * 1024 : (2 * KS + ((s - KS) >> 2) * NT + 2 * ((s - KS) & 3) + j) * 1024;
     }
   };
-  auto interleave = [&](int valu_per_mfma) {
-    (void)valu_per_mfma;
+  // one MFMA : up to four vector instructions of the step's slice (the 32x32x16 shape leaves room for 4-5, see the top)
+  auto interleave = [&]() {
 #pragma unroll
     for (int i = 0; i < (ALO ? 4 : 2); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void layer32_kernel(Layer32Params p) {
         acc1[T + 1] = mfma32(w1, h_hi[kk], acc1[T + 1]);
         copy_out(std::integral_constant<int, u>{});  // (the GeGLU of pair t-1 ended with step KS-1)
       }
-      interleave(0);
+      interleave();
     });
   };
   auto end_of_stage = [&]() {
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 1) void layer32_kernel(Layer32Params p) {
         qb[cur] = SW ? mfma32(w1, a_hi[s], (s == 0 && !ALO) ? zero : qb[cur]) : mfma32(a_hi[s], w1, (s == 0 && !ALO) ? zero : qb[cur]);
         if constexpr (!FIRST) {
           epilogue_slice(it - 1, swp_tag, step_tag, qa[cur ^ 1], qb[cur ^ 1]);
-          interleave(0);
+          interleave();
         }
       });
       if (!FIRST) epilogue_store(it - 1, swp_tag);
