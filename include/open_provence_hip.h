@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 2
+#define OP_ABI_VERSION 3 /* 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
