@@ -10,6 +10,12 @@ BASELINE.json configs[1]: open-provence-reranker-xsmall-v1 dims, 256 pairs x 512
 shared by all contexts, random-init weights (no network: no checkpoint, no dataset).  N > 1 is weak
 scaling: every rank processes its own 256 pairs (no data-path collective) and the per-pair outputs are
 gathered on rank 0 over RCCL inside the timed step.  Rank 0 prints ONE JSON line.
+
+On one GPU a step enqueues the batch as TWO independent launch sequences (the two halves of the pairs, each on its own
+HIP stream bound to one half of the CUs: ``HipEncoder.forward_packed_on``, ``--pipelines 1`` turns it off): +2.9 %
+pairs/s same-box, because the halves drift out of phase and one's memory phases fill the other's MFMA phases.  The
+same batch as one launch sequence is timed right after and reported as ``one_pipeline`` (that is what each rank of a
+multi-GPU run executes: a per-step gather re-aligns the halves and two sequences then lose 7 %).
 """
 
 from __future__ import annotations
@@ -139,6 +145,10 @@ def main() -> None:
     parser.add_argument("--no-long", action="store_true", help="skip the seq_len 2048 sub-record")
     parser.add_argument("--varlen", action="store_true",
                         help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
+    parser.add_argument("--pipelines", type=int, default=2, choices=[1, 2],
+                        help="single GPU: the batch as this many independent launch sequences (each on its own HIP stream and "
+                        "its own half of the CUs; 2 = HipEncoder.forward_packed_on).  Multi-GPU runs and the per-kernel "
+                        "profile use one")
     parser.add_argument("--exercise-gather", action="store_true",
                         help="test hook: run the N > 1 code path (process group, ShardPlan, gather, MAX all-reduce) on a "
                         "one-rank RCCL group, so that it is executed on hardware even where only one GPU is granted")
@@ -196,13 +206,38 @@ def main() -> None:
     cu = torch.from_numpy(cu_np).to(device)
     total_tokens = int(cu_np[-1])
 
+    # Single GPU: the batch runs as two independent launch sequences (contiguous halves of the pairs, each on its own
+    # stream and its own half of the CUs -- HipEncoder.forward_packed_on explains why); a step enqueues both halves.
+    # With a per-step gather behind them (N > 1) the halves re-align every step and two sequences LOSE 7 % (measured
+    # on a one-rank RCCL group): multi-GPU runs keep one sequence per GPU, and the N = 1 line also carries the
+    # one-sequence figure (`one_pipeline`) for like-for-like scaling arithmetic.
+    n_pipes = args.pipelines if (not grouped and not args.varlen and len(rows) >= 2) else 1
     keep_dev = torch.empty(total_tokens, dtype=torch.float32, device=device)
+    pipes = []
+    if n_pipes == 2:
+        half = len(rows) // 2
+        lo = 0
+        for part, part_rows in enumerate((rows[:half], rows[half:])):
+            p_ids_np, p_cu_np, p_max = pack_rows(part_rows)
+            n_tok = int(p_cu_np[-1])
+            pipes.append((part, torch.from_numpy(p_ids_np).to(device), torch.from_numpy(p_cu_np).to(device), p_cu_np, p_max,
+                          keep_dev[lo : lo + n_tok]))
+            lo += n_tok
+        torch.cuda.synchronize(device)
 
-    def step():
+    def step_one():
         prune, rank_logits = encoder.forward_packed(ids, cu, cu_np, max_len, keep_prob=keep_dev)
         if plan is not None:  # the exchange step of the path: ShardPlan.gather (open_provence_amd/sharding.py)
             plan.gather(keep_dev, rank_logits, dst=0)
         return prune, rank_logits
+
+    def step():
+        if not pipes:
+            return step_one()
+        out = None
+        for part, p_ids, p_cu, p_cu_np, p_max, p_keep in pipes:
+            out = encoder.forward_packed_on(part, p_ids, p_cu, p_cu_np, p_max, keep_prob=p_keep)
+        return out
 
     def fence():
         if grouped:
@@ -214,11 +249,12 @@ def main() -> None:
     fence()
     # per-step device times from events on the launch stream (the library enqueues on torch's current stream)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    mark_stream = encoder.pipeline_stream(1) if pipes else torch.cuda.current_stream(device)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        marks[i].record()
+        marks[i].record(mark_stream)
         out = step()
-    marks[args.steps].record()
+    marks[args.steps].record(mark_stream)
     fence()
     elapsed = time.perf_counter() - t0
     step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
@@ -227,7 +263,6 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(out[0]).all().item() and torch.isfinite(out[1]).all().item())
-
     # per-kernel HIP-event timing on the launch stream (separate, un-timed passes)
     encoder.profile_enable(True)
     encoder.profile_reset()
@@ -236,6 +271,19 @@ def main() -> None:
         encoder.forward_packed(ids, cu, cu_np, max_len)
     profile = encoder.profile_read()
     encoder.profile_enable(False)
+
+    one_pipeline = None
+    if pipes:  # the same batch as ONE launch sequence on the whole chip (what every rank of a multi-GPU run does)
+        for _ in range(args.warmup):
+            step_one()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_one()
+        torch.cuda.synchronize(device)
+        dt1 = (time.perf_counter() - t1) / args.steps
+        one_pipeline = {"value": n_pairs_rank / dt1, "unit": "pairs/s", "ms_per_step": dt1 * 1e3, "steps": args.steps}
+
 
     if rank != 0:
         dist.destroy_process_group()
@@ -347,15 +395,18 @@ def main() -> None:
             "precision": args.precision,
             "checkpoint_dtype": args.weights,
             "policy": policy,  # term masks evaluated per contraction family + the kernel set running them
-            "parallelism": f"dp{world} (pairs sharded, RCCL gather of per-pair outputs)" if world > 1 else "single GPU",
+            "parallelism": f"dp{world} (pairs sharded, RCCL gather of per-pair outputs)" if world > 1
+            else ("single GPU, two independent half-batch launch sequences on CU-partitioned streams" if pipes else "single GPU"),
             "algorithmic_gflop_per_pair": flops_pair / 1e9,
             "outputs_finite": finite,
         },
         "roofline": roofline,
         "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in profile.items()},
     }
+    if one_pipeline is not None:
+        line["one_pipeline"] = one_pipeline
     line["step_ms"] = {"median": float(np.median(step_ms)), "p10": float(np.percentile(step_ms, 10)),
-                       "p90": float(np.percentile(step_ms, 90)), "source": "HIP events on the launch stream, rank 0"}
+                       "p90": float(np.percentile(step_ms, 90)), "source": "HIP events on the launch stream" + (" of the second half-batch" if pipes else "") + ", rank 0"}
     if world == 1 and not args.varlen and args.seq_len != 2048 and not args.no_long:
         # north_star also asks for seq_len 2048: same model, same token count per step (sub-record, not the headline)
         long_pairs = max(1, args.pairs * args.seq_len // 2048)

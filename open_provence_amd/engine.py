@@ -131,6 +131,8 @@ class HipEncoder:
         code = self.lib.op_create(ctypes.byref(cfg), ctypes.byref(handle))
         _lib.check(self.lib, None, code, "op_create")
         self._handle = handle
+        self._split_state: dict | None = None  # CU-partitioned streams + their workspaces (forward_packed_on)
+        self._profiling = False
         self._workspace: torch.Tensor | None = None
         self._capture: torch.Tensor | None = None
         self._capture_result: torch.Tensor | None = None
@@ -255,9 +257,6 @@ class HipEncoder:
         if n_seqs == 0:
             return prune, rank
         ws = self._ensure_workspace(n_seqs, total, int(max_seqlen))
-        base = ws.data_ptr()
-        aligned = (base + 255) // 256 * 256
-        capture_ptr = None
         if self._capture is not None:
             self._capture = torch.zeros(
                 (self.dims.num_layers + 1, total, self.dims.hidden_size), dtype=torch.float32, device=self.device
@@ -266,23 +265,98 @@ class HipEncoder:
             _lib.check(self.lib, self._handle, self.lib.op_debug_capture_hidden(self._handle, capture_ptr), "capture")
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            code = self.lib.op_forward_packed(
-                self._handle,
-                ctypes.c_void_p(ids.data_ptr()),
-                ctypes.c_void_p(cu_seqlens.data_ptr()),
-                cu_host.ctypes.data_as(ctypes.c_void_p),
-                n_seqs,
-                total,
-                int(max_seqlen),
-                ctypes.c_void_p(prune.data_ptr()),
-                ctypes.c_void_p(rank.data_ptr()),
-                ctypes.c_void_p(keep_prob.data_ptr()) if keep_prob is not None else None,
-                ctypes.c_void_p(aligned),
-                ctypes.c_size_t(ws.numel() - (aligned - base)),
-                ctypes.c_void_p(stream),
-            )
-        _lib.check(self.lib, self._handle, code, "op_forward_packed")
+            self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, int(max_seqlen),
+                                 prune.data_ptr(), rank.data_ptr(), keep_prob.data_ptr() if keep_prob is not None else None,
+                                 ws, stream)
         return prune, rank
+
+    def _forward_native(self, ids_ptr, cu_ptr, cu_host: np.ndarray, n_seqs: int, total: int, max_seqlen: int,
+                        prune_ptr, rank_ptr, keep_ptr, ws: torch.Tensor, stream: int) -> None:
+        base = ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        code = self.lib.op_forward_packed(
+            self._handle,
+            ctypes.c_void_p(ids_ptr),
+            ctypes.c_void_p(cu_ptr),
+            cu_host.ctypes.data_as(ctypes.c_void_p),
+            n_seqs,
+            total,
+            max_seqlen,
+            ctypes.c_void_p(prune_ptr),
+            ctypes.c_void_p(rank_ptr),
+            ctypes.c_void_p(keep_ptr) if keep_ptr is not None else None,
+            ctypes.c_void_p(aligned),
+            ctypes.c_size_t(ws.numel() - (aligned - base)),
+            ctypes.c_void_p(stream),
+        )
+        _lib.check(self.lib, self._handle, code, "op_forward_packed")
+
+    def _split_streams(self) -> dict:
+        """Two HIP streams bound to disjoint halves of the device's CUs (hipExtStreamCreateWithCUMask; plain streams if
+        the runtime refuses) and a workspace per half, created once."""
+
+        st = self._split_state
+        if st is None:
+            n_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+            streams = []
+            try:
+                hip = ctypes.CDLL("libamdhip64.so")
+                words = (n_cus + 31) // 32
+                with torch.cuda.device(self.device):
+                    for half in range(2):
+                        bits = [(c * 2 // n_cus) == half for c in range(n_cus)]
+                        mask = (ctypes.c_uint32 * words)(
+                            *[sum(1 << b for b in range(32) if w * 32 + b < n_cus and bits[w * 32 + b]) for w in range(words)]
+                        )
+                        handle = ctypes.c_void_p()
+                        if hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask) != 0:
+                            raise OSError("hipExtStreamCreateWithCUMask failed")
+                        streams.append(torch.cuda.ExternalStream(handle.value, device=self.device))
+            except (OSError, AttributeError):
+                streams = [torch.cuda.Stream(self.device) for _ in range(2)]
+            st = self._split_state = {"streams": streams, "ws": [None, None]}
+        return st
+
+    def forward_packed_on(
+        self,
+        part: int,
+        ids: torch.Tensor,
+        cu_seqlens: torch.Tensor,
+        cu_seqlens_host: np.ndarray,
+        max_seqlen: int,
+        keep_prob: torch.Tensor | None = None,
+    ) -> tuple[torch.Tensor, torch.Tensor]:
+        """``forward_packed`` enqueued on pipeline ``part`` (0 or 1): its own HIP stream, bound to one half of the
+        device's CUs, and its own workspace -- nothing is ordered against the caller's current stream or the other
+        pipeline (inputs must already be resident; wait on ``pipeline_stream(part)`` before reading the outputs).
+
+        Why two pipelines: every CU of a launch is in the same phase at the same time -- all fetch, then all multiply
+        -- so HBM idles while the matrix pipes work and vice versa; two INDEPENDENT launch sequences on disjoint CUs
+        drift apart and fill each other's gaps (xsmall, 2 x 128 pairs x 512 against 1 x 256: +3 % pairs/s, same box).
+        Forking and joining the halves inside every forward instead re-aligns them each time and loses 4 %."""
+
+        if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
+            raise TypeError("ids and cu_seqlens must be int32")
+        total, n_seqs = int(ids.numel()), int(cu_seqlens.numel()) - 1
+        cu_host = np.ascontiguousarray(cu_seqlens_host, dtype=np.int32)
+        st = self._split_streams()
+        side = st["streams"][part]
+        with torch.cuda.device(self.device), torch.cuda.stream(side):
+            prune = torch.empty((total, 2), dtype=torch.float32, device=self.device)
+            rank = torch.empty((n_seqs, self.dims.num_labels), dtype=torch.float32, device=self.device)
+            if n_seqs == 0:
+                return prune, rank
+            need = int(self.lib.op_workspace_bytes(self._handle, n_seqs, total, int(max_seqlen)))
+            ws = st["ws"][part]
+            if ws is None or ws.numel() < need + 256:
+                ws = st["ws"][part] = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, int(max_seqlen),
+                                 prune.data_ptr(), rank.data_ptr(), keep_prob.data_ptr() if keep_prob is not None else None,
+                                 ws, side.cuda_stream)
+        return prune, rank
+
+    def pipeline_stream(self, part: int) -> torch.cuda.Stream:
+        return self._split_streams()["streams"][part]
 
     def check_ids(self, ids: np.ndarray) -> None:
         """``nn.Embedding`` raises on out-of-range ids (the reference's behaviour); the kernel only clamps them as a
@@ -323,6 +397,7 @@ class HipEncoder:
 
     def profile_enable(self, enabled: bool) -> None:
         _lib.check(self.lib, self._handle, self.lib.op_profile_enable(self._handle, 1 if enabled else 0), "profile")
+        self._profiling = bool(enabled)  # (per-kernel events time whole-chip launches: no stream split while they are on)
 
     def profile_reset(self) -> None:
         _lib.check(self.lib, self._handle, self.lib.op_profile_reset(self._handle), "profile_reset")

@@ -3,7 +3,7 @@
 import json
 import sys
 
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+d = json.loads([line for line in sys.stdin.read().strip().splitlines() if line.startswith("{")][-1])  # (RCCL prints after it)
 r = d.get("roofline") or {}
 print(
     f"{d['config']['precision'].split()[0]:7s} {d['value']:9.0f} pairs/s {d['ms_per_step']:7.2f} ms | dominant {r.get('kernel')} "

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--parts", type=int, default=2)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--model", default="xsmall")
+    ap.add_argument("--cu-mask", default="", help="'alt': stream i gets the CUs with index % parts == i; 'half': contiguous "
+                    "ranges of CUs (hipExtStreamCreateWithCUMask): the parts then run on disjoint CUs, truly side by side")
+    ap.add_argument("--n-cus", type=int, default=256)
     args = ap.parse_args()
     dims = named_dims(args.model)
     state = synth_state_dict(dims, seed=7)
@@ -40,7 +43,22 @@ def main():
     full = prepare(rows)
     n = len(rows) // args.parts
     parts = [prepare(rows[i * n : (i + 1) * n]) for i in range(args.parts)]
-    streams = [torch.cuda.Stream(dev) for _ in range(args.parts)]
+    if args.cu_mask:
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")
+        words = (args.n_cus + 31) // 32
+        streams, keep = [], []
+        for i in range(args.parts):
+            bits = [(c % args.parts == i) if args.cu_mask == "alt" else (c * args.parts // args.n_cus == i) for c in range(args.n_cus)]
+            mask = (ctypes.c_uint32 * words)(*[sum(1 << b for b in range(32) if w * 32 + b < args.n_cus and bits[w * 32 + b]) for w in range(words)])
+            handle = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
+            assert rc == 0, f"hipExtStreamCreateWithCUMask failed: {rc}"
+            keep.append(mask)
+            streams.append(torch.cuda.ExternalStream(handle.value, device=dev))
+    else:
+        streams = [torch.cuda.Stream(dev) for _ in range(args.parts)]
 
     def run_full():
         enc, ids, cu, cu_np, ml = full
