@@ -11,8 +11,11 @@
  *   - every function returns OP_OK (0) or a negative OP_ERR_* code and never throws;
  *     the message is available from op_last_error(handle) (or op_last_error(NULL) when no
  *     handle exists yet);
- *   - one handle per device; calls on one handle must be serialised by the caller; the forward is
- *     asynchronous with respect to the given HIP stream;
+ *   - one handle per device; calls on one handle must be serialised by the caller (host side); the
+ *     forward is asynchronous with respect to the given HIP stream, and forwards enqueued on DIFFERENT
+ *     streams with DIFFERENT workspaces may run side by side on the device (the weights are read-only;
+ *     profiling and hidden-state capture off) -- HipEncoder.forward_packed_on does that on two streams
+ *     bound to disjoint halves of the CUs;
  *   - the caller owns every I/O buffer and the workspace; the library owns only its re-packed weights.
  */
 #ifndef OPEN_PROVENCE_HIP_H
