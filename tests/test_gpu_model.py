@@ -577,3 +577,43 @@ def test_segment_means_equal_numpy_mean_bit_for_bit():
         want = 1.0 if e <= s else float(values[s:e].mean())
         assert float(got) == want, (s, e, float(got), want)
     enc.close()
+
+
+def test_two_launch_sequences_give_the_single_sequence_bits():
+    """``forward_packed_on``: the two halves of a batch enqueued on the two CU-partitioned streams (independent launch
+    sequences, own workspaces, nothing ordered between them) produce, pair for pair, exactly the outputs of one
+    ``forward_packed`` over the whole batch -- also when both pipelines are re-used back to back."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.packing import pack_rows
+    from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict
+
+    dims = named_dims("xsmall")
+    state = synth_state_dict(dims, seed=7)
+    state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3")
+    enc.load_state_dict(state)
+    rows = synth_pair_batch(dims, 24, 160, seed=5) + synth_pair_batch(dims, 8, 512, seed=6)
+    ids_np, cu_np, max_len = pack_rows(rows)
+    dev = torch.device("cuda:0")
+    keep = torch.empty(int(cu_np[-1]), dtype=torch.float32, device=dev)
+    prune, rank = enc.forward_packed(torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev), cu_np, max_len, keep_prob=keep)
+    torch.cuda.synchronize()
+    want = (prune.cpu().numpy(), rank.cpu().numpy(), keep.cpu().numpy())
+    half = len(rows) // 2
+    for _ in range(2):  # second round: workspaces and streams re-used
+        got_p, got_r, got_k = [], [], []
+        outs = []
+        for part, part_rows in enumerate((rows[:half], rows[half:])):
+            p_ids, p_cu, p_max = pack_rows(part_rows)
+            p_keep = torch.empty(int(p_cu[-1]), dtype=torch.float32, device=dev)
+            ids_d, cu_d = torch.from_numpy(p_ids).to(dev), torch.from_numpy(p_cu).to(dev)
+            torch.cuda.synchronize()  # inputs resident before the pipeline's stream touches them
+            outs.append((enc.forward_packed_on(part, ids_d, cu_d, p_cu, p_max, keep_prob=p_keep), p_keep, ids_d, cu_d))
+        torch.cuda.synchronize()
+        for (p, r), k, _, _ in outs:
+            got_p.append(p.cpu().numpy()); got_r.append(r.cpu().numpy()); got_k.append(k.cpu().numpy())
+        assert np.array_equal(np.concatenate(got_p), want[0])
+        assert np.array_equal(np.concatenate(got_r), want[1])
+        assert np.array_equal(np.concatenate(got_k), want[2])
+    enc.close()
