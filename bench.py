@@ -145,10 +145,12 @@ def main() -> None:
     parser.add_argument("--no-long", action="store_true", help="skip the seq_len 2048 sub-record")
     parser.add_argument("--varlen", action="store_true",
                         help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
-    parser.add_argument("--pipelines", type=int, default=2, choices=[1, 2],
+    parser.add_argument("--pipelines", type=int, default=0, choices=[0, 1, 2],
                         help="single GPU: the batch as this many independent launch sequences (each on its own HIP stream and "
-                        "its own half of the CUs; 2 = HipEncoder.forward_packed_on).  Multi-GPU runs and the per-kernel "
-                        "profile use one")
+                        "its own half of the CUs; 2 = HipEncoder.forward_packed_on).  0 = automatic: two for the "
+                        "row-stationary models (hidden <= 256: +3 %), one for the panel-path models (base / large / "
+                        "en-gte: two measure -0.7 %, their XCD-aware block maps assume all eight XCDs).  Multi-GPU runs "
+                        "and the per-kernel profile use one")
     parser.add_argument("--exercise-gather", action="store_true",
                         help="test hook: run the N > 1 code path (process group, ShardPlan, gather, MAX all-reduce) on a "
                         "one-rank RCCL group, so that it is executed on hardware even where only one GPU is granted")
@@ -211,7 +213,8 @@ def main() -> None:
     # With a per-step gather behind them (N > 1) the halves re-align every step and two sequences LOSE 7 % (measured
     # on a one-rank RCCL group): multi-GPU runs keep one sequence per GPU, and the N = 1 line also carries the
     # one-sequence figure (`one_pipeline`) for like-for-like scaling arithmetic.
-    n_pipes = args.pipelines if (not grouped and not args.varlen and len(rows) >= 2) else 1
+    want_pipes = args.pipelines or (2 if dims.hidden_size <= 256 else 1)
+    n_pipes = want_pipes if (not grouped and not args.varlen and len(rows) >= 2) else 1
     keep_dev = torch.empty(total_tokens, dtype=torch.float32, device=device)
     pipes = []
     if n_pipes == 2:
