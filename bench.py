@@ -369,6 +369,10 @@ def main() -> None:
             "algorithmic_flops_per_launch": flops_per_launch,
             "whole_forward_tflops": whole_tflops,
             "whole_forward_frac": whole_tflops / BF16_MFMA_PEAK_TFLOPS,
+            # per-kernel figures (achieved, avg_launch_ms, traffic) are those of a launch over the whole batch on the whole
+            # chip -- the form rocprofv3 sees and every rank of a multi-GPU run executes; `value` may come from two
+            # half-batch launch sequences side by side (config.parallelism), whose launches each use half the CUs
+            "measured_as": "one launch sequence over the whole batch (HIP events around each launch, separate pass)",
         }
 
     line = {
