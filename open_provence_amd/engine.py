@@ -132,7 +132,6 @@ class HipEncoder:
         _lib.check(self.lib, None, code, "op_create")
         self._handle = handle
         self._split_state: dict | None = None  # CU-partitioned streams + their workspaces (forward_packed_on)
-        self._profiling = False
         self._workspace: torch.Tensor | None = None
         self._capture: torch.Tensor | None = None
         self._capture_result: torch.Tensor | None = None
@@ -397,7 +396,6 @@ class HipEncoder:
 
     def profile_enable(self, enabled: bool) -> None:
         _lib.check(self.lib, self._handle, self.lib.op_profile_enable(self._handle, 1 if enabled else 0), "profile")
-        self._profiling = bool(enabled)  # (per-kernel events time whole-chip launches: no stream split while they are on)
 
     def profile_reset(self) -> None:
         _lib.check(self.lib, self._handle, self.lib.op_profile_reset(self._handle), "profile_reset")
