@@ -33,6 +33,9 @@ def test_bench_json_line_contract():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 1e-6
+    # single GPU, row-stationary model: the batch ran as two launch sequences, and the one-sequence figure is beside it
+    assert "two independent" in line["config"]["parallelism"]
+    assert line["one_pipeline"]["value"] > 0 and line["one_pipeline"]["unit"] == "pairs/s"
 
 
 @pytest.mark.gpu
@@ -51,3 +54,4 @@ def test_bench_multi_gpu_code_path_on_a_one_rank_group():
     line = json.loads(lines[0])
     assert REQUIRED <= set(line)
     assert line["n_gpus"] == 1 and line["config"]["outputs_finite"] is True and line["value"] > 0
+    assert "one_pipeline" not in line  # a rank of a multi-GPU run executes one launch sequence
