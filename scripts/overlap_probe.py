@@ -50,7 +50,12 @@ def main():
         words = (args.n_cus + 31) // 32
         streams, keep = [], []
         for i in range(args.parts):
-            bits = [(c % args.parts == i) if args.cu_mask == "alt" else (c * args.parts // args.n_cus == i) for c in range(args.n_cus)]
+            if args.cu_mask == "alt":
+                bits = [c % args.parts == i for c in range(args.n_cus)]
+            elif args.cu_mask == "xcd-alt":  # 32 mask bits per XCD (assumed): every other XCD
+                bits = [(c // 32) % args.parts == i for c in range(args.n_cus)]
+            else:
+                bits = [c * args.parts // args.n_cus == i for c in range(args.n_cus)]
             mask = (ctypes.c_uint32 * words)(*[sum(1 << b for b in range(32) if w * 32 + b < args.n_cus and bits[w * 32 + b]) for w in range(words)])
             handle = ctypes.c_void_p()
             rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
