@@ -14,8 +14,9 @@ gathered on rank 0 over RCCL inside the timed step.  Rank 0 prints ONE JSON line
 On one GPU a step enqueues the batch as TWO independent launch sequences (the two halves of the pairs, each on its own
 HIP stream bound to one half of the CUs: ``HipEncoder.forward_packed_on``, ``--pipelines 1`` turns it off): +2.9 %
 pairs/s same-box, because the halves drift out of phase and one's memory phases fill the other's MFMA phases.  The
-same batch as one launch sequence is timed right after and reported as ``one_pipeline`` (that is what each rank of a
-multi-GPU run executes: a per-step gather re-aligns the halves and two sequences then lose 7 %).
+same batch as one launch sequence is timed right after and reported as ``one_pipeline``.  The ranks of a multi-GPU run
+do the same, each sequence followed on its own stream by the gather of its own half of the pairs (``ShardPlan.split``):
+one gather behind both sequences re-aligns them every step and loses 7 %.
 """
 
 from __future__ import annotations
@@ -149,8 +150,8 @@ def main() -> None:
                         help="single GPU: the batch as this many independent launch sequences (each on its own HIP stream and "
                         "its own half of the CUs; 2 = HipEncoder.forward_packed_on).  0 = automatic: two for the "
                         "row-stationary models (hidden <= 256: +3 %), one for the panel-path models (base / large / "
-                        "en-gte: two measure -0.7 %, their XCD-aware block maps assume all eight XCDs).  Multi-GPU runs "
-                        "and the per-kernel profile use one")
+                        "en-gte: two measure -0.7 %, their XCD-aware block maps assume all eight XCDs).  The per-kernel "
+                        "profile uses one")
     parser.add_argument("--exercise-gather", action="store_true",
                         help="test hook: run the N > 1 code path (process group, ShardPlan, gather, MAX all-reduce) on a "
                         "one-rank RCCL group, so that it is executed on hardware even where only one GPU is granted")
@@ -208,24 +209,28 @@ def main() -> None:
     cu = torch.from_numpy(cu_np).to(device)
     total_tokens = int(cu_np[-1])
 
-    # Single GPU: the batch runs as two independent launch sequences (contiguous halves of the pairs, each on its own
-    # stream and its own half of the CUs -- HipEncoder.forward_packed_on explains why); a step enqueues both halves.
-    # With a per-step gather behind them (N > 1) the halves re-align every step and two sequences LOSE 7 % (measured
-    # on a one-rank RCCL group): multi-GPU runs keep one sequence per GPU, and the N = 1 line also carries the
-    # one-sequence figure (`one_pipeline`) for like-for-like scaling arithmetic.
+    # The rank's pairs run as two independent launch sequences (contiguous halves, each on its own stream and its own
+    # half of the CUs -- HipEncoder.forward_packed_on explains why); a step enqueues both halves.  With more than one
+    # rank each sequence is followed, on ITS stream, by the gather of its own half (ShardPlan.split: the same cut on
+    # every rank, one plan per half), so the sequences never wait for each other: one gather behind both re-aligns
+    # them every step and loses 7 %, one behind each keeps +1.9 % of the +2.9 % (measured on a one-rank RCCL group).
+    # The plain single-GPU line also carries the one-sequence figure (`one_pipeline`).
     want_pipes = args.pipelines or (2 if dims.hidden_size <= 256 else 1)
-    n_pipes = want_pipes if (not grouped and not args.varlen and len(rows) >= 2) else 1
+    n_pipes = want_pipes if (not args.varlen and len(rows) >= 2) else 1
     keep_dev = torch.empty(total_tokens, dtype=torch.float32, device=device)
     pipes = []
     if n_pipes == 2:
-        half = len(rows) // 2
-        lo = 0
-        for part, part_rows in enumerate((rows[:half], rows[half:])):
+        if plan is not None:
+            halves = []
+            for plan_j, rows_j in plan.split(2):
+                halves.append(([rows_all[rows_j[k]] for k in plan_j.local_rows(rank)], plan_j))
+        else:
+            half = len(rows) // 2
+            halves = [(rows[:half], None), (rows[half:], None)]
+        for part, (part_rows, part_plan) in enumerate(halves):
             p_ids_np, p_cu_np, p_max = pack_rows(part_rows)
-            n_tok = int(p_cu_np[-1])
             pipes.append((part, torch.from_numpy(p_ids_np).to(device), torch.from_numpy(p_cu_np).to(device), p_cu_np, p_max,
-                          keep_dev[lo : lo + n_tok]))
-            lo += n_tok
+                          torch.empty(int(p_cu_np[-1]), dtype=torch.float32, device=device), part_plan))
         torch.cuda.synchronize(device)
 
     def step_one():
@@ -238,8 +243,11 @@ def main() -> None:
         if not pipes:
             return step_one()
         out = None
-        for part, p_ids, p_cu, p_cu_np, p_max, p_keep in pipes:
+        for part, p_ids, p_cu, p_cu_np, p_max, p_keep, part_plan in pipes:
             out = encoder.forward_packed_on(part, p_ids, p_cu, p_cu_np, p_max, keep_prob=p_keep)
+            if part_plan is not None:
+                with torch.cuda.stream(encoder.pipeline_stream(part)):
+                    part_plan.gather(p_keep, out[1], dst=0)
         return out
 
     def fence():
@@ -276,7 +284,7 @@ def main() -> None:
     encoder.profile_enable(False)
 
     one_pipeline = None
-    if pipes:  # the same batch as ONE launch sequence on the whole chip (what every rank of a multi-GPU run does)
+    if pipes and not grouped:  # the same batch as ONE launch sequence on the whole chip
         for _ in range(args.warmup):
             step_one()
         torch.cuda.synchronize(device)

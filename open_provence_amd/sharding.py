@@ -54,12 +54,19 @@ class ShardPlan:
     logits, fp32.  ``width`` is 1 for keep-probabilities (4 B per token: what ``process()`` ships) or 2 for the raw
     pruning logits."""
 
-    def __init__(self, lengths: Sequence[int], world_size: int, *, width: int = 1, num_labels: int = 1) -> None:
+    def __init__(self, lengths: Sequence[int], world_size: int, *, width: int = 1, num_labels: int = 1,
+                 shards: Sequence[Sequence[int]] | None = None) -> None:
         self.lengths = np.asarray([int(n) for n in lengths], dtype=np.int64)
         self.world_size = int(world_size)
         self.width = int(width)
         self.num_labels = int(num_labels)
-        self.shards = partition_rows(self.lengths.tolist(), self.world_size)
+        if shards is None:
+            self.shards = partition_rows(self.lengths.tolist(), self.world_size)
+        else:  # a given assignment (every rank must pass the same one): e.g. one half of each rank's rows, see split()
+            self.shards = [sorted(int(i) for i in s) for s in shards]
+            seen = sorted(i for s in self.shards for i in s)
+            if len(self.shards) != self.world_size or seen != list(range(len(self.lengths))):
+                raise ValueError("shards must assign every row to exactly one of world_size ranks")
         self.tokens = [int(self.lengths[s].sum()) if s else 0 for s in self.shards]
         self.rows = [len(s) for s in self.shards]
         self.max_tokens = max(self.tokens + [1])
@@ -86,6 +93,26 @@ class ShardPlan:
 
     def local_rows(self, rank: int) -> list[int]:
         return self.shards[rank]
+
+    def split(self, parts: int = 2) -> list[tuple["ShardPlan", list[int]]]:
+        """This plan cut into ``parts`` plans over disjoint subsets of the rows: part ``j`` takes the ``j``-th contiguous
+        slice of EVERY rank's rows (equal row counts up to one).  Returns ``(plan_j, rows_j)`` pairs -- ``rows_j`` = the
+        part's rows as indices into this plan's rows, ascending; ``plan_j`` indexes into ``rows_j``.  A rank that runs its
+        rows as ``parts`` independent launch sequences gathers each part with its own plan, so no sequence ever waits
+        for another (bench.py)."""
+
+        out = []
+        for j in range(parts):
+            per_rank = []
+            for shard in self.shards:
+                n = len(shard)
+                per_rank.append(shard[n * j // parts : n * (j + 1) // parts])
+            rows_j = sorted(i for s in per_rank for i in s)
+            pos = {row: k for k, row in enumerate(rows_j)}
+            plan_j = ShardPlan(self.lengths[rows_j].tolist() if rows_j else [], self.world_size, width=self.width,
+                               num_labels=self.num_labels, shards=[[pos[i] for i in s] for s in per_rank])
+            out.append((plan_j, rows_j))
+        return out
 
     def pack(self, rank: int, values: torch.Tensor, rank_logits: torch.Tensor) -> torch.Tensor:
         """This rank's payload (on the tensors' device)."""

@@ -143,3 +143,47 @@ def test_process_sharded_over_two_gloo_ranks_matches_golden(tmp_path):
     assert len(results) == len(meta["cases"])
     for res, case in zip(results, meta["cases"]):
         assert_process_result_matches(res, case["expected"], prob_tol=1e-6, score_tol=1e-6)
+
+
+def _split_worker(rank, world, port, lengths, out_path):
+    from open_provence_amd.sharding import ShardPlan
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = ShardPlan(lengths, world, width=1, num_labels=1)
+        got = {}
+        for j, (plan_j, rows_j) in enumerate(plan.split(2)):  # the order bench.py issues them in: part 0, then part 1
+            mine = [rows_j[k] for k in plan_j.local_rows(rank)]
+            assert set(mine) <= set(plan.local_rows(rank))
+            values = torch.cat([torch.arange(lengths[i], dtype=torch.float32) + 1000.0 * i for i in mine]) if mine else torch.zeros(0)
+            ranks = torch.tensor([[float(i)] for i in mine], dtype=torch.float32).reshape(len(mine), 1)
+            out = plan_j.gather(values, ranks, dst=0)
+            if rank == 0:
+                got[j] = (rows_j, out[0].reshape(-1), out[1].reshape(-1))
+            else:
+                assert out is None
+        if rank == 0:
+            torch.save(got, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_plans_gather_each_half_in_row_order(tmp_path, world):
+    """ShardPlan.split: every rank's rows cut in two, one plan per half (what a rank running two launch sequences
+    gathers with) -- the halves partition the rows, each rank's share of a half is a slice of its own rows, and each
+    half's gather returns its rows' values in ascending row order."""
+
+    rng = np.random.default_rng(5)
+    lengths = rng.integers(1, 30, size=23).tolist()
+    out_path = str(tmp_path / "split.pt")
+    mp.spawn(_split_worker, args=(world, _free_port(), lengths, out_path), nprocs=world, join=True)
+    got = torch.load(out_path)
+    assert sorted(i for j in got for i in got[j][0]) == list(range(23))
+    for j in got:
+        rows_j, tok, rk = got[j]
+        want = torch.cat([torch.arange(lengths[i], dtype=torch.float32) + 1000.0 * i for i in rows_j])
+        assert torch.equal(tok, want) and torch.equal(rk, torch.tensor([float(i) for i in rows_j]))
