@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 3 /* 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
+#define OP_ABI_VERSION 4 /* 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
@@ -83,7 +83,8 @@ enum op_flags {
   OP_FLAG_NO_LAYER_FUSION = 32,   /* two fused kernels per layer instead of the whole-layer kernel (A/B hook) */
   OP_FLAG_LAYER_8X16 = 64,        /* whole-layer kernel as 8 waves x 16 rows (two waves per SIMD) (A/B hook)   */
   OP_FLAG_NO_HEAD_FUSION = 256,   /* embedding + LayerNorm and final_norm + pruning head as their own launches on the row path too (A/B hook) */
-  OP_FLAG_LAYER_M32 = 128         /* whole-layer kernel on 32x32x16 MFMAs (hidden = 256): fewer cycles, more power per flop -- slower under the power limit (A/B hook) */
+  OP_FLAG_LAYER_M32 = 128,        /* whole-layer kernel on 32x32x16 MFMAs (hidden = 256): fewer cycles, more power per flop -- slower under the power limit (A/B hook) */
+  OP_FLAG_NO_F8 = 512             /* never select kernel set 3 (fp16 hi + e4m3 lo operands in the whole-layer kernel): keep the (hi, lo) bf16 kernel sets (A/B and bit-identity test hook) */
 };
 
 enum op_pooling { OP_POOL_CLS = 0, OP_POOL_MEAN = 1 };
@@ -144,8 +145,11 @@ size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int 
 /* After op_weights_ready: the term masks actually evaluated (requested policy minus the weight-lo
  * terms that are identically zero for this checkpoint), terms_out[OP_FAM_COUNT], and *kernel_set =
  * index of the curated kernel set that implements them with exactly those MFMA passes (0 = all
- * terms, 1 = bf16 weights, 2 = single pass), or -1 when the policy runs on the all-terms kernels
- * with cleared lo operands (same numerics, no speed-up). */
+ * terms, 1 = bf16 weights, 2 = single pass, 3 = the terms of 1 with the whole-layer kernel's
+ * operands carried as fp16 hi + e4m3 lo -- 1.5 instead of 2 MFMA units per product, selected for
+ * hidden <= 256 when every GEMM weight is exactly an fp16 value and OP_FLAG_NO_F8 is clear), or -1
+ * when the policy runs on the all-terms kernels with cleared lo operands (same numerics, no
+ * speed-up). */
 int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set);
 
 /* Replaces: OpenProvenceModel.forward (standalone.py:1666-1739) = HF

@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 
 OP_MAX_LAYERS = 128
-OP_ABI_VERSION = 3
+OP_ABI_VERSION = 4
 
 OP_OK = 0
 OP_DTYPE_F32, OP_DTYPE_BF16, OP_DTYPE_F16 = 0, 1, 2
@@ -25,6 +25,7 @@ OP_FLAG_NO_LAYER_FUSION = 32
 OP_FLAG_LAYER_8X16 = 64
 OP_FLAG_LAYER_M32 = 128
 OP_FLAG_NO_HEAD_FUSION = 256
+OP_FLAG_NO_F8 = 512
 OP_POOL_CLS, OP_POOL_MEAN = 0, 1
 
 LIB_NAME = "libopenprovence_hip.so"

@@ -71,6 +71,9 @@ struct LayerWeights {
   u16* wo_ks = nullptr;   // ... and attention output projection (fused kernels)
   // hi planes in the fragment order of the 32x32x16 whole-layer kernel (opk_layer32.hip.h), hidden = 256 only
   u16 *wo_p32 = nullptr, *wi_p32 = nullptr, *wo2_p32 = nullptr, *wqkv_p32 = nullptr;
+  // "f16 + fp8" kernel set (opk_common.hip.h): chunks of [fp16 plane | e4m3 plane] (Wqkv, Wi), fp16 k-streamed slabs
+  // (attention Wo, MLP Wo) and the e4m3 K = 128 slabs of the attention Wo
+  u16 *wqkv_f8 = nullptr, *wi_f8 = nullptr, *wo_f16 = nullptr, *wo_f8 = nullptr, *wo2_f16 = nullptr;
 };
 
 struct ProfileEvent {
@@ -89,6 +92,8 @@ struct op_handle {
   bool emulate = false;            // eff is not curated: kernel set 0 with the unused lo operands cleared
   bool resolved = false;           // eff / pi / emulate are valid (set by op_weights_ready)
   int* any_lo_dev = nullptr;       // [OP_FAM_COUNT] device flags: some weight of the family has a non-zero lo element
+                                   // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value (no "f16 + fp8" set)
+  bool f8_packs = false;           // the "f16 + fp8" weight packs exist (row path, hidden a multiple of 128)
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
   int n_cus = 256;          // compute units of the device (hipDeviceProp multiProcessorCount)
@@ -326,7 +331,12 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   OP_TRY(L.end());
 
   // rows >= `rows` are never produced by the attention kernel: keep its output finite there
-  if (fp_layout) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
+  const bool o_f8 = h->pi == opl::PI_F16_F8 && !h->emulate;  // o = fp16 pieces (ws.o_hi) + e4m3 pieces (ws.o_lo)
+  if (fp_layout && o_f8) {
+    const size_t n16 = (size_t)((r_pad - rows) / 16);
+    if (n16) OP_HIP(h, hipMemsetAsync(ws.o_hi + (size_t)(rows / 16) * (H / 32) * 512, 0, n16 * (H / 32) * 512 * sizeof(u16), st));
+    if (n16) OP_HIP(h, hipMemsetAsync(ws.o_lo + (size_t)(rows / 16) * h->nh * 512, 0, n16 * h->nh * 512 * sizeof(u16), st));
+  } else if (fp_layout) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
     const size_t tail_off = (size_t)(rows / 16) * (H / 32) * 2 * 512;
     const size_t tail_bytes = (size_t)((r_pad - rows) / 16) * (H / 32) * 2 * 512 * sizeof(u16);
     if (tail_bytes) OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));  // (a zero-byte node fails stream capture)
@@ -373,6 +383,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.k_fp = ws.k_hi;
       ap.vt_fp = ws.vt_hi;
       ap.o_fp = ws.o_hi;
+      ap.o_lo8 = ws.o_lo;
       ap.cu = cu_dev;
       ap.s0 = s0;
       ap.roff = ws.roff;
@@ -531,6 +542,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         rl.wi_pk = lw.wi_pk;
         rl.wo2_ks = lw.wo2_pk;
         rl.n_pairs = I / 32;
+        if (o_f8) {  // the "f16 + fp8" packs of the same weights
+          rl.a1_lo8 = ws.o_lo;
+          rl.w1p = lw.wo_f16;
+          rl.w1p8 = lw.wo_f8;
+          rl.wi_pk = lw.wi_f8;
+          rl.wo2_ks = lw.wo2_f16;
+          rl.wp = h->layers[with_qkv ? li + 1 : li].wqkv_f8;
+        }
         if (!with_qkv && head_in_last_layer) {
           // the last layer's rows go straight through final_norm + the pruning head (no write-back of x, no
           // final_ln_prune launch); mean pooling and hidden-state capture need all normalised rows and keep the kernel
@@ -884,8 +903,9 @@ int op_create(const op_config* cfg, op_handle** out) {
       h->n_cus = prop.multiProcessorCount;
   }
   const size_t HH = (size_t)H * H;
-  OP_CREATE_TRY(dev_alloc(h, &h->any_lo_dev, OP_FAM_COUNT));
-  OP_CREATE_HIP(hipMemset(h->any_lo_dev, 0, OP_FAM_COUNT * sizeof(int)));
+  OP_CREATE_TRY(dev_alloc(h, &h->any_lo_dev, OP_FAM_COUNT + 1));
+  OP_CREATE_HIP(hipMemset(h->any_lo_dev, 0, (OP_FAM_COUNT + 1) * sizeof(int)));
+  h->f8_packs = h->row_path && (H / 32) % 4 == 0 && !(cfg->flags & OP_FLAG_NO_F8);
   OP_CREATE_TRY(dev_alloc(h, &h->emb, (size_t)h->V * H));
   OP_CREATE_TRY(dev_alloc(h, &h->emb_norm, H));
   OP_CREATE_TRY(dev_alloc(h, &h->final_norm, H));
@@ -920,6 +940,13 @@ int op_create(const op_config* cfg, op_handle** out) {
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
+      if (h->f8_packs) {  // 3 bytes per weight element: fp16 + e4m3
+        OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_f8, 3 * HH * 3 / 2));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wi_f8, (size_t)2 * I * H * 3 / 2));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo_f16, HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo_f8, HH / 2));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo2_f16, (size_t)H * I));
+      }
       if (h->row_path && H == 256) {
         OP_CREATE_TRY(dev_alloc(h, &lw.wo_p32, HH));
         OP_CREATE_TRY(dev_alloc(h, &lw.wi_p32, (size_t)2 * I * H));
@@ -971,6 +998,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   u16* dst_pk = nullptr;
   u16* dst_ks = nullptr;  // additional k-streamed packing (attention Wo)
   u16* dst_p32 = nullptr; // additional packing for the 32x32x16 whole-layer kernel
+  u16 *dst_f8a = nullptr, *dst_f8b = nullptr;  // "f16 + fp8" packs: chunked (a) or k-streamed fp16 (a) + e4m3 (b)
   int p32_mode = 0, p32_kmajor = 0;
   int pk_mode = -1;
   int family = -1;        // op_gemm_family of a GEMM weight
@@ -1016,18 +1044,22 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       kind = PLANES; dst_hi = lw.wqkv_hi; dst_lo = lw.wqkv_lo; expect(3 * H, H);
       dst_pk = lw.wqkv_pk; pk_mode = RE_QKV; family = OP_FAM_WQKV;
       dst_p32 = lw.wqkv_p32; p32_mode = L32_QKV; p32_kmajor = 0;
+      dst_f8a = lw.wqkv_f8;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
       dst_pk = nullptr; pk_mode = 101; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
       dst_p32 = lw.wo_p32; p32_mode = L32_RESID; p32_kmajor = 1;
+      dst_f8a = lw.wo_f16; dst_f8b = lw.wo_f8;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
       dst_pk = lw.wi_pk; pk_mode = RE_GEGLU; family = OP_FAM_WI;
       dst_p32 = lw.wi_p32; p32_mode = L32_GEGLU; p32_kmajor = 0;
+      dst_f8a = lw.wi_f8;
     } else if (t == "mlp.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo2_hi; dst_lo = lw.wo2_lo; expect(H, I);
       dst_pk = lw.wo2_pk; pk_mode = 100; family = OP_FAM_MLP_OUT;  // k-streamed
       dst_p32 = lw.wo2_p32; p32_mode = L32_RESID; p32_kmajor = 1;
+      dst_f8a = lw.wo2_f16;
     } else {
       return fail(h, OP_ERR_INVALID, "op_load_weight: unknown tensor name '%s'", name_c);
     }
@@ -1105,6 +1137,13 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
                          zero_lo, any_lo);
     if (dst_ks)
       hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_ks, zero_lo, any_lo);
+    if (dst_f8a) {  // "f16 + fp8" kernel set; raises the not-fp16 flag (any_lo_dev[OP_FAM_COUNT]) for a weight it cannot hold exactly
+      int* not_f16 = h->any_lo_dev + OP_FAM_COUNT;
+      if (pk_mode == 100 || pk_mode == 101)
+        hipLaunchKernelGGL(pack_kstream_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_f8a, dst_f8b, not_f16);
+      else
+        hipLaunchKernelGGL(pack_rowgemm_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_f8a, not_f16);
+    }
     if (dst_p32)  // the 32x32x16 whole-layer kernel's order (hi plane; that kernel runs only when the lo planes are zero)
       hipLaunchKernelGGL(pack_layer32_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, p32_mode, p32_kmajor, H, I,
                          dst_p32);
@@ -1126,7 +1165,7 @@ namespace {
 // exactly those terms -- or kernel set 0 with the unused lo operands cleared.
 int resolve_policy(op_handle* h) {
   if (h->resolved) return OP_OK;
-  int any_lo[OP_FAM_COUNT] = {0};
+  int any_lo[OP_FAM_COUNT + 1] = {0};  // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value
   OP_HIP(h, hipSetDevice(h->cfg.device_id));
   OP_HIP(h, hipMemcpy(any_lo, h->any_lo_dev, sizeof(any_lo), hipMemcpyDeviceToHost));
   Policy e = h->req;
@@ -1144,6 +1183,11 @@ int resolve_policy(op_handle* h) {
         h->emulate = false;
         break;
       }
+    // bf16-valued weights that are also exact fp16 values, on the whole-layer kernel's shapes: the "f16 + fp8" kernel
+    // set evaluates the same terms at 1.5 instead of 2 MFMA units per product (op_internal.h)
+    if (!h->emulate && h->pi == opl::PI_BF16_WEIGHTS && h->f8_packs && !any_lo[OP_FAM_COUNT] &&
+        !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32)))
+      h->pi = opl::PI_F16_F8;
   } else if (opl::kPolicies[0] == e) {
     h->emulate = false;
   }

@@ -19,6 +19,7 @@ namespace opl {
 //   wqkv: LN(x) x Wqkv    qk: q x k    pv: p x v    attn_out: o x Wo    wi: LN(x) x Wi    mlp_out: h x Wo
 struct Policy {
   int wqkv, qk, pv, attn_out, wi, mlp_out;
+  int fmt = 0;  // operand format of the whole-layer kernel: 0 = (hi, lo) bf16 planes, 1 = fp16 hi + e4m3 lo (opk_common.hip.h)
   constexpr bool operator==(const Policy& o) const {
     return wqkv == o.wqkv && qk == o.qk && pv == o.pv && attn_out == o.attn_out && wi == o.wi && mlp_out == o.mlp_out;
   }
@@ -31,11 +32,17 @@ struct Policy {
 //   1  bf16 weights           weight lo planes are zero (bf16 checkpoint, or OP_PRECISION_BF16X2): 2 passes in the four
 //                             weight GEMMs, 3 in attention (q, k, p, v are all activations)
 //   2  bf16                   single pass everywhere
+//   3  f16 + fp8              the terms of set 1 with the whole-layer kernel's operands as fp16 hi + e4m3 lo: 1.5 MFMA
+//                             units per product instead of 2 (hidden <= 256, weights exactly representable in fp16;
+//                             layer-0 q / k / v and attention run set 1's kernels, attention writes o in the new format).
+//                             Never matched by terms (operator== ignores fmt): resolve_policy() upgrades 1 -> 3.
 constexpr Policy kPolicies[] = {
     {3, 3, 3, 3, 3, 3},
     {1, 3, 3, 1, 1, 1},
     {0, 0, 0, 0, 0, 0},
+    {1, 3, 3, 1, 1, 1, 1},
 };
+constexpr int PI_BF16_WEIGHTS = 1, PI_F16_F8 = 3;
 constexpr int N_POLICIES = (int)(sizeof(kPolicies) / sizeof(kPolicies[0]));
 
 // template arguments each kernel family derives from a policy
@@ -52,6 +59,8 @@ bool launch_kstream(hipStream_t st, const opk::KStreamParams& p, int nf, int pi,
 bool has_row_layer_fused(int pi);
 bool launch_row_layer_fused(hipStream_t st, const opk::RowGemmParams& p, int ks, int pi, bool with_qkv, unsigned grid,
                             bool waves8);
+// ... of the "f16 + fp8" kernel set (hidden 128 / 256)
+bool launch_row_layer_f8(hipStream_t st, const opk::RowGemmParams& p, int ks, bool with_qkv, unsigned grid);
 // the same launch on the 32x32x16 shape (hidden = 256; kernel sets 1 and 2)
 bool has_layer32(int pi);
 bool launch_layer32(hipStream_t st, const opk::Layer32Params& p, int pi, bool with_qkv, unsigned grid);

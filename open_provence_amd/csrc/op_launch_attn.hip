@@ -9,7 +9,7 @@ namespace {
 template <int PI, int WAVES, int KT>
 void launch_one(hipStream_t st, const AttnFpParams& p, dim3 grid) {
   constexpr Policy P = kPolicies[PI];
-  hipLaunchKernelGGL((attn_fp_kernel<P.qk, P.pv, o_lo(P), WAVES, KT>), grid, dim3(WAVES * 64), 0, st, p);
+  hipLaunchKernelGGL((attn_fp_kernel<P.qk, P.pv, o_lo(P), WAVES, KT, false, P.fmt == 1>), grid, dim3(WAVES * 64), 0, st, p);
 }
 
 template <int PI>
@@ -32,11 +32,12 @@ bool launch_attn(hipStream_t st, const AttnFpParams& p, int waves, int kt, int p
     else return false;
     return true;
   }
-  static_assert(N_POLICIES == 3, "extend the switch below");
+  static_assert(N_POLICIES == 4, "extend the switch below");
   switch (pi) {
     case 0: return launch_pi<0>(st, p, waves, kt, grid);
     case 1: return launch_pi<1>(st, p, waves, kt, grid);
     case 2: return launch_pi<2>(st, p, waves, kt, grid);
+    case 3: return launch_pi<3>(st, p, waves, kt, grid);
     default: return false;
   }
 }

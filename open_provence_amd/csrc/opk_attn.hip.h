@@ -21,7 +21,8 @@ struct AttnFpParams {
   const u16* q_fp;   // [rows/16][H/32][2][512]
   const u16* k_fp;
   const u16* vt_fp;  // [heads][rows/32][2][4][512]
-  u16* o_fp;         // [rows/16][H/32][2][512]
+  u16* o_fp;         // [rows/16][H/32][2][512]; OF8: fp16 pieces [rows/16][H/32][512] ...
+  u16* o_lo8;        // ... and e4m3 lo pieces [rows/16][heads][512] (one 1 KiB half-fragment per head, opk_common.hip.h)
   const int32_t* cu;
   int s0;
   const int32_t* roff;
@@ -61,8 +62,11 @@ constexpr int ATT_ITEM_GROUP = 4;
 // Scores arrive pre-multiplied by log2(e) (folded into the q scale by the QKV epilogue), so the softmax uses
 // exp2 directly: p = 2^(s - max).
 // ZP: lo(p) is cleared (a policy without the lo(p) x hi(v) term evaluated on the instantiation that has it).
-template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false>
+// OF8: the output is written for the "f16 + fp8" whole-layer kernel: hi = fp16 pieces, lo = e4m3 x 2^12 (a head's 64
+// dims are one 16-byte half-fragment per lane: the lane's 8 dims of both k-steps of the head).
+template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false, bool OF8 = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) {
+  if constexpr (OF8) set_saturating_conversions();
   constexpr int ATT_FP_BQ = WAVES * 32;
   constexpr int TILE_KEYS = 32 * KT;
   constexpr bool Q_LO = (TQK & T_LEFT_LO) != 0, K_LO = (TQK & T_RIGHT_LO) != 0;
@@ -329,6 +333,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
       l_tot += __shfl_xor(l_tot, 32, 64);
       const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
       // oacc[n][qf][r]: d = 32(n>>1) + 8g + 4(n&1) + r  ->  lane owns d = 8g..8g+7 of k-step (n>>1) of this head
+      if constexpr (OF8) {
+        uint32_t lo8[4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float v0[4] = {oacc[2 * half][qf][0] * inv, oacc[2 * half][qf][1] * inv, oacc[2 * half][qf][2] * inv,
+                               oacc[2 * half][qf][3] * inv};
+          const float v1[4] = {oacc[2 * half + 1][qf][0] * inv, oacc[2 * half + 1][qf][1] * inv,
+                               oacc[2 * half + 1][qf][2] * inv, oacc[2 * half + 1][qf][3] * inv};
+          uint2 h0, h1;
+          split4_f8(v0, h0, lo8[2 * half]);
+          split4_f8(v1, h1, lo8[2 * half + 1]);
+          store_stream16(p.o_fp + ((q_rb + qf) * kbn + head * 2 + half) * 512 + lane * 8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        }
+        store_stream16(p.o_lo8 + ((q_rb + qf) * (size_t)p.n_heads + head) * 512 + lane * 8, make_uint4(lo8[0], lo8[1], lo8[2], lo8[3]));
+        continue;
+      }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const float v0[4] = {oacc[2 * half][qf][0] * inv, oacc[2 * half][qf][1] * inv, oacc[2 * half][qf][2] * inv,

@@ -145,6 +145,88 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Kernel set "f16 + fp8" (round 3).  The (hi, lo) bf16 pair costs two 16x16x32 MFMAs per algorithmic product.  Here
+//   hi = RNE_fp16(v)                      11 significant bits, multiplied on v_mfma_f32_16x16x32_f16 against the weight
+//                                         as fp16 (exact for a bf16-valued weight);
+//   lo = e4m3((v - hi) * 2^12)            4 more bits, multiplied on v_mfma_scale_f32_16x16x128_f8f6f4 against the
+//                                         weight as e4m3, block scale 2^-12 on the lo operand: TWICE the rate of the
+//                                         16-bit shapes, accumulating into the same fp32 registers
+// = 1.5 MFMA units per product instead of 2 at the same ~2^-15 operand precision (microbench/f8_probe.hip: stream
+// rate on random operands 1.31 vs 1.03 PFLOP/s algorithmic; scripts/precision_emulate.py: g1_xsmall 3.6e-4 vs 1.9e-4).
+// The conversions saturate (MODE.FP16_OVFL, set_saturating_conversions()): without it an e4m3 overflow is NaN.
+//
+// fp8 fragment of one 16-row tile and one K = 128 step S (k-steps 4S .. 4S+3 of the 16-bit shapes): lane (i, g) holds
+// 32 bytes = two 16-byte halves hh = 0, 1; byte p of half hh is k = 32 (4S + 2hh + (p >> 3)) + 8g + (p & 7) -- the same
+// 8 k-values per (lane, k-step) as the 16-bit fragments, so hi and lo of a value are produced by the same lane.  In
+// memory a half is one 1 KiB piece [lane][16 B].  Both MFMA operands use this map (the contraction only needs them equal).
+// ----------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+
+constexpr int F8_LO_SHIFT = 12;                   // lo planes are stored x 2^12
+constexpr int F8_SCALE_LO = 127 - F8_LO_SHIFT;    // e8m0 block scale 2^-12 of the lo operand
+constexpr int F8_SCALE_ONE = 127;                 // e8m0 2^0 (weights)
+
+__device__ __forceinline__ void set_saturating_conversions() {
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // MODE.FP16_OVFL: f16 / fp8 conversions clamp to max normal
+}
+
+// the 16-bit product of this kernel set: operands carry fp16 bits in the registers the bf16 kernels use
+__device__ __forceinline__ f32x4 mfma16h(bf16x8 x, bf16x8 y, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+}
+__device__ __forceinline__ i32x8 f8_frag(bf16x8 half0, bf16x8 half1) {
+  const uint4 a = __builtin_bit_cast(uint4, half0), b = __builtin_bit_cast(uint4, half1);
+  return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+}
+// D += X8 * Y8 (e4m3 x e4m3, K = 128); LO_IS_Y: which operand is the 2^12-scaled lo plane (the other is a weight)
+template <bool LO_IS_Y>
+__device__ __forceinline__ f32x4 mfma8(i32x8 x, i32x8 y, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, c, 0, 0, 0, LO_IS_Y ? F8_SCALE_ONE : F8_SCALE_LO, 0,
+                                                          LO_IS_Y ? F8_SCALE_LO : F8_SCALE_ONE);
+}
+
+// two fp32 -> one dword of two fp16 (RNE): v_cvt_pk_f16_f32
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// v - float(half `HI_HALF` of h): exact, one instruction (v_fma_mix_f32 with an fp16 source)
+template <int HI_HALF>
+__device__ __forceinline__ float sub_f16_half(float v, uint32_t h) {
+  float r;
+  if (HI_HALF) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+  return r;
+}
+// four fp32 -> two dwords of fp16 (hi) + one dword of four e4m3 bytes (lo x 2^12): 2 + 4 + 2 = 8 VALU instructions
+__device__ __forceinline__ void split4_f8(const float v[4], uint2& hi, uint32_t& lo8) {
+  hi.x = pack_f16x2(v[0], v[1]);
+  hi.y = pack_f16x2(v[2], v[3]);
+  const float l0 = sub_f16_half<0>(v[0], hi.x), l1 = sub_f16_half<1>(v[1], hi.x);
+  const float l2 = sub_f16_half<0>(v[2], hi.y), l3 = sub_f16_half<1>(v[3], hi.y);
+  constexpr float inv_scale = 1.0f / (float)(1 << F8_LO_SHIFT);  // the instruction divides by its scale operand
+  i16x2 w = {0, 0};
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, l0, l1, inv_scale, false);
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, l2, l3, inv_scale, true);
+  lo8 = __builtin_bit_cast(uint32_t, w);
+}
+// four fp32 -> (hi, lo) fp16 pairs (lo = RNE_fp16(v - hi)): the 16-bit form, for operands whose K is too short for fp8
+__device__ __forceinline__ void split4_f16(const float v[4], uint2& hi, uint2& lo) {
+  hi.x = pack_f16x2(v[0], v[1]);
+  hi.y = pack_f16x2(v[2], v[3]);
+  lo.x = pack_f16x2(sub_f16_half<0>(v[0], hi.x), sub_f16_half<1>(v[1], hi.x));
+  lo.y = pack_f16x2(sub_f16_half<0>(v[2], hi.y), sub_f16_half<1>(v[3], hi.y));
+}
+// e4m3 of one value through the hardware conversion (weight packing; the caller has set saturating conversions)
+__device__ __forceinline__ unsigned char f2e4m3(float v) {
+  return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+}
+__device__ __forceinline__ u16 f2h(float v) { return __builtin_bit_cast(u16, (_Float16)v); }
+
 // ---- hand-placed LDS fragment reads -------------------------------------------------------------------------
 // While a global_load_lds DMA is in flight hipcc (ROCm 7.2) cannot count lgkmcnt: every wait it inserts in front of
 // an MFMA is `s_waitcnt lgkmcnt(0)`, which also waits for the fragment reads issued just before it for the NEXT

@@ -57,6 +57,12 @@ struct RowGemmParams {
   const u16* a1_fp;
   const u16* w1p;
   int k1_steps;
+  // F8 kernel set: a1_fp = fp16 pieces [r_pad/16][k1_steps][512] (no plane interleave), a1_lo8 = e4m3 pieces
+  // [r_pad/16][k1_steps/2][512] (one 1 KiB half-fragment per head, opk_common.hip.h); w1p = fp16 slabs [k-step][NF1][512],
+  // w1p8 = e4m3 slabs [K-step of 128][NF1][2 halves][512]; wi_pk / wp = chunks of [fp16 plane | e4m3 plane] pieces
+  // (pack_rowgemm_f8_kernel), wo2_ks = fp16 slabs [k-step][NF1][512]
+  const u16* a1_lo8;
+  const u16* w1p8;
   float* x_io;
   int zero_a_lo;  // clear the lo fragments of the in-register (LayerNorm / split) operand: see rowgemm_kernel
   // RP_MLP: the whole MLP between phase 1 and the chunk loop, h kept on chip
@@ -130,6 +136,61 @@ __global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, i
   if ((l & 0x7fffu) != 0) *any_lo = 1;
   dst[base] = h;
   dst[base + 1024] = zero_lo ? (u16)0 : l;
+}
+
+// "f16 + fp8" kernel set: chunk c = [fp16 pieces (ks, nf)][e4m3 pieces (nf, K-step S, half hh)], 1 KiB each (F8Chunk
+// below); the same source-row permutations as pack_rowgemm_kernel.  *not_f16 is raised when a weight of magnitude
+// >= 2^-14 is not exactly an fp16 value (then this kernel set would drop bits of the weight and the library keeps the
+// bf16 sets; every bf16 value in [2^-14, 65504] is an fp16 value).  Smaller weights land on the fp16 subnormal grid:
+// absolute error <= 2^-25 per weight, ~1e-6 on a logit.
+__global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows, int K, int mode, int H, int I,
+                                       u16* __restrict__ dst, int* __restrict__ not_f16) {
+  set_saturating_conversions();
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_rows * K;
+  if (idx >= total) return;
+  const int KS = K / 32, NS8 = KS / 4, CP = 2 * KS + 4 * NS8;
+  size_t t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int i = (int)(t & 15); t >>= 4;
+  const int g = (int)(t & 3); t >>= 2;
+  const int nf = (int)(t & 1); t >>= 1;
+  const int ks = (int)(t % KS);
+  const int c = (int)(t / KS);
+  const int srow = rowgemm_source_row(mode, c, nf * 16 + i, H, I);
+  const float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
+  const _Float16 hv = (_Float16)v;
+  if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;  // (below 2^-14: fp16 subnormal grid, |error| <= 2^-25)
+  dst[((size_t)c * CP + ks * 2 + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
+  const int s8 = ks >> 2, hh = (ks & 3) >> 1, pbyte = 8 * (ks & 1) + e;
+  unsigned char* d8 = reinterpret_cast<unsigned char*>(dst + ((size_t)c * CP + 2 * KS + (nf * NS8 + s8) * 2 + hh) * 512);
+  d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v);
+}
+
+// k-streamed weights of the "f16 + fp8" kernel set: fp16 slabs dst16[ks][nf][512] and (dst8 != nullptr, the attention
+// output projection) e4m3 slabs dst8[K-step S][nf][half][1 KiB]; `permute` as pack_kstream_kernel.
+__global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst16,
+                                       u16* __restrict__ dst8, int* __restrict__ not_f16) {
+  set_saturating_conversions();
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * K) return;
+  const int NF = N / 16;
+  size_t t = idx;
+  const int e = (int)(t & 7); t >>= 3;
+  const int i = (int)(t & 15); t >>= 4;
+  const int g = (int)(t & 3); t >>= 2;
+  const int nf = (int)(t % NF);
+  const int ks = (int)(t / NF);
+  const int row = permute ? (32 * (nf >> 1) + 8 * (i >> 2) + 4 * (nf & 1) + (i & 3)) : (nf * 16 + i);
+  const float v = src[(size_t)row * K + ks * 32 + g * 8 + e];
+  const _Float16 hv = (_Float16)v;
+  if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;  // (below 2^-14: fp16 subnormal grid, |error| <= 2^-25)
+  dst16[((size_t)ks * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
+  if (dst8 != nullptr) {
+    const int s8 = ks >> 2, hh = (ks & 3) >> 1, pbyte = 8 * (ks & 1) + e;
+    unsigned char* d8 = reinterpret_cast<unsigned char*>(dst8 + (((size_t)s8 * NF + nf) * 2 + hh) * 512);
+    d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v);
+  }
 }
 #endif
 
@@ -211,14 +272,98 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16
   });
 }
 
+// ---- "f16 + fp8" kernel set: a weight chunk (32 output features x K) is CHUNK = 2 KS fp16 pieces [ks][fragment]
+// followed by 4 (KS / 4) e4m3 pieces [fragment][K-step of 128][half].  Its fragment stream is KS / 4 groups of
+//   4 fp16 steps (both fragments of one k-step: 2 x MF MFMAs of 16 cycles) + 2 e4m3 steps (the two halves of ONE
+//   fragment of the group's K-step: MF MFMAs of 32 cycles)
+// so every step reads two 1 KiB pieces and keeps the matrix pipe busy for 64 cycles (MF = 2).
+template <int KS>
+struct F8Chunk {
+  static constexpr int NS8 = KS / 4;
+  static constexpr int STEPS = KS + 2 * NS8;
+  static constexpr int BYTES = (2 * KS + 4 * NS8) * 1024;
+  static constexpr bool is_f8(int cs) { return cs % 6 >= 4; }
+  static constexpr int ks(int cs) { return 4 * (cs / 6) + cs % 6; }   // fp16 step: k-step
+  static constexpr int nf(int cs) { return cs % 6 - 4; }              // e4m3 step: fragment
+  static constexpr int s8(int cs) { return cs / 6; }                  //            K-step of 128
+  static constexpr int off(int cs, int j) {
+    return is_f8(cs) ? (2 * KS + (nf(cs) * NS8 + s8(cs)) * 2 + j) * 1024 : (ks(cs) * 2 + j) * 1024;
+  }
+};
+// LDS byte offsets of the fused MLP's macro-iteration stream, F8 form: [Wi chunk 2t][Wi chunk 2t+1][MLP-Wo slab t-1]
+template <int KS, int NF1, bool SLAB>
+struct MlpStreamOff8 {
+  using C = F8Chunk<KS>;
+  static constexpr int NS = SLAB ? NF1 / 2 : 0;
+  static constexpr int at(int s, int j) {
+    if (s < C::STEPS) return C::off(s, j);
+    if (s < C::STEPS + NS) return 2 * C::BYTES + ((s - C::STEPS) * 2 + j) * 1024;
+    return C::BYTES + C::off(s - C::STEPS - NS, j);
+  }
+};
+
+// One F8 weight chunk against this wave's 32 rows (the q / k / v^T loop of the whole-layer kernel): the same
+// discipline as rowgemm_chunk_mfma -- reads one step ahead in two rotating register sets, each read group pinned
+// behind the MFMAs of the step whose set it re-uses.
+template <int KS, int MF, bool SWAPPED, bool PIN_AGPR>
+__device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const bf16x8 (&a_hi)[MF][KS], const i32x8 (&a_lo8)[MF][KS / 4],
+                                                      f32x4 (&acc)[2][MF]) {
+  using C = F8Chunk<KS>;
+  static_assert(MF == 2, "32 rows per wave");
+  bf16x8 w[2][2];
+  auto read_step = [&](auto cs_tag, auto pinned_tag) {
+    constexpr int cs = decltype(cs_tag)::value;
+    constexpr int S = cs % 2;
+    if constexpr (!decltype(pinned_tag)::value) w[S][0] = lds_read_frag<C::off(cs, 0)>(lds_addr);
+    else w[S][0] = lds_read_frag_after<C::off(cs, 0), PIN_AGPR>(lds_addr, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    w[S][1] = lds_read_frag<C::off(cs, 1)>(lds_addr);
+  };
+  auto mfma_step = [&](auto cs_tag) {
+    constexpr int cs = decltype(cs_tag)::value;
+    constexpr int S = cs % 2;
+    if constexpr (!C::is_f8(cs)) {
+      constexpr int ks = C::ks(cs);
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+          acc[nf][mf] = SWAPPED ? mfma16h(w[S][nf], a_hi[mf][ks], acc[nf][mf]) : mfma16h(a_hi[mf][ks], w[S][nf], acc[nf][mf]);
+    } else {
+      constexpr int nf = C::nf(cs), s8 = C::s8(cs);
+      const i32x8 w8 = f8_frag(w[S][0], w[S][1]);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+        acc[nf][mf] = SWAPPED ? mfma8<true>(w8, a_lo8[mf][s8], acc[nf][mf]) : mfma8<false>(a_lo8[mf][s8], w8, acc[nf][mf]);
+    }
+  };
+  const std::true_type yes{};
+  const std::false_type no{};
+  read_step(std::integral_constant<int, 0>{}, no);
+  read_step(std::integral_constant<int, 1>{}, no);
+  static_for<C::STEPS>([&](auto t) {
+    constexpr int cs = decltype(t)::value;
+    constexpr int ahead = cs + 1 < C::STEPS ? 1 : 0;
+    lds_wait2<2 * ahead>(w[cs % 2][0], w[cs % 2][1]);
+    mfma_step(t);
+    if constexpr (cs + 2 < C::STEPS) read_step(std::integral_constant<int, cs + 2>{}, yes);
+  });
+}
+
 // T2 = term mask of the chunk loop's GEMM (left = this block's rows, right = the streamed weight), T1 = term mask of
 // the fused phase-1 GEMM (RP_KSTREAM only), OLO = which outputs also get a lo plane (bit 0: o0 = q / h, bit 1: o1 = k,
 // bit 2: o2 = v^T).
 // RP_MLP only: TW = term mask of LN(x) x Wi, TM = of h x Wo(mlp); T1 is then the attention output projection and T2
 // the next layer's q/k/v projection.  Both weights must be single-plane (no hi x lo(weight) term): two LDS stages of
 // [two Wi chunks | one Wo slab] are 96 KiB then.
-template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0>
+// F8 (whole-layer kernel only): the "f16 + fp8" kernel set (opk_common.hip.h) -- every hi operand is fp16, the lo
+// operand of the three K = hidden contractions (attention output projection, Wi, next q / k / v) is an e4m3 plane
+// multiplied at twice the rate on the K = 128 block-scaled MFMA, h (K = 32 per step) keeps a 16-bit lo fragment.
+template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0, bool F8 = false>
 __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : ((MF == 1 && WAVES == 8) ? 4 : 2)) void rowgemm_kernel(RowGemmParams p) {
+  static_assert(!F8 || (PRO == RP_MLP && WAVES == 4 && MF == 2 && KS % 4 == 0 && T1 == T_LEFT_LO && TW == T_LEFT_LO && TM == T_LEFT_LO &&
+                        (EPI == RE_NONE || T2 == T_LEFT_LO)),
+                "f16 + fp8 kernel set: whole-layer kernel, 4 waves x 32 rows, single-plane weights, every activation lo term");
+  constexpr int NS8 = F8 ? KS / 4 : 1;  // K = 128 steps of the fp8 lo product
   // A block is WAVES x MF x 16 rows; the library launches 4 waves x 2 fragments = 128 rows, two blocks per CU, and
   // 4 waves x 1 fragment = 64 rows for small batches (fewer than one 128-row block per CU-slot: twice the blocks, so
   // twice the CUs work on a latency-bound request).
@@ -238,10 +383,14 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   constexpr int PLANES = W_LO ? 2 : 1;
   constexpr int PLANES1 = W_LO1 ? 2 : 1;
   constexpr int K = KS * 32;
-  constexpr int CHUNK_SRC = KS * 2 * 1024;        // elements per packed chunk in global memory
-  constexpr int STAGE = KS * PLANES * 1024;       // elements per LDS stage
-  constexpr int MLP_UNIT = PRO == RP_MLP ? 3 * KS * 1024 : 0;  // two Wi chunks + one Wo slab (2 KS fragments), one plane
-  constexpr int STAGE_GEMM = KS * (PLANES > PLANES1 ? PLANES : PLANES1) * 1024;  // phase 1 slabs: 2 KS fragments per plane
+  // F8: a chunk is [fp16 plane: KS k-steps x 2 fragments | e4m3 plane: 2 fragments x KS/4 K-steps x 2 halves] 1 KiB pieces
+  constexpr int CHUNK_PIECES8 = 2 * KS + 4 * NS8;
+  constexpr int CHUNK_SRC = F8 ? CHUNK_PIECES8 * 512 : KS * 2 * 1024;  // elements per packed chunk in global memory
+  constexpr int STAGE = F8 ? CHUNK_PIECES8 * 512 : KS * PLANES * 1024;  // elements per LDS stage
+  // two Wi chunks + one Wo slab (2 KS fragments), one plane; F8: the chunks carry their e4m3 plane
+  constexpr int MLP_UNIT = PRO == RP_MLP ? (F8 ? (2 * CHUNK_PIECES8 + 2 * KS) * 512 : 3 * KS * 1024) : 0;
+  // phase 1 slabs: 2 KS fragments per plane; F8: two fp16 slabs + half an e4m3 K = 128 slab per stage
+  constexpr int STAGE_GEMM = F8 ? 6 * KS * 512 : KS * (PLANES > PLANES1 ? PLANES : PLANES1) * 1024;
   constexpr int STAGE_ALLOC = STAGE_GEMM > MLP_UNIT ? STAGE_GEMM : MLP_UNIT;
   static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE_ALLOC];
@@ -254,6 +403,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #else
   constexpr bool LN_V2 = PRO == RP_MLP;
 #endif
+  static_assert(!F8 || LN_V2, "f16 + fp8 kernel set: LayerNorm phases of the whole-layer kernel");
   constexpr bool FIN_HEAD = LN_V2 && EPI == RE_NONE;  // (run-time switch: p.fin_ln)
   __shared__ __attribute__((aligned(16))) float sLn[LN_V2 ? (FIN_HEAD ? 4 : 2) * KS * 32 : 4];
 
@@ -311,13 +461,15 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       const int elem = piece * 512;                    // position inside the LDS stage
       const int ks = elem / (PLANES * 1024);
       const int rem = elem % (PLANES * 1024);
-      const int src_elem = ks * 2048 + rem;            // source keeps both planes per k-step
+      const int src_elem = F8 ? elem : ks * 2048 + rem;  // source keeps both planes per k-step (F8: packed as staged)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(src + src_elem + lane * 8),
           (__attribute__((address_space(3))) void*)(&sW[stage][elem]), 16, 0, 0);
     }
   };
   bf16x8 a_hi[MF][KS], a_lo[MF][KS];
+  i32x8 a_lo8[MF][NS8];  // F8: e4m3 lo plane of the in-register operand, one K = 128 fragment per 4 k-steps
+  if constexpr (F8) set_saturating_conversions();
   // RE_QKV: RoPE rows of this lane's tokens, cos/sin [pos][8g + 4j .. +3] for half-head j.  Two-wave kernels fetch the
   // half-head of the chunk whose (deferred) epilogue runs in an iteration at the top of that iteration (the partner wave
   // covers the latency).  The one-wave-per-SIMD layer kernel (RP_MLP) has nobody to cover it -- the loads sat behind a
@@ -360,7 +512,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     // are exactly lane slot g of k-step s of THIS kernel's chunk loop: residual add, LayerNorm and the hi/lo
     // split happen in registers and the hidden state makes one fp32 round trip (read + write) per block.
     constexpr int NF1 = 2 * KS;
-    constexpr int SLAB_SRC = NF1 * 2 * 512;
+    constexpr int SLAB_SRC = F8 ? NF1 * 512 : NF1 * 2 * 512;
     constexpr int SLAB_PIECES = (NF1 * PLANES1) / WAVES;
     static_assert((NF1 * PLANES1) % WAVES == 0, "slab must split evenly over the waves");
     auto stage_slab = [&](int ks1, int stage) {
@@ -396,17 +548,35 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     float4 xq0[(PRO == RP_MLP) ? NF1 : 1];
     if constexpr (PRO == RP_MLP) {
       static_assert(PLANES1 == 1, "whole-layer kernel: single-plane attention output weight");
-      constexpr int PAIR_PIECES = 2 * NF1 / WAVES;  // DMA instructions per wave per stage (two k-steps)
-      static_assert(2 * NF1 * 512 <= STAGE_ALLOC, "two slabs per LDS stage");
+      // DMA instructions per wave per stage: two k-steps of fp16 slabs (+ F8: NF1 / 2 fragments = NF1 half-pieces of the
+      // e4m3 slab of K-step j / 2: its first half of the output features in the even stage, the second in the odd one)
+      constexpr int PAIR_PIECES = (F8 ? 3 : 2) * NF1 / WAVES;
+      static_assert((F8 ? 3 : 2) * NF1 * 512 <= STAGE_ALLOC, "two slabs per LDS stage");
       auto stage_pair = [&](int j, int stage) {
 #pragma unroll
         for (int u = 0; u < PAIR_PIECES; ++u) {
           const int piece = wave + WAVES * u;  // [k-step 2j | 2j+1][nf]
           const u16* src = p.w1p + (size_t)(2 * j + piece / NF1) * SLAB_SRC + (piece % NF1) * 512;
+          if (F8 && u >= 2 * NF1 / WAVES)
+            src = p.w1p8 + ((size_t)(j >> 1) * NF1 + (NF1 / 2) * (j & 1)) * 1024 + (piece - 2 * NF1) * 512;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
                                            (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
         }
       };
+      if constexpr (F8) {
+        const u16* h_base = p.a1_fp + (size_t)(m0 >> 4) * nks1 * 512 + lane * 8;
+        const u16* l_base = p.a1_lo8 + (size_t)(m0 >> 4) * (nks1 >> 1) * 512 + lane * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) a_hi[mf][ks] = load_stream_frag(h_base + ((size_t)mf * nks1 + ks) * 512);
+#pragma unroll
+        for (int s8 = 0; s8 < NS8; ++s8)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+            a_lo8[mf][s8] = f8_frag(load_stream_frag(l_base + ((size_t)mf * (nks1 >> 1) + 2 * s8) * 512),
+                                    load_stream_frag(l_base + ((size_t)mf * (nks1 >> 1) + 2 * s8 + 1) * 512));
+      } else {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -414,6 +584,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           a_hi[mf][ks] = load_stream_frag(a_base0 + mf * a_block + (size_t)ks * 1024);
           a_lo[mf][ks] = A_LO1 ? load_stream_frag(a_base0 + mf * a_block + (size_t)ks * 1024 + 512) : a_hi[mf][ks];
         }
+      }
       stage_pair(0, 0);
       __builtin_amdgcn_sched_barrier(0);  // the residual rows are requested last and are not waited for here
       {
@@ -445,9 +616,24 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         struct P1Off {
           static constexpr int at(int st, int jj) { return (2 * st + jj) * 1024; }
         };
-        frag_stream2<NF1, 2, P1Off>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+        frag_stream2<(F8 ? NF1 + NF1 / 2 : NF1), 2, P1Off>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int st = decltype(step_tag)::value;
-          constexpr int ks = 2 * j + st / (NF1 / 2), nf = (st % (NF1 / 2)) * 2;
+          if constexpr (F8) {
+            if constexpr (st < NF1) {  // fp16: fragments nf, nf + 1 of k-step ks
+              constexpr int ks = 2 * j + st / (NF1 / 2), nf = (st % (NF1 / 2)) * 2;
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, a_hi[mf][ks], acc1[nf][mf]);
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16h(w1, a_hi[mf][ks], acc1[nf + 1][mf]);
+            } else {  // e4m3: the two halves of fragment nf8, K-step j / 2
+              constexpr int nf8 = (NF1 / 2) * (j & 1) + (st - NF1);
+              const i32x8 w8 = f8_frag(w0, w1);
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) acc1[nf8][mf] = mfma8<true>(w8, a_lo8[mf][j >> 1], acc1[nf8][mf]);
+            }
+            return;
+          }
+          constexpr int ks = 2 * j + (st % NF1) / (NF1 / 2), nf = (st % (NF1 / 2)) * 2;
           if (A_LO1) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, a_lo[mf][ks], acc1[nf][mf]);
@@ -645,12 +831,29 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           f32x4& w1 = wq[ks & 1][1];
           lds_wait_f4<(ks + 1 < KS ? 2 : 0)>(w0, w1);
           const f32x2 lw[4] = {f32x2{w0[0], w0[1]}, f32x2{w0[2], w0[3]}, f32x2{w1[0], w1[1]}, f32x2{w1[2], w1[3]}};
+          if constexpr (F8) {
+            // fp16 hi fragment + the 8 e4m3 lo bytes of this k-step inside the K = 128 fragment ks / 4 (opk_common.hip.h)
+            f32x2 y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]);
+            const float va[4] = {y[0].x, y[0].y, y[1].x, y[1].y}, vb[4] = {y[2].x, y[2].y, y[3].x, y[3].y};
+            uint2 h0, h1;
+            uint32_t l0, l1;
+            split4_f8(va, h0, l0);
+            split4_f8(vb, h1, l1);
+            a_hi[mf][ks] = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
+            constexpr int d0 = 4 * ((ks % 4) / 2) + 2 * (ks % 2);
+            a_lo8[mf][ks / 4][d0] = (int)l0;
+            a_lo8[mf][ks / 4][d0 + 1] = (int)l1;
+            if constexpr (LOAD && (ks % 4) == 3) asm volatile("" : "+a"(a_lo8[mf][ks / 4]));  // parked where the MLP wants it
+          } else {
           uint32_t h[4], l[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) split2_pk<LO>(pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]), h[j], l[j]);
           a_hi[mf][ks] = as_frag(make_uint4(h[0], h[1], h[2], h[3]));
           a_lo[mf][ks] = as_frag(make_uint4(l[0], l[1], l[2], l[3]));
           if constexpr (LO && LOAD && MF == 2) asm volatile("" : "+a"(a_lo[mf][ks]));  // parked where the MLP wants it (see below)
+          }
           if constexpr (ks + 2 < KS) ln_read(std::integral_constant<int, ks + 2>{});
         });
 #ifdef OPK_TIMING
@@ -768,7 +971,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       constexpr bool A_LOW = (TW & T_LEFT_LO) != 0;  // lo(LN(x)) x hi(Wi)
       constexpr bool H_LO = (TM & T_LEFT_LO) != 0;   // lo(h) x hi(Wo)
       constexpr int UNIT_PIECES = MLP_UNIT / 512;
-      constexpr int WI_PIECES = 2 * KS * 2;  // both chunks
+      constexpr int WI_PIECES = F8 ? 2 * CHUNK_PIECES8 : 2 * KS * 2;  // both chunks
       static_assert(UNIT_PIECES % WAVES == 0 && WI_PIECES % WAVES == 0, "stage regions must split over the waves");
       const int n_pairs = p.n_pairs;
       constexpr int UNIT_DMA = UNIT_PIECES / WAVES;  // DMA instructions per wave per stage
@@ -781,7 +984,10 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         const int ts = t > 0 ? t - 1 : 0;
         const int piece = wave + WAVES * u;  // wave-uniform
         const u16* src;
-        if (u < WI_PIECES / WAVES) {  // [chunk 0..1][ks][frag]: hi pieces of the chunk-major pack
+        if (F8) {  // the pack is in stage order: two consecutive chunks, then the fp16 slab
+          src = u < WI_PIECES / WAVES ? p.wi_pk + (size_t)(2 * tc) * CHUNK_SRC + piece * 512
+                                      : p.wo2_ks + (size_t)ts * (NF1 * 512) + (piece - WI_PIECES) * 512;
+        } else if (u < WI_PIECES / WAVES) {  // [chunk 0..1][ks][frag]: hi pieces of the chunk-major pack
           const int c = piece / (2 * KS), within = piece % (2 * KS);
           src = p.wi_pk + (size_t)(2 * tc + c) * CHUNK_SRC + (within >> 1) * 2048 + (within & 1) * 512;
         } else {
@@ -797,7 +1003,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       // The lo fragments of the normalised rows live in AGPRs from here on (an MFMA takes its A / B operands from
       // either file): the 256 architectural VGPRs were short by about that much, and the compiler's own answer was to
       // park fragments in AGPRs and move them back in front of each use -- ~8 issue cycles per v_accvgpr move.
-      if (A_LOW && MF == 2) {
+      if (A_LOW && MF == 2 && !F8) {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -876,7 +1082,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         return;
 #endif
         uint2 h2, l2;
-        split4<H_LO>(g_prev[mf], h2, l2);
+        if constexpr (F8) split4_f16(g_prev[mf], h2, l2);
+        else split4<H_LO>(g_prev[mf], h2, l2);
         h_hi[mf] = as_frag(make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y));
         h_lo[mf] = as_frag(make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y));
       };
@@ -885,12 +1092,20 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #ifdef OPK_ABL_NO_MLP_VALU
         return;
 #endif
-        split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
+        if constexpr (F8) split4_f16(g_cur[mf], hold_hi[mf], hold_lo[mf]);
+        else split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
       };
       auto chunk_step = [&](f32x4 (&acc)[2][MF], auto ks_tag, const bf16x8& w0, const bf16x8& w1) {
         constexpr int ks = decltype(ks_tag)::value;
         // the first MFMA of an accumulator takes the constant 0 as its C operand (no zero-fill of the registers)
         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (F8) {  // fp16 product only; the e4m3 lo product follows in chunk_step8
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc[0][mf] = mfma16h(w0, a_hi[mf][ks], ks == 0 ? zero : acc[0][mf]);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16h(w1, a_hi[mf][ks], ks == 0 ? zero : acc[1][mf]);
+          return;
+        }
         if (A_LOW) {
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) acc[0][mf] = mfma16(w0, a_lo[mf][ks], ks == 0 ? zero : acc[0][mf]);
@@ -902,8 +1117,26 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16(w1, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[1][mf]);
       };
+      // F8: lo(LN(x)) x Wi as e4m3, fragment nf of the chunk, K-step s8: (w0, w1) are the fragment's two halves
+      auto chunk_step8 = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1) {
+        constexpr int nf = decltype(nf_tag)::value, s8 = decltype(s8_tag)::value;
+        const i32x8 w8 = f8_frag(w0, w1);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = mfma8<true>(w8, a_lo8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
+      };
       auto slab_pair = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1) {
         constexpr int nf = decltype(nf_tag)::value;
+        if constexpr (F8) {  // h: (hi, lo) fp16 pair, both on the fp16 shape (K = 32 per step is too short for the fp8 one)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_lo[mf], acc1[nf][mf]);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16h(w1, h_lo[mf], acc1[nf + 1][mf]);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_hi[mf], acc1[nf][mf]);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16h(w1, h_hi[mf], acc1[nf + 1][mf]);
+          return;
+        }
         if (H_LO) {
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, h_lo[mf], acc1[nf][mf]);
@@ -922,6 +1155,15 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         for (int i = 0; i < STEP_MFMA; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      };
+      // F8: a step holds n_mfma MFMAs (4 fp16 or 2 e4m3 of a chunk: 64 pipe cycles; 8 fp16 of a slab) and up to
+      // n_mfma x per vector instructions of the GeGLU slice riding on it
+      auto interleave_n = [&](auto n_tag, auto per_tag) {
+#pragma unroll
+        for (int i = 0; i < decltype(n_tag)::value; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, decltype(per_tag)::value, 0);
         }
       };
       constexpr int DEPTH = 2;  // fragment groups in flight ahead of the one being consumed (a step = 8 MFMAs)
@@ -961,6 +1203,36 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(src));
         }
 #endif
+        if constexpr (F8) {
+          using Off8 = MlpStreamOff8<KS, NF1, SLAB>;
+          using C8 = F8Chunk<KS>;
+          constexpr int CS = C8::STEPS;
+          frag_stream2<2 * CS + NS, DEPTH, Off8>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+            constexpr int s = decltype(step_tag)::value;
+#ifndef OPK_ABL_NO_DMA
+            if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
+#endif
+            if constexpr (s < CS || s >= CS + NS) {  // a chunk step: chunk 2t into na, chunk 2t+1 into acc_b
+              constexpr bool FIRST_CHUNK = s < CS;
+              constexpr int cs = FIRST_CHUNK ? s : s - CS - NS;
+              auto& acc = *(FIRST_CHUNK ? &na : &acc_b);
+              if constexpr (!C8::is_f8(cs)) {
+                chunk_step(acc, std::integral_constant<int, C8::ks(cs)>{}, w0, w1);
+                // the GeGLU slices ride on the fp16 steps: chunk 2t-1's on chunk 2t (-> h of pair t-1 ready for the
+                // slab), and in the first iteration (no slab yet) chunk 0's on chunk 1
+                if constexpr (FIRST_CHUNK && SLAB) geglu_slice(acc_b, g_prev, std::integral_constant<int, C8::ks(cs)>{}, pack_h);
+                if constexpr (!FIRST_CHUNK && !SLAB) geglu_slice(na, g_cur, std::integral_constant<int, C8::ks(cs)>{}, pack_hold);
+                interleave_n(std::integral_constant<int, 2 * MF>{}, std::integral_constant<int, 6>{});
+              } else {
+                chunk_step8(acc, std::integral_constant<int, C8::nf(cs)>{}, std::integral_constant<int, C8::s8(cs)>{}, w0, w1);
+              }
+            } else {  // slab t-1, with the GeGLU of chunk 2t
+              slab_pair(std::integral_constant<int, 2 * (s - CS)>{}, w0, w1);
+              geglu_slice(na, g_cur, std::integral_constant<int, s - CS>{}, pack_hold);
+              interleave_n(std::integral_constant<int, 4 * MF>{}, std::integral_constant<int, 3>{});
+            }
+          });
+        } else
         frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int s = decltype(step_tag)::value;
 #ifndef OPK_ABL_NO_DMA
@@ -1006,7 +1278,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
         static_for<KS>([&](auto sl) { geglu_slice(acc_b, g_prev, sl, pack_h); });
         struct TailOff {
-          static constexpr int at(int s, int j) { return 2 * KS * 2048 + (s * 2 + j) * 1024; }
+          static constexpr int at(int s, int j) { return (F8 ? 2 * F8Chunk<KS>::BYTES : 2 * KS * 2048) + (s * 2 + j) * 1024; }
         };
         frag_stream2<NF1 / 2, DEPTH, TailOff>(lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           slab_pair(std::integral_constant<int, 2 * decltype(step_tag)::value>{}, w0, w1);
@@ -1355,7 +1627,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP)>(lds_stage[cur], a_hi, a_lo, acc);
+    if constexpr (F8) rowgemm_chunk_mfma_f8<KS, MF, SW, true>(lds_stage[cur], a_hi, a_lo8, acc);
+    else rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP)>(lds_stage[cur], a_hi, a_lo, acc);
 #if !defined(OPK_ABL_NO_EPILOGUE)
     if (!FIRST) epilogue_store(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag);
 #endif
@@ -1370,7 +1643,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       // instruction costs its issue slot -- so the gain of the interleave is only that no wave sits in a VALU-only
       // phase while its partner waits for the same port; the lever that pays is fewer epilogue instructions.
       constexpr int NT = term_count(T2);
-      constexpr int N_MFMA = KS * 2 * MF * NT;
+      constexpr int N_MFMA = F8 ? KS * 2 * MF + 2 * NS8 * MF : KS * 2 * MF * NT;
       constexpr int VALU_PER_MFMA = NT == 3 ? 2 : (NT == 2 ? 3 : 5);  // (2 or 4 for NT == 2: no change, measured)
 #pragma unroll
       for (int i = 0; i < N_MFMA; ++i) {

@@ -29,6 +29,7 @@ _ENV_FLAGS = {
     "OPEN_PROVENCE_LAYER_8X16": _lib.OP_FLAG_LAYER_8X16,
     "OPEN_PROVENCE_LAYER_M32": _lib.OP_FLAG_LAYER_M32,
     "OPEN_PROVENCE_NO_HEAD_FUSION": _lib.OP_FLAG_NO_HEAD_FUSION,
+    "OPEN_PROVENCE_NO_F8": _lib.OP_FLAG_NO_F8,
 }
 
 
@@ -175,13 +176,14 @@ class HipEncoder:
     def effective_policy(self) -> dict:
         """Term masks actually evaluated (the requested policy minus weight-lo terms that are identically zero
         for the loaded checkpoint) and the kernel set running them: ``{"terms": {family: mask}, "kernel_set":
-        "bf16x3" | "bf16-weights" | "bf16" | "all-terms kernels, cleared lo operands"}``."""
+        "bf16x3" | "bf16-weights" | "bf16" | "f16-f8" | "all-terms kernels, cleared lo operands"}`` ("f16-f8": the
+        terms of "bf16-weights" with the whole-layer kernel's operands carried as fp16 hi + e4m3 lo)."""
 
         terms = (ctypes.c_uint8 * 8)()
         kernel_set = ctypes.c_int(0)
         code = self.lib.op_effective_policy(self._handle, terms, ctypes.byref(kernel_set))
         _lib.check(self.lib, self._handle, code, "op_effective_policy")
-        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", -1: "all-terms kernels, cleared lo operands"}
+        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", -1: "all-terms kernels, cleared lo operands"}
         return {
             "terms": {name: int(terms[i]) for i, name in enumerate(_lib.OP_FAMILIES)},
             "kernel_set": names.get(int(kernel_set.value), str(kernel_set.value)),
