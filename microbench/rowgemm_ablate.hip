@@ -43,8 +43,28 @@ static void fill_bf16(std::vector<u16>& v, unsigned seed, float scale) {
   }
 }
 
+// -DABL_F8: the "f16 + fp8" form of the whole-layer kernel; operand buffers are filled with fp16 bit patterns of
+// uniform values and finite e4m3 bytes in the layouts the kernel reads (the values are not a real packing: timing only)
+static void fill_f16(u16* v, size_t n, unsigned seed, float scale) {
+  unsigned s = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 1664525u + 1013904223u;
+    const _Float16 h = (_Float16)(((int)(s >> 9) / 8388608.0f - 0.5f) * 2.0f * scale);
+    memcpy(&v[i], &h, 2);
+  }
+}
+static void fill_e4m3(unsigned char* v, size_t n, unsigned seed, int max_exp_code) {
+  unsigned s = seed * 2654435761u + 999u;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 1664525u + 1013904223u;
+    v[i] = (unsigned char)(((s >> 8) & 0x80u) | (((s >> 16) % (unsigned)max_exp_code) << 3) | ((s >> 24) & 7u));
+  }
+}
+
 int main() {
-  const int R = 131072, H = 256, I = 1024, KS = 8;
+  // ABL_ROWS: rows of the launch (default 131072 = 1024 blocks = 4 rounds of 256 CUs); 16384 = half the CUs, one round
+  const int R = getenv("ABL_ROWS") ? atoi(getenv("ABL_ROWS")) : 131072;
+  constexpr int H = 256, I = 1024, KS = 8;
   std::vector<u16> o((size_t)R * H * 2), wo((size_t)H * H * 2), wi((size_t)2 * I * H * 2);
   std::vector<float> x((size_t)R * H), lnw(H, 1.0f);
   // ABL_ZERO=1: all-zero operands (nothing toggles in the datapaths): how much of the run time is the power limit
@@ -123,6 +143,36 @@ int main() {
   CHECK(hipMalloc(&p.dbg, (size_t)(R / 128) * 16 * 8));
   CHECK(hipMemset(p.dbg, 0, (size_t)(R / 128) * 16 * 8));
 #endif
+#ifdef ABL_F8
+  {
+    // o: fp16 pieces [R/16][KS][512] then e4m3 pieces [R/16][KS/2][1 KiB]; Wo: fp16 slabs + e4m3 slabs; Wi / Wqkv: chunks
+    // of (2 KS + KS) pieces; Wo(mlp): fp16 slabs
+    std::vector<u16> ob((size_t)R * H * 2), wob((size_t)H * H * 2), wib((size_t)2 * I * H * 2), wo2b((size_t)H * I), wqb((size_t)3 * H * H * 2);
+    if (!zero_data) {
+      fill_f16(ob.data(), (size_t)R * H, 11, 1.0f);
+      fill_e4m3(reinterpret_cast<unsigned char*>(ob.data() + (size_t)R * H), (size_t)R * H, 12, 12);
+      fill_f16(wob.data(), (size_t)H * H, 13, 0.06f);
+      fill_e4m3(reinterpret_cast<unsigned char*>(wob.data() + (size_t)H * H), (size_t)H * H, 14, 5);
+      fill_f16(wo2b.data(), wo2b.size(), 15, 0.03f);
+      const size_t CP = 2 * KS + KS;  // pieces per chunk
+      for (size_t c = 0; c < (size_t)2 * I / 32; ++c) {
+        fill_f16(wib.data() + c * CP * 512, 2 * KS * 512, 100 + (unsigned)c, 0.06f);
+        fill_e4m3(reinterpret_cast<unsigned char*>(wib.data() + (c * CP + 2 * KS) * 512), KS * 1024, 300 + (unsigned)c, 5);
+      }
+      for (size_t c = 0; c < (size_t)3 * H / 32; ++c) {
+        fill_f16(wqb.data() + c * CP * 512, 2 * KS * 512, 500 + (unsigned)c, 0.06f);
+        fill_e4m3(reinterpret_cast<unsigned char*>(wqb.data() + (c * CP + 2 * KS) * 512), KS * 1024, 700 + (unsigned)c, 5);
+      }
+    }
+    CHECK(hipMemcpy(d_o, ob.data(), ob.size() * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_wo, wob.data(), wob.size() * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_wi, wib.data(), wib.size() * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_wo2, wo2b.data(), wo2b.size() * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_wqkv, wqb.data(), wqb.size() * 2, hipMemcpyHostToDevice));
+    p.a1_lo8 = d_o + (size_t)R * H;
+    p.w1p8 = d_wo + (size_t)H * H;
+  }
+#endif
   p.ln_w_mlp = d_ln;
   p.wi_pk = d_wi;
   p.wo2_ks = d_wo2;
@@ -165,9 +215,14 @@ int main() {
   lp.max_pos = 8192;
   auto launch = [&]() { hipLaunchKernelGGL((layer32_kernel<8, true, ABL_T != 0, 7>), dim3(R / 128), dim3(256), 0, 0, lp); };
 #else
+#ifdef ABL_F8
+  constexpr bool kF8 = true;
+#else
+  constexpr bool kF8 = false;
+#endif
   auto launch = [&]() {
     if (ABL_LAYER == 2)
-      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, ABL_T, ABL_T, 7, 4, 2, ABL_T, ABL_T>), dim3(R / 128), dim3(256), 0, 0, p);
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, ABL_T, ABL_T, 7, 4, 2, ABL_T, ABL_T, kF8>), dim3(R / 128), dim3(256), 0, 0, p);
     else
       hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, ABL_T, 0, 0, 4, 2, ABL_T, ABL_T>), dim3(R / 128), dim3(256), 0, 0, p);
   };

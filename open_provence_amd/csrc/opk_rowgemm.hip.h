@@ -295,32 +295,36 @@ template <int KS, int NF1, bool SLAB>
 struct MlpStreamOff8 {
   using C = F8Chunk<KS>;
   static constexpr int NS = SLAB ? NF1 / 2 : 0;
+  // stream order (F8): chunk 2t, chunk 2t+1, slab t-1
   static constexpr int at(int s, int j) {
     if (s < C::STEPS) return C::off(s, j);
-    if (s < C::STEPS + NS) return 2 * C::BYTES + ((s - C::STEPS) * 2 + j) * 1024;
-    return C::BYTES + C::off(s - C::STEPS - NS, j);
+    if (s < 2 * C::STEPS) return C::BYTES + C::off(s - C::STEPS, j);
+    return 2 * C::BYTES + ((s - 2 * C::STEPS) * 2 + j) * 1024;
   }
 };
 
 // One F8 weight chunk against this wave's 32 rows (the q / k / v^T loop of the whole-layer kernel): the same
 // discipline as rowgemm_chunk_mfma -- reads one step ahead in two rotating register sets, each read group pinned
 // behind the MFMAs of the step whose set it re-uses.
-template <int KS, int MF, bool SWAPPED, bool PIN_AGPR>
+// DEPTH steps of reads stay in flight behind the one being multiplied (a step is 64 pipe cycles: one step ahead does
+// not cover the LDS latency under load).
+template <int KS, int MF, bool SWAPPED, bool PIN_AGPR, int DEPTH = 3>
 __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const bf16x8 (&a_hi)[MF][KS], const i32x8 (&a_lo8)[MF][KS / 4],
                                                       f32x4 (&acc)[2][MF]) {
   using C = F8Chunk<KS>;
   static_assert(MF == 2, "32 rows per wave");
-  bf16x8 w[2][2];
+  constexpr int SETS = DEPTH + 1;
+  bf16x8 w[SETS][2];
   auto read_step = [&](auto cs_tag, auto pinned_tag) {
     constexpr int cs = decltype(cs_tag)::value;
-    constexpr int S = cs % 2;
+    constexpr int S = cs % SETS;
     if constexpr (!decltype(pinned_tag)::value) w[S][0] = lds_read_frag<C::off(cs, 0)>(lds_addr);
     else w[S][0] = lds_read_frag_after<C::off(cs, 0), PIN_AGPR>(lds_addr, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
     w[S][1] = lds_read_frag<C::off(cs, 1)>(lds_addr);
   };
   auto mfma_step = [&](auto cs_tag) {
     constexpr int cs = decltype(cs_tag)::value;
-    constexpr int S = cs % 2;
+    constexpr int S = cs % SETS;
     if constexpr (!C::is_f8(cs)) {
       constexpr int ks = C::ks(cs);
 #pragma unroll
@@ -338,14 +342,13 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
   };
   const std::true_type yes{};
   const std::false_type no{};
-  read_step(std::integral_constant<int, 0>{}, no);
-  read_step(std::integral_constant<int, 1>{}, no);
+  static_for<(SETS < C::STEPS ? SETS : C::STEPS)>([&](auto t) { read_step(t, no); });
   static_for<C::STEPS>([&](auto t) {
     constexpr int cs = decltype(t)::value;
-    constexpr int ahead = cs + 1 < C::STEPS ? 1 : 0;
-    lds_wait2<2 * ahead>(w[cs % 2][0], w[cs % 2][1]);
+    constexpr int ahead = (C::STEPS - 1 - cs) < DEPTH ? (C::STEPS - 1 - cs) : DEPTH;
+    lds_wait2<2 * ahead>(w[cs % SETS][0], w[cs % SETS][1]);
     mfma_step(t);
-    if constexpr (cs + 2 < C::STEPS) read_step(std::integral_constant<int, cs + 2>{}, yes);
+    if constexpr (cs + SETS < C::STEPS) read_step(std::integral_constant<int, cs + SETS>{}, yes);
   });
 }
 
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         struct P1Off {
           static constexpr int at(int st, int jj) { return (2 * st + jj) * 1024; }
         };
-        frag_stream2<(F8 ? NF1 + NF1 / 2 : NF1), 2, P1Off>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+        frag_stream2<(F8 ? NF1 + NF1 / 2 : NF1), (F8 ? 4 : 2), P1Off>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int st = decltype(step_tag)::value;
           if constexpr (F8) {
             if constexpr (st < NF1) {  // fp16: fragments nf, nf + 1 of k-step ks
@@ -1075,6 +1078,29 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         });
 #endif
       };
+      // The same GeGLU as micro-operations [B, E) of its stage-major list (operation o = stage o / NV of value o % NV, 8 NV
+      // in all; the pack follows the last one): the F8 stream spreads a chunk's GeGLU evenly over ALL steps of the next
+      // chunk -- fp16 and e4m3 steps last 64 pipe cycles each and hide about as many vector instructions.
+      auto geglu_ops = [&](const f32x4 (&av)[2][MF], float (&gv)[MF][4], auto begin_tag, auto end_tag, auto&& pack) {
+        constexpr int B = decltype(begin_tag)::value, E = decltype(end_tag)::value;
+        static_for<E - B>([&](auto o_tag) {
+          constexpr int o = B + decltype(o_tag)::value;
+          constexpr int st = o / NV, i = o % NV, mf = i >> 2, r = i & 3;
+          if constexpr (st == 0) {
+            gx[i] = av[0][mf][r];
+            gq[i] = gelu_erf_poly(0.f, fabsf(gx[i]), 0);
+          } else if constexpr (st < 5) {
+            gq[i] = gelu_erf_poly(gq[i], fabsf(gx[i]), st);
+          } else if constexpr (st == 5) {
+            gq[i] = __builtin_amdgcn_exp2f(gq[i]);
+          } else if constexpr (st == 6) {
+            gq[i] = gelu_erf_finish(gq[i], gx[i]);
+          } else {
+            gv[mf][r] = gq[i] * av[1][mf][r];
+          }
+          if constexpr (o == 8 * NV - 1) static_for<MF>([&](auto mf_tag) { pack(mf_tag); });
+        });
+      };
       auto pack_h = [&](auto mf_tag) {  // second half of a pair -> the pair's h fragment of this row fragment
         constexpr int mf = decltype(mf_tag)::value;
 #ifdef OPK_ABL_NO_MLP_VALU
@@ -1167,6 +1193,10 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         }
       };
       constexpr int DEPTH = 2;  // fragment groups in flight ahead of the one being consumed (a step = 8 MFMAs)
+#ifndef OPK_F8_DEPTH
+#define OPK_F8_DEPTH 4
+#endif
+      constexpr int DEPTH8 = OPK_F8_DEPTH;  // F8: a chunk step is 4 fp16 / 2 e4m3 MFMAs = half the pipe time, twice the steps ahead
       // The stage index is a RUNTIME value here (one copy of the loop body): the fragment reads are inline asm with
       // the stage's base address in a register, so the compiler has no DMA-vs-read aliasing to resolve, and a body
       // unrolled by two would permute the 128 accumulator registers between its copies on every back edge.
@@ -1204,34 +1234,38 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         }
 #endif
         if constexpr (F8) {
+          // F8 stream order: chunk 2t -> na | chunk 2t+1 -> nb, GeGLU(2t) riding on its steps | slab t-1 (h of pair
+          // t-1 from the previous iteration), GeGLU(2t+1) riding on its steps and closing h of pair t.  No chunk
+          // accumulator crosses the back edge (only the 16 registers of h do): with one that did, the register
+          // allocator moved accumulators through VGPRs on every iteration (40 of 72 v_accvgpr moves, ~8 cycles each).
           using Off8 = MlpStreamOff8<KS, NF1, SLAB>;
           using C8 = F8Chunk<KS>;
           constexpr int CS = C8::STEPS;
-          frag_stream2<2 * CS + NS, DEPTH, Off8>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+          f32x4 nb[2][MF];
+          frag_stream2<2 * CS + NS, DEPTH8, Off8>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
             constexpr int s = decltype(step_tag)::value;
 #ifndef OPK_ABL_NO_DMA
             if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
 #endif
-            if constexpr (s < CS || s >= CS + NS) {  // a chunk step: chunk 2t into na, chunk 2t+1 into acc_b
+            if constexpr (s < 2 * CS) {  // a chunk step
               constexpr bool FIRST_CHUNK = s < CS;
-              constexpr int cs = FIRST_CHUNK ? s : s - CS - NS;
-              auto& acc = *(FIRST_CHUNK ? &na : &acc_b);
-              if constexpr (!C8::is_f8(cs)) {
-                chunk_step(acc, std::integral_constant<int, C8::ks(cs)>{}, w0, w1);
-                // the GeGLU slices ride on the fp16 steps: chunk 2t-1's on chunk 2t (-> h of pair t-1 ready for the
-                // slab), and in the first iteration (no slab yet) chunk 0's on chunk 1
-                if constexpr (FIRST_CHUNK && SLAB) geglu_slice(acc_b, g_prev, std::integral_constant<int, C8::ks(cs)>{}, pack_h);
-                if constexpr (!FIRST_CHUNK && !SLAB) geglu_slice(na, g_cur, std::integral_constant<int, C8::ks(cs)>{}, pack_hold);
-                interleave_n(std::integral_constant<int, 2 * MF>{}, std::integral_constant<int, 6>{});
-              } else {
-                chunk_step8(acc, std::integral_constant<int, C8::nf(cs)>{}, std::integral_constant<int, C8::s8(cs)>{}, w0, w1);
+              constexpr int cs = FIRST_CHUNK ? s : s - CS;
+              auto& acc = *(FIRST_CHUNK ? &na : &nb);
+              if constexpr (!C8::is_f8(cs)) chunk_step(acc, std::integral_constant<int, C8::ks(cs)>{}, w0, w1);
+              else chunk_step8(acc, std::integral_constant<int, C8::nf(cs)>{}, std::integral_constant<int, C8::s8(cs)>{}, w0, w1);
+              if constexpr (!FIRST_CHUNK) {  // GeGLU(2t), evenly over the steps of chunk 2t+1
+                constexpr int OB = cs * 8 * NV / CS, OE = (cs + 1) * 8 * NV / CS;
+                geglu_ops(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_hold);
               }
-            } else {  // slab t-1, with the GeGLU of chunk 2t
-              slab_pair(std::integral_constant<int, 2 * (s - CS)>{}, w0, w1);
-              geglu_slice(na, g_cur, std::integral_constant<int, s - CS>{}, pack_hold);
+              if constexpr (!C8::is_f8(cs)) interleave_n(std::integral_constant<int, 2 * MF>{}, std::integral_constant<int, 2>{});
+              else interleave_n(std::integral_constant<int, MF>{}, std::integral_constant<int, 5>{});
+            } else {  // slab t-1, with the GeGLU of chunk 2t+1
+              slab_pair(std::integral_constant<int, 2 * (s - 2 * CS)>{}, w0, w1);
+              geglu_slice(nb, g_prev, std::integral_constant<int, s - 2 * CS>{}, pack_h);
               interleave_n(std::integral_constant<int, 4 * MF>{}, std::integral_constant<int, 3>{});
             }
           });
+          if constexpr (!SLAB) static_for<KS>([&](auto sl) { geglu_slice(nb, g_prev, sl, pack_h); });  // first pair: no slab to ride on
         } else
         frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int s = decltype(step_tag)::value;
@@ -1276,7 +1310,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         } while (++t < n_pairs);
       }
       {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
-        static_for<KS>([&](auto sl) { geglu_slice(acc_b, g_prev, sl, pack_h); });
+        if constexpr (!F8) static_for<KS>([&](auto sl) { geglu_slice(acc_b, g_prev, sl, pack_h); });
         struct TailOff {
           static constexpr int at(int s, int j) { return (F8 ? 2 * F8Chunk<KS>::BYTES : 2 * KS * 2048) + (s * 2 + j) * 1024; }
         };
