@@ -266,6 +266,7 @@ class OpenProvenceConfig:
         cfg = cls.from_dict(payload)
         if cfg._name_or_path is None:
             cfg._name_or_path = str(Path(path).parent)
+        cfg._from_file = True  # (resolve_pruning_hidden_state: a checkpoint's config, not one built in code)
         return cfg
 
     def save_json(self, path: str | Path) -> None:

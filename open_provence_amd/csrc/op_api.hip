@@ -1140,9 +1140,9 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     if (dst_f8a) {  // "f16 + fp8" kernel set; raises the not-fp16 flag (any_lo_dev[OP_FAM_COUNT]) for a weight it cannot hold exactly
       int* not_f16 = h->any_lo_dev + OP_FAM_COUNT;
       if (pk_mode == 100 || pk_mode == 101)
-        hipLaunchKernelGGL(pack_kstream_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_f8a, dst_f8b, not_f16);
+        hipLaunchKernelGGL(pack_kstream_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_f8a, dst_f8b, zero_lo, not_f16);
       else
-        hipLaunchKernelGGL(pack_rowgemm_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_f8a, not_f16);
+        hipLaunchKernelGGL(pack_rowgemm_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_f8a, zero_lo, not_f16);
     }
     if (dst_p32)  // the 32x32x16 whole-layer kernel's order (hi plane; that kernel runs only when the lo planes are zero)
       hipLaunchKernelGGL(pack_layer32_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, p32_mode, p32_kmajor, H, I,

@@ -144,7 +144,7 @@ __global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, i
 // bf16 sets; every bf16 value in [2^-14, 65504] is an fp16 value).  Smaller weights land on the fp16 subnormal grid:
 // absolute error <= 2^-25 per weight, ~1e-6 on a logit.
 __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows, int K, int mode, int H, int I,
-                                       u16* __restrict__ dst, int* __restrict__ not_f16) {
+                                       u16* __restrict__ dst, int round_bf16, int* __restrict__ not_f16) {
   set_saturating_conversions();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_rows * K;
@@ -158,7 +158,8 @@ __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows
   const int ks = (int)(t % KS);
   const int c = (int)(t / KS);
   const int srow = rowgemm_source_row(mode, c, nf * 16 + i, H, I);
-  const float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
+  float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
+  if (round_bf16) v = bf2f(f2bf(v));  // a policy without the hi x lo(weight) term: the weight IS its bf16 rounding
   const _Float16 hv = (_Float16)v;
   if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;  // (below 2^-14: fp16 subnormal grid, |error| <= 2^-25)
   dst[((size_t)c * CP + ks * 2 + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
@@ -170,7 +171,7 @@ __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows
 // k-streamed weights of the "f16 + fp8" kernel set: fp16 slabs dst16[ks][nf][512] and (dst8 != nullptr, the attention
 // output projection) e4m3 slabs dst8[K-step S][nf][half][1 KiB]; `permute` as pack_kstream_kernel.
 __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst16,
-                                       u16* __restrict__ dst8, int* __restrict__ not_f16) {
+                                       u16* __restrict__ dst8, int round_bf16, int* __restrict__ not_f16) {
   set_saturating_conversions();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * K) return;
@@ -182,7 +183,8 @@ __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int
   const int nf = (int)(t % NF);
   const int ks = (int)(t / NF);
   const int row = permute ? (32 * (nf >> 1) + 8 * (i >> 2) + 4 * (nf & 1) + (i & 3)) : (nf * 16 + i);
-  const float v = src[(size_t)row * K + ks * 32 + g * 8 + e];
+  float v = src[(size_t)row * K + ks * 32 + g * 8 + e];
+  if (round_bf16) v = bf2f(f2bf(v));
   const _Float16 hv = (_Float16)v;
   if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;  // (below 2^-14: fp16 subnormal grid, |error| <= 2^-25)
   dst16[((size_t)ks * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);

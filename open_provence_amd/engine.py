@@ -143,6 +143,15 @@ class HipEncoder:
         if handle is not None and handle.value:
             self.lib.op_destroy(handle)
             self._handle = ctypes.c_void_p()
+        st = getattr(self, "_split_state", None)
+        if st is not None:  # the CU-masked streams were created through the HIP runtime directly: destroy them here
+            self._split_state = None
+            for raw in st.get("raw_streams", []):
+                try:
+                    st["hip"].hipStreamSynchronize(ctypes.c_void_p(raw))
+                    st["hip"].hipStreamDestroy(ctypes.c_void_p(raw))
+                except Exception:  # pragma: no cover - interpreter shutdown
+                    pass
 
     def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
         try:
@@ -239,22 +248,12 @@ class HipEncoder:
 
         Asynchronous on the current torch stream of ``self.device``."""
 
-        if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
-            raise TypeError("ids and cu_seqlens must be int32")
-        if ids.device != self.device or cu_seqlens.device != self.device:
-            raise ValueError(f"ids/cu_seqlens must live on {self.device}")
-        total = int(ids.numel())
-        n_seqs = int(cu_seqlens.numel()) - 1
+        total, n_seqs = self._check_packed_inputs(ids, cu_seqlens, keep_prob)
         cu_host = np.ascontiguousarray(cu_seqlens_host, dtype=np.int32)
         if cu_host.shape[0] != n_seqs + 1:
             raise ValueError("cu_seqlens_host length mismatch")
         prune = torch.empty((total, 2), dtype=torch.float32, device=self.device)
         rank = torch.empty((n_seqs, self.dims.num_labels), dtype=torch.float32, device=self.device)
-        if keep_prob is not None and (
-            keep_prob.dtype != torch.float32 or keep_prob.device != self.device or keep_prob.numel() != total
-            or not keep_prob.is_contiguous()
-        ):
-            raise ValueError("keep_prob must be a contiguous fp32 tensor of total_tokens elements on the encoder's device")
         if n_seqs == 0:
             return prune, rank
         ws = self._ensure_workspace(n_seqs, total, int(max_seqlen))
@@ -270,6 +269,21 @@ class HipEncoder:
                                  prune.data_ptr(), rank.data_ptr(), keep_prob.data_ptr() if keep_prob is not None else None,
                                  ws, stream)
         return prune, rank
+
+    def _check_packed_inputs(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, keep_prob: torch.Tensor | None) -> tuple[int, int]:
+        """Shared argument checks of forward_packed / forward_packed_on -> (total_tokens, n_seqs)."""
+
+        if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
+            raise TypeError("ids and cu_seqlens must be int32")
+        if ids.device != self.device or cu_seqlens.device != self.device:
+            raise ValueError(f"ids/cu_seqlens must live on {self.device}")
+        total = int(ids.numel())
+        if keep_prob is not None and (
+            keep_prob.dtype != torch.float32 or keep_prob.device != self.device or keep_prob.numel() != total
+            or not keep_prob.is_contiguous()
+        ):
+            raise ValueError("keep_prob must be a contiguous fp32 tensor of total_tokens elements on the encoder's device")
+        return total, int(cu_seqlens.numel()) - 1
 
     def _forward_native(self, ids_ptr, cu_ptr, cu_host: np.ndarray, n_seqs: int, total: int, max_seqlen: int,
                         prune_ptr, rank_ptr, keep_ptr, ws: torch.Tensor, stream: int) -> None:
@@ -300,6 +314,8 @@ class HipEncoder:
         if st is None:
             n_cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
             streams = []
+            raw_streams: list[int] = []
+            hip = None
             try:
                 hip = ctypes.CDLL("libamdhip64.so")
                 words = (n_cus + 31) // 32
@@ -312,10 +328,11 @@ class HipEncoder:
                         handle = ctypes.c_void_p()
                         if hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask) != 0:
                             raise OSError("hipExtStreamCreateWithCUMask failed")
+                        raw_streams.append(int(handle.value))
                         streams.append(torch.cuda.ExternalStream(handle.value, device=self.device))
             except (OSError, AttributeError):
                 streams = [torch.cuda.Stream(self.device) for _ in range(2)]
-            st = self._split_state = {"streams": streams, "ws": [None, None]}
+            st = self._split_state = {"streams": streams, "ws": [None, None], "raw_streams": raw_streams[: len(streams)] if len(raw_streams) == len(streams) else [], "hip": hip}
         return st
 
     def forward_packed_on(
@@ -336,15 +353,25 @@ class HipEncoder:
         drift apart and fill each other's gaps (xsmall, 2 x 128 pairs x 512 against 1 x 256: +3 % pairs/s, same box).
         Forking and joining the halves inside every forward instead re-aligns them each time and loses 4 %."""
 
-        if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
-            raise TypeError("ids and cu_seqlens must be int32")
-        total, n_seqs = int(ids.numel()), int(cu_seqlens.numel()) - 1
+        if part not in (0, 1):
+            raise ValueError("part must be 0 or 1")
+        if self._capture is not None:
+            raise RuntimeError("hidden-state capture is not available on the pipelined path (use forward_packed)")
+        total, n_seqs = self._check_packed_inputs(ids, cu_seqlens, keep_prob)
         cu_host = np.ascontiguousarray(cu_seqlens_host, dtype=np.int32)
+        if cu_host.shape[0] != n_seqs + 1:
+            raise ValueError("cu_seqlens_host length mismatch")
         st = self._split_streams()
         side = st["streams"][part]
-        with torch.cuda.device(self.device), torch.cuda.stream(side):
+        # The outputs are allocated on the CALLER's stream (its caching-allocator pool) and handed to the side stream
+        # with record_stream: a consumer that reads them on its own stream after waiting for pipeline_stream(part) can
+        # never see the block recycled by a later call while that read is still in flight.
+        with torch.cuda.device(self.device):
             prune = torch.empty((total, 2), dtype=torch.float32, device=self.device)
             rank = torch.empty((n_seqs, self.dims.num_labels), dtype=torch.float32, device=self.device)
+            prune.record_stream(side)
+            rank.record_stream(side)
+        with torch.cuda.device(self.device), torch.cuda.stream(side):
             if n_seqs == 0:
                 return prune, rank
             need = int(self.lib.op_workspace_bytes(self._handle, n_seqs, total, int(max_seqlen)))

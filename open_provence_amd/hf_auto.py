@@ -46,15 +46,18 @@ class OpenProvenceConfig(PretrainedConfig):  # same NAME as the native class: Au
     model_type = "open_provence"
 
     def __init__(self, **kwargs: Any) -> None:
-        self._native_keys = {k: kwargs[k] for k in list(kwargs) if k in _NATIVE_FIELDS}
-        for key in self._native_keys:
-            kwargs.pop(key)
+        native = {k: kwargs.pop(k) for k in list(kwargs) if k in _NATIVE_FIELDS}
+        # whether the source config.json carried num_labels (PretrainedConfig always has the attribute: default 2)
+        explicit_labels = "num_labels" in kwargs or "id2label" in kwargs
         super().__init__(**kwargs)
-        for key, value in self._native_keys.items():
+        for key, value in native.items():
             setattr(self, key, value)
+        if not explicit_labels:
+            self.num_labels = 1  # the reference's default (standalone.py:1279)
 
     def to_native(self) -> NativeConfig:
         payload = {k: getattr(self, k) for k in _NATIVE_FIELDS if hasattr(self, k)}
+        payload["num_labels"] = int(self.num_labels)  # ranking head width: a checkpoint with num_labels != 1 must keep it
         for extra in ("transformers_version",):
             if getattr(self, extra, None) is not None:
                 payload[extra] = getattr(self, extra)

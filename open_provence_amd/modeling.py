@@ -145,8 +145,15 @@ def resolve_pruning_hidden_state(config: OpenProvenceConfig, override: str | Non
     (utils/output_capturing.py:269-277); the 4.x line the reference pins (uv.lock: 4.57.1) appended the last layer's
     output BEFORE ``final_norm`` -- so a released checkpoint's head was trained on, and the reference under its own
     lock evaluates, the un-normalised state.  Order of precedence: the ``pruning_hidden_state`` argument, the config
-    field of the same name, then ``"auto"``: the ``transformers_version`` HF wrote into the checkpoint's config.json
-    (major < 5 -> pre-norm), and post-norm -- what the reference computes in this image -- when nothing is recorded."""
+    field of the same name (``save_pretrained`` always writes it, so the guess below runs at most once per checkpoint),
+    then ``"auto"``, a HEURISTIC that is logged as a warning because it changes pruning logits by > 0.1:
+    * the ``transformers_version`` HF wrote into config.json (major < 5 -> pre-norm).  That stamp names the environment
+      that last SAVED the config, not the one that trained the head: a 4.x checkpoint re-saved through a 5.x config
+      path flips -- pass ``pruning_hidden_state=`` explicitly for such files;
+    * no stamp, config read from a checkpoint directory: pre-norm (the reference's lock is 4.57.1: released
+      checkpoints were trained on the un-normalised state);
+    * no stamp, config built in code: the installed transformers' behaviour (post-norm under >= 5 -- what the
+      reference computes in this image -- else pre-norm)."""
 
     choice = override or getattr(config, "extra", {}).get("pruning_hidden_state") or "auto"
     if choice in ("post_final_norm", "pre_final_norm"):
@@ -155,10 +162,25 @@ def resolve_pruning_hidden_state(config: OpenProvenceConfig, override: str | Non
         raise ValueError("pruning_hidden_state must be 'auto', 'post_final_norm' or 'pre_final_norm'")
     version = str(getattr(config, "extra", {}).get("transformers_version") or "")
     try:
-        major = int(version.split(".")[0])
+        major: int | None = int(version.split(".")[0])
     except ValueError:
-        return "post_final_norm"
-    return "pre_final_norm" if major < 5 else "post_final_norm"
+        major = None
+    if major is not None:
+        resolved, why = ("pre_final_norm" if major < 5 else "post_final_norm"), f"config.json transformers_version={version}"
+    elif getattr(config, "_from_file", False):
+        resolved, why = "pre_final_norm", "checkpoint config without a transformers_version stamp (reference lock: 4.57.1)"
+    else:
+        try:
+            import importlib.metadata as _md
+
+            installed = int(_md.version("transformers").split(".")[0])
+        except Exception:  # transformers absent: nothing to imitate
+            installed = 5
+        resolved = "pre_final_norm" if installed < 5 else "post_final_norm"
+        why = f"config built in code, installed transformers major {installed}"
+    LOGGER.warning("pruning_hidden_state='auto' resolved to %r (%s); pass pruning_hidden_state= or set it in config.json "
+                   "to pin it", resolved, why)
+    return resolved
 
 
 class OpenProvenceModel:
@@ -396,6 +418,7 @@ class OpenProvenceModel:
         else:
             config = OpenProvenceConfig.from_json_file(directory / "config.json")
         config._name_or_path = str(directory)
+        config._from_file = True  # every route here reads a checkpoint's config.json (resolve_pruning_hidden_state)
         if "dtype" in kwargs and torch_dtype is None:
             torch_dtype = kwargs.pop("dtype")
         # HF plumbing the Auto* factories add; the HIP attention kernel is the only attention implementation

@@ -277,8 +277,8 @@ def _int_list(ids: Any) -> list[int]:
     """``[int(t) for t in ids]`` without the per-token call when ``ids`` already is a list of Python ints (what HF
     fast tokenizers and this module's own stages hand over): the hot loops below copy ~500 ids per context."""
 
-    if type(ids) is list and (not ids or (type(ids[0]) is int and type(ids[-1]) is int)):
-        return ids
+    if type(ids) is list and (not ids or (type(ids[0]) is int and type(ids[-1]) is int and set(map(type, ids)) == {int})):
+        return ids  # the caller's list, NOT a copy: callers below never mutate it and copy where a row leaves this module
     return [int(t) for t in ids]
 
 
@@ -480,7 +480,7 @@ def prepare_block_inputs(
         if manual_sep is not None and ctx:
             ids.append(manual_sep)
     else:
-        ids = built if built else query + ctx
+        ids = list(built) if built else query + ctx  # a fresh list: the row is handed to the batch, `built` may alias the tokenizer's
 
     try:
         type_ids = tokenizer.create_token_type_ids_from_sequences(query, ctx)
@@ -491,8 +491,11 @@ def prepare_block_inputs(
     ranges: list[tuple[int, int]] = []
     if ctx:
         start = _find_subsequence(ids, ctx)
-        if start < 0:
-            start = len(build_inputs_with_special_tokens(tokenizer, query, []))
+        if start < 0:  # (ref :2176-2178; cannot happen on the manual path, whose layout is known)
+            if manual_specials:
+                start = (1 if manual_cls is not None else 0) + len(query) + (1 if manual_sep is not None else 0)
+            else:
+                start = len(build_inputs_with_special_tokens(tokenizer, query, []))
         cursor = start
         for frag in fragments:
             ranges.append((cursor, cursor + len(frag.token_ids)))

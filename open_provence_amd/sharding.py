@@ -157,13 +157,15 @@ class ShardPlan:
         """ONE ``torch.distributed.gather`` of the fixed-size payloads to ``dst`` (no size exchange: every rank derives
         the sizes from the plan).  Returns ``unpack`` of the bucket on ``dst``, ``None`` elsewhere."""
 
-        me = dist.get_rank(group)
+        me = dist.get_rank(group)  # rank INSIDE the group: what shards / tokens are indexed by, and what `dst` names
         payload = self.pack(me, values, rank_logits)
+        # torch.distributed.gather takes the GLOBAL rank of the destination: translate for a real sub-group
+        dst_global = dist.get_global_rank(group, dst) if group is not None and group is not dist.group.WORLD else dst
         if me == dst:
             bucket = torch.empty(self.world_size * self.payload_size, dtype=torch.float32, device=payload.device)
-            dist.gather(payload, gather_list=list(bucket.split(self.payload_size)), dst=dst, group=group)
+            dist.gather(payload, gather_list=list(bucket.split(self.payload_size)), dst=dst_global, group=group)
             return self.unpack(bucket)
-        dist.gather(payload, gather_list=None, dst=dst, group=group)
+        dist.gather(payload, gather_list=None, dst=dst_global, group=group)
         return None
 
 
@@ -183,8 +185,8 @@ def gather_row_outputs(
     world = dist.get_world_size(group)
     me = dist.get_rank(group)
     nl = rank_logits.shape[1] if rank_logits.ndim == 2 else 1
-    plan = ShardPlan(lengths, world, width=2, num_labels=nl)
-    if [list(s) for s in shards] != plan.shards or list(local_rows) != plan.shards[me]:
+    plan = ShardPlan(lengths, world, width=2, num_labels=nl, shards=[list(s) for s in shards])  # any assignment of rows to ranks
+    if list(local_rows) != plan.shards[me]:
         raise ValueError("local outputs do not match this rank's shard")
     out = plan.gather(prune, rank_logits, dst=dst, group=group)
     if out is None:

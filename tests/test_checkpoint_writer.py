@@ -137,3 +137,43 @@ def test_reference_reads_the_written_checkpoint_report():
     assert report["reference_on_written_checkpoint_vs_oracle"]["max_abs_prune"] < 5e-5
     assert report["reference_on_written_checkpoint_vs_oracle"]["max_abs_rank"] < 5e-5
     assert "all_tied_weights_keys" in report["reference_from_pretrained"]
+
+
+def test_hf_config_round_trips_num_labels_and_serialises_no_bookkeeping():
+    """AutoConfig route: a checkpoint with num_labels != 1 keeps its ranking-head width in the native config, the
+    default stays the reference's 1 (standalone.py:1279), and config.json gets no private bookkeeping keys."""
+
+    from open_provence_amd.hf_auto import OpenProvenceHFConfig
+
+    three = OpenProvenceHFConfig(base_model_config=BASE, pruning_config={"hidden_size": 128}, max_length=96, num_labels=3)
+    assert three.to_native().num_labels == 3
+    assert three.to_native().encoder_dims().num_labels == 3
+    plain = OpenProvenceHFConfig(base_model_config=BASE, pruning_config={"hidden_size": 128}, max_length=96)
+    assert plain.to_native().num_labels == 1
+    payload = three.to_dict()
+    assert not any(key.startswith("_native") for key in payload), sorted(payload)
+    again = OpenProvenceHFConfig(**{k: v for k, v in payload.items() if k != "model_type"})
+    assert again.to_native().num_labels == 3 and again.to_native().max_length == 96
+
+
+def test_pruning_hidden_state_auto_is_logged_and_defaults_by_origin(caplog):
+    """'auto' is a heuristic that changes pruning logits: it is logged, a stamped config follows its stamp, an unstamped
+    CHECKPOINT config takes the reference lock's convention (transformers 4.57.1 = pre-norm), an explicit value wins."""
+
+    import logging
+
+    from open_provence_amd.modeling import resolve_pruning_hidden_state
+
+    base = dict(base_model_config=BASE, pruning_config={"hidden_size": 128})
+    with caplog.at_level(logging.WARNING, logger="open_provence_amd.modeling"):
+        assert resolve_pruning_hidden_state(OpenProvenceConfig(**base, transformers_version="4.57.1")) == "pre_final_norm"
+        assert resolve_pruning_hidden_state(OpenProvenceConfig(**base, transformers_version="5.15.0")) == "post_final_norm"
+        from_file = OpenProvenceConfig(**base)
+        from_file._from_file = True
+        assert resolve_pruning_hidden_state(from_file) == "pre_final_norm"
+    assert sum("pruning_hidden_state='auto'" in r.getMessage() for r in caplog.records) == 3
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="open_provence_amd.modeling"):
+        assert resolve_pruning_hidden_state(OpenProvenceConfig(**base, pruning_hidden_state="post_final_norm")) == "post_final_norm"
+        assert resolve_pruning_hidden_state(from_file, "post_final_norm") == "post_final_norm"
+    assert not caplog.records

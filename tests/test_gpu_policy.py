@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 NO_POLICY_KERNELS = 16  # OP_FLAG_NO_POLICY_KERNELS
 NO_LAYER_FUSION = 32    # OP_FLAG_NO_LAYER_FUSION: two fused kernels per layer (the shape the all-terms set has too)
 LAYER_M32 = 128         # OP_FLAG_LAYER_M32: the whole-layer kernel on 32x32x16 MFMAs (hidden = 256)
+NO_F8 = 512             # OP_FLAG_NO_F8: keep the (hi, lo) bf16 whole-layer kernel (kernel set "bf16-weights")
 
 
 @pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
@@ -83,15 +84,17 @@ def test_whole_layer_kernel_matches_two_kernel_path(fixture):
              for k, v in state_from_fixture(arrays, meta).items()}
     rows = rows_from_fixture(arrays)
     outs = {}
-    for label, flags in (("layer", 0), ("two", NO_LAYER_FUSION)):
+    # default flags: kernel set "f16-f8" (fp16 hi + e4m3 lo operands in the whole-layer kernel: 1.5 MFMA units per
+    # product); NO_F8: the same launch on (hi, lo) bf16 operands; NO_LAYER_FUSION: two kernels per layer
+    for label, flags, kernel_set in (("f8", 0, "f16-f8"), ("layer", NO_F8, "bf16-weights"), ("two", NO_LAYER_FUSION, "bf16-weights")):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
         enc.load_state_dict(state)
-        assert enc.effective_policy()["kernel_set"] == "bf16-weights"
+        assert enc.effective_policy()["kernel_set"] == kernel_set
         enc.profile_enable(True)
         prune, rank, _ = enc.forward_rows(rows)
         torch.cuda.synchronize()
         kinds = set(enc.profile_read())
-        assert ("fused_layer_attnout_mlp_qkv" in kinds) == (label == "layer"), kinds
+        assert ("fused_layer_attnout_mlp_qkv" in kinds) == (label != "two"), kinds
         outs[label] = (prune.cpu().numpy(), rank.cpu().numpy())
         enc.close()
     scale = max(1.0, float(np.abs(outs["two"][0]).max()))
@@ -100,8 +103,9 @@ def test_whole_layer_kernel_matches_two_kernel_path(fixture):
     ids, mask = pad_rows(rows)
     ref = oracle_forward(state, dims, ids, mask)
     m = mask.bool().numpy()
-    assert np.abs(outs["layer"][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3
-    assert np.abs(outs["layer"][1] - ref.ranking_logits.numpy()).max() < 1e-3
+    for label in ("f8", "layer"):  # tolerance of the path: 1e-3 on logits against the CPU reference arithmetic
+        assert np.abs(outs[label][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3, label
+        assert np.abs(outs[label][1] - ref.ranking_logits.numpy()).max() < 1e-3, label
 
 
 @pytest.mark.parametrize("fixture", ["g1_xsmall", "g7_xsmall_refinit", "g1m_meanpool"])
@@ -122,7 +126,7 @@ def test_layer32_kernel_matches_the_default_kernel(fixture, precision):
              for k, v in state_from_fixture(arrays, meta).items()}
     rows = rows_from_fixture(arrays)
     outs = {}
-    for label, flags in (("m16", 0), ("m32", LAYER_M32)):
+    for label, flags in (("m16", NO_F8), ("m32", LAYER_M32)):
         enc = HipEncoder(dims, device="cuda:0", precision=precision, flags=flags)
         enc.load_state_dict(state)
         enc.profile_enable(True)
@@ -177,7 +181,7 @@ def test_embedding_and_head_inside_the_first_and_last_kernels(fixture):
     scale = max(1.0, float(np.abs(outs["separate"][0]).max()))
     assert np.abs(outs["fused"][0] - outs["separate"][0]).max() < 3e-4 * scale
     assert np.abs(outs["fused"][1] - outs["separate"][1]).max() < 3e-4 * scale
-    # bf16 checkpoint + default policy against the reference outputs: the bar
+    # the fixture's own (fp32) weights, default policy, no capture, against the REFERENCE outputs stored in the fixture:
+    # the bar, on every fixture (fp32 weights carry their lo planes: all-terms kernel set, two kernels per layer)
     rep = run_fixture_on_gpu(fixture, "bf16x3", capture=False)
-    if "refinit" in fixture:  # (the O(1)-weight fixtures need their fp32 lo planes: checked with capture in test_gpu_parity)
-        assert rep["prune_max_err"] < 1e-3 and rep["rank_max_err"] < 1e-3
+    assert rep["prune_max_err"] < 1e-3 and rep["rank_max_err"] < 1e-3, rep

@@ -1,0 +1,98 @@
+"""The configuration ``bench.py`` TIMES, checked against the oracle (GPU).
+
+``bench.py`` (BASELINE.json configs[1]): xsmall dims, 256 pairs x 512 tokens, synthetic weights of seed 7 -- by default
+rounded to bf16 (a bf16 checkpoint), or kept fp32 (``--weights fp32``) -- default flags, no hidden-state capture, the
+batch either as ONE launch sequence (``forward_packed``) or as TWO half-batch sequences on CU-partitioned streams
+(``forward_packed_on``).  At that size every launch runs its large-batch form (128-row blocks; the layer-0 q / k / v
+kernel gathers the embeddings itself over 1024 blocks; the last whole-layer launch carries final_norm + the pruning
+head), which the small fixtures of the other parity tests never reach.  Here exactly that path runs and spread pairs --
+the first and the last pair of each half included -- are compared with ``oracle_forward`` on the same weights.
+
+Tolerance of the path (north_star): 1e-3 on pruning and ranking logits against the CPU reference arithmetic
+(reference forward: standalone.py:1686-1719 + HF modeling_modernbert.py:434-652, restated in oracle/modernbert_oracle.py).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PAIRS, SEQ_LEN = 256, 512
+CHECKED = [0, 1, 63, 126, 127, 128, 129, 200, 254, 255]  # first / last pair of each half of the batch, and spread ones
+
+
+def _bench_setup(weights: str):
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict
+
+    dims = named_dims("xsmall")
+    state = synth_state_dict(dims, seed=7)
+    if weights == "bf16":  # exactly bench.py's rounding of the GEMM weights
+        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    rows = synth_pair_batch(dims, PAIRS, SEQ_LEN, seed=1234)
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)  # default flags, as the driver's bench run
+    enc.load_state_dict(state)
+    return dims, state, rows, enc
+
+
+def _oracle(state, dims, rows):
+    from open_provence_amd.synthetic import pad_rows
+    from oracle.modernbert_oracle import oracle_forward
+
+    ids, mask = pad_rows(rows)
+    with torch.no_grad():
+        ref = oracle_forward(state, dims, ids, mask, attn="sdpa")
+    return ref.pruning_logits.numpy(), ref.ranking_logits.numpy()
+
+
+@pytest.mark.parametrize("weights,kernel_set", [("bf16", "f16-f8"), ("fp32", "bf16x3")])
+def test_bench_configuration_matches_the_oracle(weights, kernel_set):
+    from open_provence_amd.packing import pack_rows
+
+    dims, state, rows, enc = _bench_setup(weights)
+    assert enc.effective_policy()["kernel_set"] == kernel_set
+    dev = enc.device
+
+    # one launch sequence over the whole batch (bench.py: one_pipeline / every rank of a multi-GPU run)
+    ids_np, cu_np, max_len = pack_rows(rows)
+    ids, cu = torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev)
+    enc.profile_enable(True)
+    prune1, rank1 = enc.forward_packed(ids, cu, cu_np, max_len)
+    torch.cuda.synchronize()
+    kinds = set(enc.profile_read())
+    enc.profile_enable(False)
+    # the launches bench.py times: no embedding / final-norm launches, the large-batch q / k / v kernel with the gather
+    assert "embed_ln" not in kinds and "rowgemm_ln_qkv_rope" in kinds, kinds
+    if weights == "bf16":
+        assert "fused_layer_attnout_mlp_qkv" in kinds and "final_ln_prune" not in kinds, kinds
+    else:
+        assert "fused_attnout_ln_wi_geglu" in kinds and "fused_mlpout_ln_qkv_rope" in kinds, kinds
+    prune1, rank1 = prune1.cpu().numpy().reshape(PAIRS, SEQ_LEN, 2), rank1.cpu().numpy()
+
+    # two half-batch launch sequences on CU-partitioned streams (bench.py: the headline `value`)
+    half = PAIRS // 2
+    outs = []
+    for part, part_rows in enumerate((rows[:half], rows[half:])):
+        p_ids_np, p_cu_np, p_max = pack_rows(part_rows)
+        p_ids, p_cu = torch.from_numpy(p_ids_np).to(dev), torch.from_numpy(p_cu_np).to(dev)
+        torch.cuda.synchronize()
+        outs.append(enc.forward_packed_on(part, p_ids, p_cu, p_cu_np, p_max))
+    for part in range(2):
+        enc.pipeline_stream(part).synchronize()
+    prune2 = np.concatenate([o[0].cpu().numpy() for o in outs]).reshape(PAIRS, SEQ_LEN, 2)
+    rank2 = np.concatenate([o[1].cpu().numpy() for o in outs])
+    enc.close()
+
+    assert np.isfinite(prune1).all() and np.isfinite(rank1).all()
+    # a pair's outputs do not depend on its batch companions, the chunking or the CUs that ran it: bit for bit
+    assert np.array_equal(prune1, prune2) and np.array_equal(rank1, rank2)
+
+    ref_prune, ref_rank = _oracle(state, dims, [rows[i] for i in CHECKED])
+    got_prune, got_rank = prune1[CHECKED], rank1[CHECKED]
+    assert np.abs(got_prune - ref_prune).max() < 1e-3, float(np.abs(got_prune - ref_prune).max())
+    assert np.abs(got_rank - ref_rank).max() < 1e-3, float(np.abs(got_rank - ref_rank).max())
+    # the decision quantity of process(): keep-probabilities (standalone.py:2918-2924)
+    keep = 1.0 / (1.0 + np.exp(-(got_prune[..., 1] - got_prune[..., 0]).astype(np.float64)))
+    keep_ref = 1.0 / (1.0 + np.exp(-(ref_prune[..., 1] - ref_prune[..., 0]).astype(np.float64)))
+    assert np.abs(keep - keep_ref).max() < 1e-3

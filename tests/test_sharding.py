@@ -187,3 +187,46 @@ def test_split_plans_gather_each_half_in_row_order(tmp_path, world):
         rows_j, tok, rk = got[j]
         want = torch.cat([torch.arange(lengths[i], dtype=torch.float32) + 1000.0 * i for i in rows_j])
         assert torch.equal(tok, want) and torch.equal(rk, torch.tensor([float(i) for i in rows_j]))
+
+
+def _subgroup_worker(rank, world, port, lengths, out_path):
+    """World of 3, group = global ranks (1, 2): the gather's root is GROUP rank 0 = GLOBAL rank 1."""
+
+    from open_provence_amd.sharding import ShardPlan, gather_row_outputs
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        group = dist.new_group(ranks=[1, 2])
+        if rank in (1, 2):
+            me = dist.get_rank(group)
+            plan = ShardPlan(lengths, 2, width=1, num_labels=1)
+            rows = plan.local_rows(me)
+            values = torch.cat([torch.full((lengths[i],), float(i)) for i in rows]) if rows else torch.zeros(0)
+            logits = torch.tensor([[10.0 * i] for i in rows], dtype=torch.float32).reshape(len(rows), 1)
+            out = plan.gather(values, logits, dst=0, group=group)
+            assert (out is not None) == (me == 0)
+            # explicit (non-default) shards through the legacy entry point
+            custom = [[i for i in range(len(lengths)) if i % 2 == 0], [i for i in range(len(lengths)) if i % 2 == 1]]
+            prune = torch.cat([torch.full((lengths[i], 2), float(i)) for i in custom[me]])
+            rk = torch.tensor([[float(i)] for i in custom[me]], dtype=torch.float32)
+            legacy = gather_row_outputs(prune, rk, custom[me], lengths, custom, dst=0, group=group)
+            if me == 0:
+                torch.save({"tok": out[0], "rank": out[1], "legacy_rows": legacy[0], "legacy_rank": legacy[1]}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_on_a_real_sub_group_translates_the_root_rank(tmp_path):
+    lengths = [5, 3, 8, 2, 7]
+    out_path = str(tmp_path / "sub.pt")
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), lengths, out_path), nprocs=3, join=True)
+    got = torch.load(out_path)
+    expect_tok = torch.cat([torch.full((n,), float(i)) for i, n in enumerate(lengths)]).reshape(-1, 1)
+    assert torch.equal(got["tok"], expect_tok)
+    assert torch.equal(got["rank"], torch.tensor([[10.0 * i] for i in range(len(lengths))]))
+    assert [t.shape[0] for t in got["legacy_rows"]] == lengths
+    assert all(torch.all(t == float(i)) for i, t in enumerate(got["legacy_rows"]))
+    assert torch.equal(got["legacy_rank"], torch.tensor([[float(i)] for i in range(len(lengths))]))
