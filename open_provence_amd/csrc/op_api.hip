@@ -331,7 +331,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   OP_TRY(L.end());
 
   // rows >= `rows` are never produced by the attention kernel: keep its output finite there
-  const bool o_f8 = h->pi == opl::PI_F16_F8 && !h->emulate;  // o = fp16 pieces (ws.o_hi) + e4m3 pieces (ws.o_lo)
+  const bool o_f8 = (h->pi == opl::PI_F16_F8 || h->pi == opl::PI_F16_F8_W) && !h->emulate;  // o = fp16 pieces (ws.o_hi) + e4m3 pieces (ws.o_lo)
   if (fp_layout && o_f8) {
     const size_t n16 = (size_t)((r_pad - rows) / 16);
     if (n16) OP_HIP(h, hipMemsetAsync(ws.o_hi + (size_t)(rows / 16) * (H / 32) * 512, 0, n16 * (H / 32) * 512 * sizeof(u16), st));
@@ -940,12 +940,12 @@ int op_create(const op_config* cfg, op_handle** out) {
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
-      if (h->f8_packs) {  // 3 bytes per weight element: fp16 + e4m3
-        OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_f8, 3 * HH * 3 / 2));
-        OP_CREATE_TRY(dev_alloc(h, &lw.wi_f8, (size_t)2 * I * H * 3 / 2));
+      if (h->f8_packs) {  // 4 bytes per weight element: fp16 + e4m3 + e4m3 of the lo part (bf16 for the MLP's Wo)
+        OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_f8, 3 * HH * 2));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wi_f8, (size_t)2 * I * H * 2));
         OP_CREATE_TRY(dev_alloc(h, &lw.wo_f16, HH));
-        OP_CREATE_TRY(dev_alloc(h, &lw.wo_f8, HH / 2));
-        OP_CREATE_TRY(dev_alloc(h, &lw.wo2_f16, (size_t)H * I));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo_f8, HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo2_f16, (size_t)2 * H * I));
       }
       if (h->row_path && H == 256) {
         OP_CREATE_TRY(dev_alloc(h, &lw.wo_p32, HH));
@@ -1185,9 +1185,11 @@ int resolve_policy(op_handle* h) {
       }
     // bf16-valued weights that are also exact fp16 values, on the whole-layer kernel's shapes: the "f16 + fp8" kernel
     // set evaluates the same terms at 1.5 instead of 2 MFMA units per product (op_internal.h)
-    if (!h->emulate && h->pi == opl::PI_BF16_WEIGHTS && h->f8_packs && !any_lo[OP_FAM_COUNT] &&
-        !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32)))
-      h->pi = opl::PI_F16_F8;
+    const bool f8_ok = !h->emulate && h->f8_packs && !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32));
+    if (f8_ok && h->pi == opl::PI_BF16_WEIGHTS && !any_lo[OP_FAM_COUNT]) h->pi = opl::PI_F16_F8;
+    // every term requested and carried (fp32-valued weights): the same format with the weights' lo part as a third
+    // plane -- one kernel per layer at 2 MFMA units per product instead of two kernels at 3
+    if (f8_ok && h->pi == opl::PI_ALL_TERMS) h->pi = opl::PI_F16_F8_W;
   } else if (opl::kPolicies[0] == e) {
     h->emulate = false;
   }

@@ -36,13 +36,17 @@ struct Policy {
 //                             units per product instead of 2 (hidden <= 256, weights exactly representable in fp16;
 //                             layer-0 q / k / v and attention run set 1's kernels, attention writes o in the new format).
 //                             Never matched by terms (operator== ignores fmt): resolve_policy() upgrades 1 -> 3.
+//   4  f16 + fp8, all terms   the terms of set 0 (fp32-valued weights) in the same format: the weight's lo part rides as a
+//                             third e4m3 plane (bf16 for the MLP output projection): 2 MFMA units per product instead of 3,
+//                             and ONE kernel per layer where set 0 needs two with h through HBM.  resolve_policy(): 0 -> 4.
 constexpr Policy kPolicies[] = {
     {3, 3, 3, 3, 3, 3},
     {1, 3, 3, 1, 1, 1},
     {0, 0, 0, 0, 0, 0},
     {1, 3, 3, 1, 1, 1, 1},
+    {3, 3, 3, 3, 3, 3, 1},
 };
-constexpr int PI_BF16_WEIGHTS = 1, PI_F16_F8 = 3;
+constexpr int PI_ALL_TERMS = 0, PI_BF16_WEIGHTS = 1, PI_F16_F8 = 3, PI_F16_F8_W = 4;
 constexpr int N_POLICIES = (int)(sizeof(kPolicies) / sizeof(kPolicies[0]));
 
 // template arguments each kernel family derives from a policy
@@ -61,6 +65,7 @@ bool launch_row_layer_fused(hipStream_t st, const opk::RowGemmParams& p, int ks,
                             bool waves8);
 // ... of the "f16 + fp8" kernel set (hidden 128 / 256)
 bool launch_row_layer_f8(hipStream_t st, const opk::RowGemmParams& p, int ks, bool with_qkv, unsigned grid);
+bool launch_row_layer_f8w(hipStream_t st, const opk::RowGemmParams& p, int ks, bool with_qkv, unsigned grid);  // kernel set 4
 // the same launch on the 32x32x16 shape (hidden = 256; kernel sets 1 and 2)
 bool has_layer32(int pi);
 bool launch_layer32(hipStream_t st, const opk::Layer32Params& p, int pi, bool with_qkv, unsigned grid);

@@ -32,12 +32,13 @@ bool launch_attn(hipStream_t st, const AttnFpParams& p, int waves, int kt, int p
     else return false;
     return true;
   }
-  static_assert(N_POLICIES == 4, "extend the switch below");
+  static_assert(N_POLICIES == 5, "extend the switch below");
   switch (pi) {
     case 0: return launch_pi<0>(st, p, waves, kt, grid);
     case 1: return launch_pi<1>(st, p, waves, kt, grid);
     case 2: return launch_pi<2>(st, p, waves, kt, grid);
     case 3: return launch_pi<3>(st, p, waves, kt, grid);
+    case 4: return launch_pi<4>(st, p, waves, kt, grid);
     default: return false;
   }
 }

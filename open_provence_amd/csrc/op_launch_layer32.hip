@@ -30,12 +30,13 @@ bool has_layer32(int pi) {
 }
 
 bool launch_layer32(hipStream_t st, const Layer32Params& p, int pi, bool with_qkv, unsigned grid) {
-  static_assert(N_POLICIES == 4, "extend the switch");
+  static_assert(N_POLICIES == 5, "extend the switch");
   switch (pi) {
     case 0: return launch_pi<0>(st, p, with_qkv, grid);
     case 1: return launch_pi<1>(st, p, with_qkv, grid);
     case 2: return launch_pi<2>(st, p, with_qkv, grid);
-    case 3: return false;  // kernel set 3 has its own whole-layer kernel
+    case 3:
+    case 4: return false;  // kernel sets 3 and 4 have their own whole-layer kernel
     default: return false;
   }
 }

@@ -35,23 +35,25 @@ void launch_qkv_pi(hipStream_t st, const PanelParams& p, dim3 grid) {
 }  // namespace
 
 bool launch_panel_qkv(hipStream_t st, const PanelParams& p, int pi, dim3 grid) {
-  static_assert(N_POLICIES == 4, "extend the switch below");
+  static_assert(N_POLICIES == 5, "extend the switch below");
   switch (pi) {
     case 0: launch_qkv_pi<0>(st, p, grid); return true;
     case 1: launch_qkv_pi<1>(st, p, grid); return true;
     case 2: launch_qkv_pi<2>(st, p, grid); return true;
     case 3: launch_qkv_pi<1>(st, p, grid); return true;
+    case 4: launch_qkv_pi<0>(st, p, grid); return true;
     default: return false;
   }
 }
 
 bool launch_panel(hipStream_t st, const PanelParams& p, int epi, int pi, dim3 grid) {
-  static_assert(N_POLICIES == 4, "extend the switch below");
+  static_assert(N_POLICIES == 5, "extend the switch below");
   switch (pi) {
     case 0: return launch_pi<0>(st, p, epi, grid);
     case 1: return launch_pi<1>(st, p, epi, grid);
     case 2: return launch_pi<2>(st, p, epi, grid);
     case 3: return launch_pi<1>(st, p, epi, grid);
+    case 4: return launch_pi<0>(st, p, epi, grid);
     default: return false;
   }
 }

@@ -30,12 +30,13 @@ bool launch_ks(hipStream_t st, const RowGemmParams& p, int ks, bool small, unsig
 
 // (kernel set 3 = the operand terms of set 1; only the whole-layer kernel has its own instantiation: OPL_ROW_PART 4)
 #define OPL_SWITCH(CALL)                              \
-  static_assert(N_POLICIES == 4, "extend the switch"); \
+  static_assert(N_POLICIES == 5, "extend the switch"); \
   switch (pi) {                                       \
     case 0: return CALL(0);                           \
     case 1: return CALL(1);                           \
     case 2: return CALL(2);                           \
     case 3: return CALL(1);                           \
+    case 4: return CALL(0);                           \
     default: return false;                            \
   }
 
@@ -112,10 +113,13 @@ bool launch_layer_pi(hipStream_t st, const RowGemmParams& p, int ks, bool with_q
 }
 }  // namespace
 
-bool has_row_layer_fused(int pi) { return pi >= 0 && pi < N_POLICIES && (kPolicies[pi].wi & 2) == 0 && (kPolicies[pi].mlp_out & 2) == 0; }
+bool has_row_layer_fused(int pi) {
+  return pi == PI_F16_F8_W || (pi >= 0 && pi < N_POLICIES && (kPolicies[pi].wi & 2) == 0 && (kPolicies[pi].mlp_out & 2) == 0);
+}
 
 bool launch_row_layer_fused(hipStream_t st, const RowGemmParams& p, int ks, int pi, bool with_qkv, unsigned grid, bool waves8) {
   if (pi == PI_F16_F8) return !waves8 && launch_row_layer_f8(st, p, ks, with_qkv, grid);
+  if (pi == PI_F16_F8_W) return !waves8 && launch_row_layer_f8w(st, p, ks, with_qkv, grid);
 #define OPL_CALL(PI) (launch_layer_pi<PI>(st, p, ks, with_qkv, grid, waves8))
   OPL_SWITCH(OPL_CALL)
 #undef OPL_CALL
@@ -129,10 +133,10 @@ template <int KS>
 void launch_layer_f8_ks(hipStream_t st, const RowGemmParams& p, bool with_qkv, unsigned grid) {
   constexpr Policy P = kPolicies[PI_F16_F8];
   if (with_qkv)
-    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, P.attn_out, P.wqkv, qkv_olo(P), 4, 2, P.wi, P.mlp_out, true>), dim3(grid),
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, P.attn_out, P.wqkv, qkv_olo(P), 4, 2, P.wi, P.mlp_out, 1>), dim3(grid),
                        dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, P.attn_out, 0, 0, 4, 2, P.wi, P.mlp_out, true>), dim3(grid), dim3(256), 0,
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, P.attn_out, 0, 0, 4, 2, P.wi, P.mlp_out, 1>), dim3(grid), dim3(256), 0,
                        st, p);
 }
 }  // namespace
@@ -140,6 +144,29 @@ void launch_layer_f8_ks(hipStream_t st, const RowGemmParams& p, bool with_qkv, u
 bool launch_row_layer_f8(hipStream_t st, const RowGemmParams& p, int ks, bool with_qkv, unsigned grid) {
   if (ks == 8) launch_layer_f8_ks<8>(st, p, with_qkv, grid);
   else if (ks == 4) launch_layer_f8_ks<4>(st, p, with_qkv, grid);
+  else return false;
+  return true;
+}
+#endif
+
+#if OPL_ROW_PART == 5
+// Whole-layer kernel of kernel set 4: fp32-valued weights, fp16 + e4m3 operands with the weights' lo part (F8 = 2).
+namespace {
+template <int KS>
+void launch_layer_f8w_ks(hipStream_t st, const RowGemmParams& p, bool with_qkv, unsigned grid) {
+  constexpr Policy P = kPolicies[PI_F16_F8_W];
+  if (with_qkv)
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, P.attn_out, P.wqkv, qkv_olo(P), 4, 2, P.wi, P.mlp_out, 2>), dim3(grid),
+                       dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, P.attn_out, 0, 0, 4, 2, P.wi, P.mlp_out, 2>), dim3(grid), dim3(256), 0,
+                       st, p);
+}
+}  // namespace
+
+bool launch_row_layer_f8w(hipStream_t st, const RowGemmParams& p, int ks, bool with_qkv, unsigned grid) {
+  if (ks == 8) launch_layer_f8w_ks<8>(st, p, with_qkv, grid);
+  else if (ks == 4) launch_layer_f8w_ks<4>(st, p, with_qkv, grid);
   else return false;
   return true;
 }

@@ -221,6 +221,20 @@ __device__ __forceinline__ void split4_f16(const float v[4], uint2& hi, uint2& l
   lo.x = pack_f16x2(sub_f16_half<0>(v[0], hi.x), sub_f16_half<1>(v[1], hi.x));
   lo.y = pack_f16x2(sub_f16_half<0>(v[2], hi.y), sub_f16_half<1>(v[3], hi.y));
 }
+// two fp16 pairs (two dwords) -> one dword of four e4m3 bytes (the value itself, unscaled): 2 VALU instructions
+__device__ __forceinline__ uint32_t f16x4_to_e4m3(uint32_t h01, uint32_t h23) {
+  i16x2 w = {0, 0};
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, __builtin_bit_cast(f16x2, h01), 1.0f, false);
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, __builtin_bit_cast(f16x2, h23), 1.0f, true);
+  return __builtin_bit_cast(uint32_t, w);
+}
+// four fp32 -> one dword of four e4m3 bytes (unscaled)
+__device__ __forceinline__ uint32_t f32x4_to_e4m3(const float v[4]) {
+  i16x2 w = {0, 0};
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, v[0], v[1], 1.0f, false);
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, v[2], v[3], 1.0f, true);
+  return __builtin_bit_cast(uint32_t, w);
+}
 // e4m3 of one value through the hardware conversion (weight packing; the caller has set saturating conversions)
 __device__ __forceinline__ unsigned char f2e4m3(float v) {
   return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
@@ -322,6 +336,12 @@ __device__ __forceinline__ void frag_stream4(uint32_t lds_addr, Body&& body) {
     if constexpr (s + DEPTH + 1 < NSTEPS) read_group(std::integral_constant<int, s + DEPTH + 1>{});
   });
 }
+
+// the offsets of `Off` from step S0 on (a stream over the tail of another stream's step list)
+template <class Off, int S0>
+struct OffShift {
+  static constexpr int at(int s, int j) { return Off::at(s + S0, j); }
+};
 
 template <int NSTEPS, int DEPTH, class Off, class Body>
 __device__ __forceinline__ void frag_stream2(uint32_t lds_addr, Body&& body) {

@@ -63,6 +63,8 @@ struct RowGemmParams {
   // (pack_rowgemm_f8_kernel), wo2_ks = fp16 slabs [k-step][NF1][512]
   const u16* a1_lo8;
   const u16* w1p8;
+  // F8 = 2: the e4m3 slabs of lo(w) of the attention output weight are at w1p8 + k1_steps * 32 * hidden / 2; wo2_ks then
+  // holds [k-step][plane][NF1][512] with plane 1 = bf16(lo(w)); F8 = 1 reads plane 0 of the same pack
   float* x_io;
   int zero_a_lo;  // clear the lo fragments of the in-register (LayerNorm / split) operand: see rowgemm_kernel
   // RP_MLP: the whole MLP between phase 1 and the chunk loop, h kept on chip
@@ -138,7 +140,8 @@ __global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, i
   dst[base + 1024] = zero_lo ? (u16)0 : l;
 }
 
-// "f16 + fp8" kernel set: chunk c = [fp16 pieces (ks, nf)][e4m3 pieces (nf, K-step S, half hh)], 1 KiB each (F8Chunk
+// "f16 + fp8" kernel sets: chunk c = [fp16 pieces (ks, nf)][e4m3 pieces (nf, K-step S, half hh)][e4m3 pieces of the
+// WEIGHT's lo part lo(w) = (w - fp16(w)) x 2^12, same order], 1 KiB each (F8Chunk
 // below); the same source-row permutations as pack_rowgemm_kernel.  *not_f16 is raised when a weight of magnitude
 // >= 2^-14 is not exactly an fp16 value (then this kernel set would drop bits of the weight and the library keeps the
 // bf16 sets; every bf16 value in [2^-14, 65504] is an fp16 value).  Smaller weights land on the fp16 subnormal grid:
@@ -149,7 +152,7 @@ __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_rows * K;
   if (idx >= total) return;
-  const int KS = K / 32, NS8 = KS / 4, CP = 2 * KS + 4 * NS8;
+  const int KS = K / 32, NS8 = KS / 4, CP = 2 * KS + 8 * NS8;
   size_t t = idx;
   const int e = (int)(t & 7); t >>= 3;
   const int i = (int)(t & 15); t >>= 4;
@@ -166,10 +169,14 @@ __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows
   const int s8 = ks >> 2, hh = (ks & 3) >> 1, pbyte = 8 * (ks & 1) + e;
   unsigned char* d8 = reinterpret_cast<unsigned char*>(dst + ((size_t)c * CP + 2 * KS + (nf * NS8 + s8) * 2 + hh) * 512);
   d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v);
+  d8[(size_t)4 * NS8 * 1024 + (g * 16 + i) * 16 + pbyte] = f2e4m3((v - (float)hv) * (float)(1 << F8_LO_SHIFT));
 }
 
-// k-streamed weights of the "f16 + fp8" kernel set: fp16 slabs dst16[ks][nf][512] and (dst8 != nullptr, the attention
-// output projection) e4m3 slabs dst8[K-step S][nf][half][1 KiB]; `permute` as pack_kstream_kernel.
+// k-streamed weights of the "f16 + fp8" kernel sets.  dst8 != nullptr (attention output projection, K = hidden): fp16
+// slabs dst16[ks][nf][512], e4m3 slabs dst8[K-step S][nf][half][1 KiB] and the same of lo(w) x 2^12 behind them
+// (dst8 + N K / 2).  dst8 == nullptr (MLP output projection, streamed 32 k at a time): dst16[ks][plane][nf][512] with
+// plane 0 = fp16(w), plane 1 = bf16(lo(w)) (multiplied on the bf16 shape against bf16(h): its exponent range holds the
+// unscaled lo part).  `permute` as pack_kstream_kernel.
 __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst16,
                                        u16* __restrict__ dst8, int round_bf16, int* __restrict__ not_f16) {
   set_saturating_conversions();
@@ -187,11 +194,16 @@ __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int
   if (round_bf16) v = bf2f(f2bf(v));
   const _Float16 hv = (_Float16)v;
   if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;  // (below 2^-14: fp16 subnormal grid, |error| <= 2^-25)
-  dst16[((size_t)ks * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
+  const float wlo = v - (float)hv;
   if (dst8 != nullptr) {
+    dst16[((size_t)ks * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
     const int s8 = ks >> 2, hh = (ks & 3) >> 1, pbyte = 8 * (ks & 1) + e;
     unsigned char* d8 = reinterpret_cast<unsigned char*>(dst8 + (((size_t)s8 * NF + nf) * 2 + hh) * 512);
     d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v);
+    d8[(size_t)N * K + (g * 16 + i) * 16 + pbyte] = f2e4m3(wlo * (float)(1 << F8_LO_SHIFT));
+  } else {
+    dst16[((size_t)ks * 2 * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
+    dst16[((size_t)(ks * 2 + 1) * NF + nf) * 512 + g * 128 + i * 8 + e] = f2bf(wlo);
   }
 }
 #endif
@@ -279,17 +291,23 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16
 //   4 fp16 steps (both fragments of one k-step: 2 x MF MFMAs of 16 cycles) + 2 e4m3 steps (the two halves of ONE
 //   fragment of the group's K-step: MF MFMAs of 32 cycles)
 // so every step reads two 1 KiB pieces and keeps the matrix pipe busy for 64 cycles (MF = 2).
-template <int KS>
+// WLO (fp32-valued weights): every group gets 2 more e4m3 steps, e4m3(left hi) x e4m3(lo(weight) x 2^12), from a third
+// region of 4 (KS / 4) pieces [fragment][K-step][half].
+template <int KS, bool WLO = false>
 struct F8Chunk {
   static constexpr int NS8 = KS / 4;
-  static constexpr int STEPS = KS + 2 * NS8;
-  static constexpr int BYTES = (2 * KS + 4 * NS8) * 1024;
-  static constexpr bool is_f8(int cs) { return cs % 6 >= 4; }
-  static constexpr int ks(int cs) { return 4 * (cs / 6) + cs % 6; }   // fp16 step: k-step
-  static constexpr int nf(int cs) { return cs % 6 - 4; }              // e4m3 step: fragment
-  static constexpr int s8(int cs) { return cs / 6; }                  //            K-step of 128
+  static constexpr int G = WLO ? 8 : 6;  // steps per group of 4 k-steps
+  static constexpr int STEPS = (G * KS) / 4;
+  static constexpr int PIECES = 2 * KS + (WLO ? 8 : 4) * NS8;
+  static constexpr int SRC_PIECES = 2 * KS + 8 * NS8;  // the packed chunk always carries the weight-lo region
+  static constexpr int BYTES = PIECES * 1024;
+  static constexpr bool is_f8(int cs) { return cs % G >= 4; }
+  static constexpr bool is_wlo(int cs) { return cs % G >= 6; }        // e4m3 step on the weight's lo part
+  static constexpr int ks(int cs) { return 4 * (cs / G) + cs % G; }   // fp16 step: k-step
+  static constexpr int nf(int cs) { return (cs % G - 4) & 1; }        // e4m3 step: fragment
+  static constexpr int s8(int cs) { return cs / G; }                  //            K-step of 128
   static constexpr int off(int cs, int j) {
-    return is_f8(cs) ? (2 * KS + (nf(cs) * NS8 + s8(cs)) * 2 + j) * 1024 : (ks(cs) * 2 + j) * 1024;
+    return is_f8(cs) ? (2 * KS + (is_wlo(cs) ? 4 * NS8 : 0) + (nf(cs) * NS8 + s8(cs)) * 2 + j) * 1024 : (ks(cs) * 2 + j) * 1024;
   }
 };
 // LDS byte offsets of the fused MLP's macro-iteration stream, F8 form: [Wi chunk 2t][Wi chunk 2t+1][MLP-Wo slab t-1]
@@ -310,10 +328,10 @@ struct MlpStreamOff8 {
 // behind the MFMAs of the step whose set it re-uses.
 // DEPTH steps of reads stay in flight behind the one being multiplied (a step is 64 pipe cycles: one step ahead does
 // not cover the LDS latency under load).
-template <int KS, int MF, bool SWAPPED, bool PIN_AGPR, int DEPTH = 3>
+template <int KS, int MF, bool SWAPPED, bool PIN_AGPR, bool WLO = false, int DEPTH = 3>
 __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const bf16x8 (&a_hi)[MF][KS], const i32x8 (&a_lo8)[MF][KS / 4],
-                                                      f32x4 (&acc)[2][MF]) {
-  using C = F8Chunk<KS>;
+                                                      const i32x8 (&a_h8)[MF][KS / 4], f32x4 (&acc)[2][MF]) {
+  using C = F8Chunk<KS, WLO>;
   static_assert(MF == 2, "32 rows per wave");
   constexpr int SETS = DEPTH + 1;
   bf16x8 w[SETS][2];
@@ -337,9 +355,15 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
     } else {
       constexpr int nf = C::nf(cs), s8 = C::s8(cs);
       const i32x8 w8 = f8_frag(w[S][0], w[S][1]);
+      if constexpr (C::is_wlo(cs)) {  // e4m3(activation) x lo(weight): the scaled operand is the weight
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
-        acc[nf][mf] = SWAPPED ? mfma8<true>(w8, a_lo8[mf][s8], acc[nf][mf]) : mfma8<false>(a_lo8[mf][s8], w8, acc[nf][mf]);
+        for (int mf = 0; mf < MF; ++mf)
+          acc[nf][mf] = SWAPPED ? mfma8<false>(w8, a_h8[mf][s8], acc[nf][mf]) : mfma8<true>(a_h8[mf][s8], w8, acc[nf][mf]);
+      } else {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+          acc[nf][mf] = SWAPPED ? mfma8<true>(w8, a_lo8[mf][s8], acc[nf][mf]) : mfma8<false>(a_lo8[mf][s8], w8, acc[nf][mf]);
+      }
     }
   };
   const std::true_type yes{};
@@ -363,11 +387,17 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
 // F8 (whole-layer kernel only): the "f16 + fp8" kernel set (opk_common.hip.h) -- every hi operand is fp16, the lo
 // operand of the three K = hidden contractions (attention output projection, Wi, next q / k / v) is an e4m3 plane
 // multiplied at twice the rate on the K = 128 block-scaled MFMA, h (K = 32 per step) keeps a 16-bit lo fragment.
-template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0, bool F8 = false>
+// F8 = 2 (fp32-valued weights, kernel set 4): additionally every weight carries its lo part lo(w) = w - fp16(w) --
+// e4m3 x 2^12 for the K = hidden contractions (multiplied against e4m3(activation): 0.5 MFMA units), bf16 for the MLP
+// output projection (against bf16(h)) -- 2 MFMA units per product where the (hi, lo) bf16 kernels need 3; one Wi chunk +
+// half a Wo slab per LDS stage (a stage of two chunks + a slab with their lo planes would be 96 KiB).
+template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0, int F8 = 0>
 __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : ((MF == 1 && WAVES == 8) ? 4 : 2)) void rowgemm_kernel(RowGemmParams p) {
-  static_assert(!F8 || (PRO == RP_MLP && WAVES == 4 && MF == 2 && KS % 4 == 0 && T1 == T_LEFT_LO && TW == T_LEFT_LO && TM == T_LEFT_LO &&
-                        (EPI == RE_NONE || T2 == T_LEFT_LO)),
-                "f16 + fp8 kernel set: whole-layer kernel, 4 waves x 32 rows, single-plane weights, every activation lo term");
+  constexpr bool WLO = F8 == 2;
+  constexpr int TF8 = WLO ? 3 : T_LEFT_LO;  // the term masks this instantiation stands for
+  static_assert(!F8 || (PRO == RP_MLP && WAVES == 4 && MF == 2 && KS % 4 == 0 && T1 == TF8 && TW == TF8 && TM == TF8 &&
+                        (EPI == RE_NONE || T2 == TF8)),
+                "f16 + fp8 kernel sets: whole-layer kernel, 4 waves x 32 rows, every activation lo term (+ F8 = 2: every weight lo term)");
   constexpr int NS8 = F8 ? KS / 4 : 1;  // K = 128 steps of the fp8 lo product
   // A block is WAVES x MF x 16 rows; the library launches 4 waves x 2 fragments = 128 rows, two blocks per CU, and
   // 4 waves x 1 fragment = 64 rows for small batches (fewer than one 128-row block per CU-slot: twice the blocks, so
@@ -376,26 +406,30 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   // instructions and L2 -> LDS traffic per row) is within +-2 % on both fused kernels; 8 waves x 1 (16 rows per wave,
   // <= 128 VGPRs, 4 waves per SIMD, twice the fragment reads per MFMA) is equal on q/k/v and 10 % slower on GeGLU.
   static_assert(MF == 1 || MF == 2, "one or two 16-row fragments per wave");
-  constexpr bool W_LO = (T2 & T_RIGHT_LO) != 0, A_LO = (T2 & T_LEFT_LO) != 0;
+  // (F8: the weight's lo part is not a second bf16 plane -- W_LO / W_LO1 describe the bf16 kernels' LDS layout only)
+  constexpr bool W_LO = !F8 && (T2 & T_RIGHT_LO) != 0, A_LO = (T2 & T_LEFT_LO) != 0;
   constexpr bool PHASE1 = PRO == RP_KSTREAM || PRO == RP_MLP;
-  constexpr bool W_LO1 = PHASE1 && (T1 & T_RIGHT_LO) != 0, A_LO1 = PHASE1 && (T1 & T_LEFT_LO) != 0;
+  constexpr bool W_LO1 = !F8 && PHASE1 && (T1 & T_RIGHT_LO) != 0, A_LO1 = PHASE1 && (T1 & T_LEFT_LO) != 0;
   // RP_MLP: 4 waves x 32 rows, ONE wave per SIMD with the 512-register budget: the normalised rows (2 x 64 registers
   // with their lo plane) and the 256 x 32 output accumulators (128) are both resident for the whole MLP; two waves of
   // 16 rows per SIMD (256 registers each) spill.  The fragment streams prefetch by hand, so latency is covered
   // without a partner wave.
-  static_assert(PRO != RP_MLP || (((WAVES == 4 && MF == 2) || (WAVES == 8 && MF == 1)) && (TW & T_RIGHT_LO) == 0 && (TM & T_RIGHT_LO) == 0),
+  static_assert(PRO != RP_MLP || (((WAVES == 4 && MF == 2) || (WAVES == 8 && MF == 1)) && (WLO || ((TW & T_RIGHT_LO) == 0 && (TM & T_RIGHT_LO) == 0))),
                 "fused MLP: 4 waves x 32 rows or 8 waves x 16 rows, single-plane Wi and Wo");
   constexpr int PLANES = W_LO ? 2 : 1;
   constexpr int PLANES1 = W_LO1 ? 2 : 1;
   constexpr int K = KS * 32;
   // F8: a chunk is [fp16 plane: KS k-steps x 2 fragments | e4m3 plane: 2 fragments x KS/4 K-steps x 2 halves] 1 KiB pieces
-  constexpr int CHUNK_PIECES8 = 2 * KS + 4 * NS8;
-  constexpr int CHUNK_SRC = F8 ? CHUNK_PIECES8 * 512 : KS * 2 * 1024;  // elements per packed chunk in global memory
+  // (WLO: + the e4m3 plane of the weight's lo part; the packed chunk in global memory always carries it)
+  constexpr int CHUNK_PIECES8 = F8Chunk<KS, WLO>::PIECES;
+  constexpr int CHUNK_SRC = F8 ? F8Chunk<KS, WLO>::SRC_PIECES * 512 : KS * 2 * 1024;  // elements per packed chunk in global memory
   constexpr int STAGE = F8 ? CHUNK_PIECES8 * 512 : KS * PLANES * 1024;  // elements per LDS stage
-  // two Wi chunks + one Wo slab (2 KS fragments), one plane; F8: the chunks carry their e4m3 plane
-  constexpr int MLP_UNIT = PRO == RP_MLP ? (F8 ? (2 * CHUNK_PIECES8 + 2 * KS) * 512 : 3 * KS * 1024) : 0;
-  // phase 1 slabs: 2 KS fragments per plane; F8: two fp16 slabs + half an e4m3 K = 128 slab per stage
-  constexpr int STAGE_GEMM = F8 ? 6 * KS * 512 : KS * (PLANES > PLANES1 ? PLANES : PLANES1) * 1024;
+  // two Wi chunks + one Wo slab (2 KS fragments), one plane; F8: the chunks carry their e4m3 plane; WLO: ONE chunk +
+  // half a slab (KS fragments, fp16 + bf16-lo planes) per stage
+  constexpr int MLP_UNIT = PRO == RP_MLP ? (WLO ? (CHUNK_PIECES8 + 2 * KS) * 512 : F8 ? (2 * CHUNK_PIECES8 + 2 * KS) * 512 : 3 * KS * 1024) : 0;
+  // phase 1 slabs: 2 KS fragments per plane; F8: two fp16 slabs + half an e4m3 K = 128 slab per stage (WLO: + the
+  // same half slab of the weight's lo part)
+  constexpr int STAGE_GEMM = WLO ? 8 * KS * 512 : F8 ? 6 * KS * 512 : KS * (PLANES > PLANES1 ? PLANES : PLANES1) * 1024;
   constexpr int STAGE_ALLOC = STAGE_GEMM > MLP_UNIT ? STAGE_GEMM : MLP_UNIT;
   static_assert(STAGE % (WAVES * 512) == 0, "stage must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) u16 sW[2][STAGE_ALLOC];
@@ -474,6 +508,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   };
   bf16x8 a_hi[MF][KS], a_lo[MF][KS];
   i32x8 a_lo8[MF][NS8];  // F8: e4m3 lo plane of the in-register operand, one K = 128 fragment per 4 k-steps
+  i32x8 a_h8[MF][NS8];   // WLO: e4m3 of the operand itself (multiplied against the weights' lo part)
   if constexpr (F8) set_saturating_conversions();
   // RE_QKV: RoPE rows of this lane's tokens, cos/sin [pos][8g + 4j .. +3] for half-head j.  Two-wave kernels fetch the
   // half-head of the chunk whose (deferred) epilogue runs in an iteration at the top of that iteration (the partner wave
@@ -555,8 +590,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       static_assert(PLANES1 == 1, "whole-layer kernel: single-plane attention output weight");
       // DMA instructions per wave per stage: two k-steps of fp16 slabs (+ F8: NF1 / 2 fragments = NF1 half-pieces of the
       // e4m3 slab of K-step j / 2: its first half of the output features in the even stage, the second in the odd one)
-      constexpr int PAIR_PIECES = (F8 ? 3 : 2) * NF1 / WAVES;
-      static_assert((F8 ? 3 : 2) * NF1 * 512 <= STAGE_ALLOC, "two slabs per LDS stage");
+      constexpr int PAIR_PIECES = (WLO ? 4 : F8 ? 3 : 2) * NF1 / WAVES;
+      static_assert((WLO ? 4 : F8 ? 3 : 2) * NF1 * 512 <= STAGE_ALLOC, "two slabs per LDS stage");
       auto stage_pair = [&](int j, int stage) {
 #pragma unroll
         for (int u = 0; u < PAIR_PIECES; ++u) {
@@ -564,6 +599,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           const u16* src = p.w1p + (size_t)(2 * j + piece / NF1) * SLAB_SRC + (piece % NF1) * 512;
           if (F8 && u >= 2 * NF1 / WAVES)
             src = p.w1p8 + ((size_t)(j >> 1) * NF1 + (NF1 / 2) * (j & 1)) * 1024 + (piece - 2 * NF1) * 512;
+          if (WLO && u >= 3 * NF1 / WAVES)  // the same half slab of lo(w): a second array right behind the first
+            src = p.w1p8 + (size_t)nks1 * 16 * K + ((size_t)(j >> 1) * NF1 + (NF1 / 2) * (j & 1)) * 1024 + (piece - 3 * NF1) * 512;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
                                            (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
         }
@@ -611,6 +648,17 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       }
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF1) : "memory");
       __builtin_amdgcn_s_barrier();
+      if constexpr (WLO) {  // e4m3(o) for the product with the weights' lo part: from the fp16 fragments that just landed
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const uint4 h = as_u4(a_hi[mf][ks]);
+            const int d0 = 4 * ((ks % 4) / 2) + 2 * (ks % 2);
+            a_h8[mf][ks / 4][d0] = (int)f16x4_to_e4m3(h.x, h.y);
+            a_h8[mf][ks / 4][d0 + 1] = (int)f16x4_to_e4m3(h.z, h.w);
+          }
+      }
       static_for<KS / 2>([&](auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         constexpr int cur = j & 1;
@@ -621,7 +669,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         struct P1Off {
           static constexpr int at(int st, int jj) { return (2 * st + jj) * 1024; }
         };
-        frag_stream2<(F8 ? NF1 + NF1 / 2 : NF1), (F8 ? 4 : 2), P1Off>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+        frag_stream2<(WLO ? 2 * NF1 : F8 ? NF1 + NF1 / 2 : NF1), (F8 ? 4 : 2), P1Off>(lds_stage[cur], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int st = decltype(step_tag)::value;
           if constexpr (F8) {
             if constexpr (st < NF1) {  // fp16: fragments nf, nf + 1 of k-step ks
@@ -630,11 +678,16 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
               for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, a_hi[mf][ks], acc1[nf][mf]);
 #pragma unroll
               for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16h(w1, a_hi[mf][ks], acc1[nf + 1][mf]);
-            } else {  // e4m3: the two halves of fragment nf8, K-step j / 2
+            } else if constexpr (st < NF1 + NF1 / 2) {  // e4m3: the two halves of fragment nf8, K-step j / 2
               constexpr int nf8 = (NF1 / 2) * (j & 1) + (st - NF1);
               const i32x8 w8 = f8_frag(w0, w1);
 #pragma unroll
               for (int mf = 0; mf < MF; ++mf) acc1[nf8][mf] = mfma8<true>(w8, a_lo8[mf][j >> 1], acc1[nf8][mf]);
+            } else {  // WLO: e4m3(o) x lo(w) of the same fragments
+              constexpr int nf8 = (NF1 / 2) * (j & 1) + (st - NF1 - NF1 / 2);
+              const i32x8 w8 = f8_frag(w0, w1);
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) acc1[nf8][mf] = mfma8<false>(w8, a_h8[mf][j >> 1], acc1[nf8][mf]);
             }
             return;
           }
@@ -850,7 +903,14 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
             constexpr int d0 = 4 * ((ks % 4) / 2) + 2 * (ks % 2);
             a_lo8[mf][ks / 4][d0] = (int)l0;
             a_lo8[mf][ks / 4][d0 + 1] = (int)l1;
-            if constexpr (LOAD && (ks % 4) == 3) asm volatile("" : "+a"(a_lo8[mf][ks / 4]));  // parked where the MLP wants it
+            if constexpr (WLO) {
+              a_h8[mf][ks / 4][d0] = (int)f32x4_to_e4m3(va);
+              a_h8[mf][ks / 4][d0 + 1] = (int)f32x4_to_e4m3(vb);
+            }
+            if constexpr (LOAD && (ks % 4) == 3) {  // parked where the MLP wants them
+              asm volatile("" : "+a"(a_lo8[mf][ks / 4]));
+              if constexpr (WLO) asm volatile("" : "+a"(a_h8[mf][ks / 4]));
+            }
           } else {
           uint32_t h[4], l[4];
 #pragma unroll
@@ -989,9 +1049,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         const int ts = t > 0 ? t - 1 : 0;
         const int piece = wave + WAVES * u;  // wave-uniform
         const u16* src;
-        if (F8) {  // the pack is in stage order: two consecutive chunks, then the fp16 slab
-          src = u < WI_PIECES / WAVES ? p.wi_pk + (size_t)(2 * tc) * CHUNK_SRC + piece * 512
-                                      : p.wo2_ks + (size_t)ts * (NF1 * 512) + (piece - WI_PIECES) * 512;
+        if (F8) {  // the chunk's fp16 + e4m3 pieces (not its weight-lo region), then plane 0 (fp16) of the slab
+          src = u < WI_PIECES / WAVES ? p.wi_pk + (size_t)(2 * tc + piece / CHUNK_PIECES8) * CHUNK_SRC + (piece % CHUNK_PIECES8) * 512
+                                      : p.wo2_ks + (size_t)ts * (2 * NF1 * 512) + (piece - WI_PIECES) * 512;
         } else if (u < WI_PIECES / WAVES) {  // [chunk 0..1][ks][frag]: hi pieces of the chunk-major pack
           const int c = piece / (2 * KS), within = piece % (2 * KS);
           src = p.wi_pk + (size_t)(2 * tc + c) * CHUNK_SRC + (within >> 1) * 2048 + (within & 1) * 512;
@@ -1002,7 +1062,25 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
                                          (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
       };
       auto stage_unit = [&](int t, int stage) { static_for<UNIT_DMA>([&](auto u) { stage_piece(u, t, stage); }); };
-      stage_unit(0, 0);  // flies while the LayerNorm below runs
+      // WLO: a stage is the half-unit of chunk c: [Wi chunk c with both e4m3 planes][half (c & 1) of the Wo slab of pair
+      // c / 2 - 1: NF1 / 2 fragments of plane 0 (fp16), then the same fragments of plane 1 (bf16 of the weight's lo part)]
+      auto stage_piece_w = [&](auto u_tag, int c, int stage) {
+        constexpr int u = decltype(u_tag)::value;
+        const int cc = c < 2 * n_pairs ? c : 2 * n_pairs - 1;  // clamped: the tail stages carry only a slab half
+        const int ts = (c >> 1) > 0 ? (c >> 1) - 1 : 0;
+        const int piece = wave + WAVES * u;  // wave-uniform
+        const u16* src;
+        if (u < CHUNK_PIECES8 / WAVES) {
+          src = p.wi_pk + (size_t)cc * CHUNK_SRC + piece * 512;
+        } else {
+          const int q = piece - CHUNK_PIECES8, plane = q / (NF1 / 2), n = q % (NF1 / 2);
+          src = p.wo2_ks + ((size_t)(ts * 2 + plane) * NF1 + (c & 1) * (NF1 / 2) + n) * 512;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+      };
+      if constexpr (WLO) static_for<UNIT_DMA>([&](auto u) { stage_piece_w(u, 0, 0); });
+      else stage_unit(0, 0);  // flies while the LayerNorm below runs
       if constexpr (LN_V2) layer_ln(yes_, std::integral_constant<bool, A_LOW>{}, 0);
       else residual_ln(yes_, no_, std::integral_constant<bool, A_LOW>{}, p.ln_w_mlp);
       // The lo fragments of the normalised rows live in AGPRs from here on (an MFMA takes its A / B operands from
@@ -1018,6 +1096,13 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       f32x4 acc_b[2][MF];  // accumulators of the pair's second chunk: [input | gate] fragment x row fragment
       uint2 hold_hi[MF], hold_lo[MF];
       bf16x8 h_hi[MF], h_lo[MF];
+      uint2 hold_b[MF];  // WLO: bf16(h), the operand of the product with bf16(lo(Wo))
+      bf16x8 h_b[MF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        hold_b[mf] = make_uint2(0u, 0u);
+        h_b[mf] = as_frag(make_uint4(0u, 0u, 0u, 0u));
+      }
       float g_prev[MF][4], g_cur[MF][4];  // GeGLU values of the chunk finished last / of this pair's first chunk
       float gx[MF * 4], gq[MF * 4];       // GeGLU in flight: inputs and the running polynomial / exponential / result
 #pragma unroll
@@ -1112,6 +1197,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         uint2 h2, l2;
         if constexpr (F8) split4_f16(g_prev[mf], h2, l2);
         else split4<H_LO>(g_prev[mf], h2, l2);
+        if constexpr (WLO)
+          h_b[mf] = as_frag(make_uint4(hold_b[mf].x, hold_b[mf].y, pack_bf16x2(g_prev[mf][0], g_prev[mf][1]), pack_bf16x2(g_prev[mf][2], g_prev[mf][3])));
         h_hi[mf] = as_frag(make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y));
         h_lo[mf] = as_frag(make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y));
       };
@@ -1122,6 +1209,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #endif
         if constexpr (F8) split4_f16(g_cur[mf], hold_hi[mf], hold_lo[mf]);
         else split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
+        if constexpr (WLO) hold_b[mf] = make_uint2(pack_bf16x2(g_cur[mf][0], g_cur[mf][1]), pack_bf16x2(g_cur[mf][2], g_cur[mf][3]));
       };
       auto chunk_step = [&](f32x4 (&acc)[2][MF], auto ks_tag, const bf16x8& w0, const bf16x8& w1) {
         constexpr int ks = decltype(ks_tag)::value;
@@ -1175,6 +1263,23 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, h_hi[mf], acc1[nf][mf]);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, h_hi[mf], acc1[nf + 1][mf]);
+      };
+      // WLO: e4m3(LN(x)) x lo(Wi), and one output fragment of the slab with all three terms:
+      //   lo(h) x Wo + h x Wo on the fp16 shape, bf16(h) x bf16(lo(Wo)) on the bf16 shape (w1 = that plane's fragment)
+      auto chunk_step8w = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1) {
+        constexpr int nf = decltype(nf_tag)::value, s8 = decltype(s8_tag)::value;
+        const i32x8 w8 = f8_frag(w0, w1);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = mfma8<false>(w8, a_h8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
+      };
+      auto slab_one = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1) {
+        constexpr int nf = decltype(nf_tag)::value;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_lo[mf], acc1[nf][mf]);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w1, h_b[mf], acc1[nf][mf]);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_hi[mf], acc1[nf][mf]);
       };
       // one MFMA : up to three vector instructions inside a step (the slice's VALU spread between its MFMAs)
       auto interleave_step = [&]() {
@@ -1303,6 +1408,68 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // stage 0 has landed
       OPK_STAMP(2);
+      if constexpr (WLO) {
+        // ---- fp32-valued weights: half-iterations.  Half hb of iteration t streams stage hb = [chunk 2t + hb | half hb
+        // of slab t-1]: the chunk's KS fp16 steps + 2 x KS/2 e4m3 steps (lo(LN(x)) x Wi, LN(x) x lo(Wi)), then NF1 / 2
+        // slab steps of ONE output fragment each with all three terms (6 MFMAs); meanwhile the DMA fills the other
+        // stage with the next half-unit.  GeGLU(2t) rides on the slab steps of half 0 and the chunk steps of half 1,
+        // GeGLU(2t+1) on the slab steps of half 1 and closes h of pair t.  Iteration 0 multiplies the slab by h = 0.
+        using C8 = F8Chunk<KS, true>;
+        constexpr int CS = C8::STEPS, NSH = NF1 / 2;
+        struct OffW {
+          static constexpr int at(int st, int j) { return st < CS ? C8::off(st, j) : C8::BYTES + (j * NSH + (st - CS)) * 1024; }
+        };
+        auto half_iter = [&](int c, auto hb_tag, auto with_chunk_tag, f32x4 (&na)[2][MF], f32x4 (&nb)[2][MF]) {
+          constexpr int hb = decltype(hb_tag)::value;
+          constexpr bool CHUNK = decltype(with_chunk_tag)::value;  // false: tail (slab steps only)
+          constexpr int S0 = CHUNK ? 0 : CS;
+          // tail: the stream is shorter than the DMA list -- the first tail half requests the last slab half up front,
+          // the second one has nothing left to request
+          if constexpr (!CHUNK && hb == 0) static_for<UNIT_DMA>([&](auto u) { stage_piece_w(u, c + 1, hb ^ 1); });
+          frag_stream2<CS + NSH - S0, DEPTH8, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+            constexpr int sr = decltype(step_tag)::value, st = sr + S0;
+#ifndef OPK_ABL_NO_DMA
+            if constexpr (CHUNK && sr < UNIT_DMA) stage_piece_w(step_tag, c + 1, hb ^ 1);
+#endif
+            if constexpr (st < CS) {
+              auto& acc = *(hb == 0 ? &na : &nb);
+              if constexpr (!C8::is_f8(st)) chunk_step(acc, std::integral_constant<int, C8::ks(st)>{}, w0, w1);
+              else if constexpr (!C8::is_wlo(st)) chunk_step8(acc, std::integral_constant<int, C8::nf(st)>{}, std::integral_constant<int, C8::s8(st)>{}, w0, w1);
+              else chunk_step8w(acc, std::integral_constant<int, C8::nf(st)>{}, std::integral_constant<int, C8::s8(st)>{}, w0, w1);
+              if constexpr (hb == 1) {  // second half of GeGLU(2t), evenly over the chunk's steps
+                constexpr int OB = 4 * NV + st * 4 * NV / CS, OE = 4 * NV + (st + 1) * 4 * NV / CS;
+                geglu_ops(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_hold);
+              }
+            } else {
+              constexpr int i = st - CS;
+              slab_one(std::integral_constant<int, hb * NSH + i>{}, w0, w1);
+              if constexpr (CHUNK && hb == 0) {  // first half of GeGLU(2t)
+                constexpr int OB = i * 4 * NV / NSH, OE = (i + 1) * 4 * NV / NSH;
+                geglu_ops(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_hold);
+              }
+              if constexpr (CHUNK && hb == 1) {  // GeGLU(2t+1): NSH steps carry the 8 NV operations
+                constexpr int OB = i * 8 * NV / NSH, OE = (i + 1) * 8 * NV / NSH;
+                geglu_ops(nb, g_prev, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_h);
+              }
+            }
+          });
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the other stage has landed
+          __builtin_amdgcn_s_barrier();
+        };
+        const std::integral_constant<int, 0> h0{};
+        const std::integral_constant<int, 1> h1{};
+        int t = 0;
+        do {
+          f32x4 na[2][MF], nb[2][MF];
+          half_iter(2 * t, h0, yes_, na, nb);
+          half_iter(2 * t + 1, h1, yes_, na, nb);
+        } while (++t < n_pairs);
+        {  // tail: slab of the last pair, half by half
+          f32x4 na[2][MF], nb[2][MF];
+          half_iter(2 * n_pairs, h0, no_, na, nb);
+          half_iter(2 * n_pairs + 1, h1, no_, na, nb);
+        }
+      } else {
       macro(0, 0, no_);
       {  // n_pairs is even (checked on the host): at least one more iteration, and the tail reads stage 0.  Written as
         // do-while: around a loop that may run zero times the compiler parks accumulator values in scratch.
@@ -1311,7 +1478,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           macro(t, t & 1, yes_);
         } while (++t < n_pairs);
       }
-      {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
+      }
+      if constexpr (!WLO) {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
         if constexpr (!F8) static_for<KS>([&](auto sl) { geglu_slice(acc_b, g_prev, sl, pack_h); });
         struct TailOff {
           static constexpr int at(int s, int j) { return (F8 ? 2 * F8Chunk<KS>::BYTES : 2 * KS * 2048) + (s * 2 + j) * 1024; }
@@ -1663,7 +1831,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (F8) rowgemm_chunk_mfma_f8<KS, MF, SW, true>(lds_stage[cur], a_hi, a_lo8, acc);
+    if constexpr (F8) rowgemm_chunk_mfma_f8<KS, MF, SW, true, WLO>(lds_stage[cur], a_hi, a_lo8, a_h8, acc);
     else rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP)>(lds_stage[cur], a_hi, a_lo, acc);
 #if !defined(OPK_ABL_NO_EPILOGUE)
     if (!FIRST) epilogue_store(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag);
@@ -1679,7 +1847,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       // instruction costs its issue slot -- so the gain of the interleave is only that no wave sits in a VALU-only
       // phase while its partner waits for the same port; the lever that pays is fewer epilogue instructions.
       constexpr int NT = term_count(T2);
-      constexpr int N_MFMA = F8 ? KS * 2 * MF + 2 * NS8 * MF : KS * 2 * MF * NT;
+      constexpr int N_MFMA = F8 ? KS * 2 * MF + (WLO ? 4 : 2) * NS8 * MF : KS * 2 * MF * NT;
       constexpr int VALU_PER_MFMA = NT == 3 ? 2 : (NT == 2 ? 3 : 5);  // (2 or 4 for NT == 2: no change, measured)
 #pragma unroll
       for (int i = 0; i < N_MFMA; ++i) {

@@ -185,14 +185,15 @@ class HipEncoder:
     def effective_policy(self) -> dict:
         """Term masks actually evaluated (the requested policy minus weight-lo terms that are identically zero
         for the loaded checkpoint) and the kernel set running them: ``{"terms": {family: mask}, "kernel_set":
-        "bf16x3" | "bf16-weights" | "bf16" | "f16-f8" | "all-terms kernels, cleared lo operands"}`` ("f16-f8": the
-        terms of "bf16-weights" with the whole-layer kernel's operands carried as fp16 hi + e4m3 lo)."""
+        "bf16x3" | "bf16-weights" | "bf16" | "f16-f8" | "f16-f8-w" | "all-terms kernels, cleared lo operands"}`` ("f16-f8":
+        the terms of "bf16-weights" with the whole-layer kernel's operands carried as fp16 hi + e4m3 lo; "f16-f8-w": the
+        terms of "bf16x3" in that format, the weights' lo part as a third plane)."""
 
         terms = (ctypes.c_uint8 * 8)()
         kernel_set = ctypes.c_int(0)
         code = self.lib.op_effective_policy(self._handle, terms, ctypes.byref(kernel_set))
         _lib.check(self.lib, self._handle, code, "op_effective_policy")
-        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", -1: "all-terms kernels, cleared lo operands"}
+        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", 4: "f16-f8-w", -1: "all-terms kernels, cleared lo operands"}
         return {
             "terms": {name: int(terms[i]) for i, name in enumerate(_lib.OP_FAMILIES)},
             "kernel_set": names.get(int(kernel_set.value), str(kernel_set.value)),

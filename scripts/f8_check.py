@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""GPU check of kernel set 3 (fp16 hi + e4m3 lo) against the oracle and against kernel set 1, bf16-valued weights."""
+"""GPU check of the fp16 + e4m3 kernel sets against the oracle and against the (hi, lo) bf16 sets on the same weights:
+bf16-valued weights -> "f16-f8" vs "bf16-weights"; fp32-valued weights -> "f16-f8-w" vs "bf16x3" (two kernels per layer)."""
 import sys
 from pathlib import Path
 
@@ -15,15 +16,18 @@ from open_provence_amd.synthetic import pad_rows  # noqa: E402
 from oracle.modernbert_oracle import oracle_forward  # noqa: E402
 
 NO_F8 = 512
-for fixture in sys.argv[1:] or ["g0c_hd64_synth", "g1_xsmall", "g7_xsmall_refinit", "g0b_hd64_refinit", "g12_prenorm_tf4"]:
+
+
+def run(fixture: str, weights: str) -> None:
     arrays, meta = load_golden(fixture)
     dims = dims_from_meta(meta)
-    state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v
-             for k, v in state_from_fixture(arrays, meta).items()}
+    state = state_from_fixture(arrays, meta)
+    if weights == "bf16":
+        state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v for k, v in state.items()}
     rows = rows_from_fixture(arrays)
     pre = bool(meta.get("prune_pre_final_norm", False))
     outs = {}
-    for label, flags in (("f8", 0), ("bf16w", NO_F8)):
+    for label, flags in (("f8", 0), ("bf16", NO_F8)):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags, prune_pre_final_norm=pre)
         enc.load_state_dict(state)
         ks = enc.effective_policy()["kernel_set"]
@@ -35,7 +39,13 @@ for fixture in sys.argv[1:] or ["g0c_hd64_synth", "g1_xsmall", "g7_xsmall_refini
     ref = oracle_forward(state, dims, ids, mask, prune_pre_final_norm=pre)
     m = mask.bool().numpy()
     rp, rr = ref.pruning_logits.numpy()[m], ref.ranking_logits.numpy()
-    for label in ("f8", "bf16w"):
+    for label in ("f8", "bf16"):
         p, r, ks = outs[label]
-        print(f"{fixture:20s} {label:6s} [{ks:12s}] prune {np.abs(p - rp).max():.2e} rank {np.abs(r - rr).max():.2e} "
+        print(f"{fixture:20s} {weights}-valued weights  [{ks:12s}] prune {np.abs(p - rp).max():.2e} rank {np.abs(r - rr).max():.2e} "
               f"finite {bool(np.isfinite(p).all() and np.isfinite(r).all())}", flush=True)
+
+
+if __name__ == "__main__":
+    for fixture in sys.argv[1:] or ["g0c_hd64_synth", "g1_xsmall", "g7_xsmall_refinit", "g0b_hd64_refinit", "g12_prenorm_tf4"]:
+        for weights in ("bf16", "fp32"):
+            run(fixture, weights)

@@ -46,7 +46,7 @@ def _oracle(state, dims, rows):
     return ref.pruning_logits.numpy(), ref.ranking_logits.numpy()
 
 
-@pytest.mark.parametrize("weights,kernel_set", [("bf16", "f16-f8"), ("fp32", "bf16x3")])
+@pytest.mark.parametrize("weights,kernel_set", [("bf16", "f16-f8"), ("fp32", "f16-f8-w")])
 def test_bench_configuration_matches_the_oracle(weights, kernel_set):
     from open_provence_amd.packing import pack_rows
 
@@ -64,10 +64,7 @@ def test_bench_configuration_matches_the_oracle(weights, kernel_set):
     enc.profile_enable(False)
     # the launches bench.py times: no embedding / final-norm launches, the large-batch q / k / v kernel with the gather
     assert "embed_ln" not in kinds and "rowgemm_ln_qkv_rope" in kinds, kinds
-    if weights == "bf16":
-        assert "fused_layer_attnout_mlp_qkv" in kinds and "final_ln_prune" not in kinds, kinds
-    else:
-        assert "fused_attnout_ln_wi_geglu" in kinds and "fused_mlpout_ln_qkv_rope" in kinds, kinds
+    assert "fused_layer_attnout_mlp_qkv" in kinds and "final_ln_prune" not in kinds, kinds  # one launch per layer, either dtype
     prune1, rank1 = prune1.cpu().numpy().reshape(PAIRS, SEQ_LEN, 2), rank1.cpu().numpy()
 
     # two half-batch launch sequences on CU-partitioned streams (bench.py: the headline `value`)
