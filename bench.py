@@ -11,6 +11,13 @@ shared by all contexts, random-init weights (no network: no checkpoint, no datas
 scaling: every rank processes its own 256 pairs (no data-path collective) and the per-pair outputs are
 gathered on rank 0 over RCCL inside the timed step.  Rank 0 prints ONE JSON line.
 
+Checkpoint dtype.  The headline (`value`) is the FP32-valued checkpoint: the reference's training wrapper loads the
+backbone in fp32 (encoder.py:128-144), `bf16: true` of configs/open-provence-reranker-xsmall-v1.yaml:94 is HF-Trainer
+autocast over fp32 master weights, and save_pretrained writes state_dict() as it stands (encoder.py:1040-1094) -- and
+fp32 weights are what the CPU reference, the parity target, computes with.  The same weights rounded to bf16 (what the
+reference's GPU default `dtype=bfloat16` makes of them at load time, standalone.py:219-233) are timed by the same
+command and reported as the `bf16_checkpoint` sub-record.
+
 On one GPU a step enqueues the batch as TWO independent launch sequences (the two halves of the pairs, each on its own
 HIP stream bound to one half of the CUs: ``HipEncoder.forward_packed_on``, ``--pipelines 1`` turns it off): +2.9 %
 pairs/s same-box, because the halves drift out of phase and one's memory phases fill the other's MFMA phases.  The
@@ -137,10 +144,15 @@ def main() -> None:
     parser.add_argument("--seq-len", type=int, default=512)
     parser.add_argument("--model", default="xsmall", choices=["xsmall", "base", "large", "en-gte"])
     parser.add_argument("--precision", default="bf16x3", help="bf16x3 | bf16x2 | bf16 | family=mask,... (see open_provence_amd.engine.parse_precision)")
-    parser.add_argument("--weights", default="bf16", choices=["bf16", "fp32"],
-                        help="dtype of the synthetic checkpoint: bf16 (BASELINE.json configs[1]; what the reference loads on a "
-                        "GPU, standalone.py:219-233) or fp32.  The arithmetic policy is --precision either way; with a bf16 "
-                        "checkpoint the hi x lo(weight) MFMA pass is dropped because that plane is identically zero")
+    parser.add_argument("--weights", default="fp32", choices=["bf16", "fp32"],
+                        help="what the synthetic checkpoint stores.  fp32 (default, the headline): what the reference's "
+                        "save_pretrained writes (encoder.py:128-144 loads the backbone in fp32, bf16: true of the training "
+                        "config is HF-Trainer autocast over fp32 master weights, encoder.py:1040-1094 saves state_dict() as "
+                        "is) and what its CPU path -- the parity target -- computes with.  bf16: the same weights rounded to "
+                        "bf16, i.e. what the reference's GPU default makes of them at load time (standalone.py:219-233); "
+                        "reported as the `bf16_checkpoint` sub-record of the default run.  The arithmetic policy is "
+                        "--precision either way")
+    parser.add_argument("--no-other-dtype", action="store_true", help="skip the sub-record of the other checkpoint dtype")
     parser.add_argument("--chunk-rows", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-long", action="store_true", help="skip the seq_len 2048 sub-record")
@@ -261,6 +273,14 @@ def main() -> None:
     # per-step device times from events on the launch stream (the library enqueues on torch's current stream)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     mark_stream = encoder.pipeline_stream(1) if pipes else torch.cuda.current_stream(device)
+    # the shader clock the chip holds while the timed steps run: a one-wave probe on its own stream spins for about
+    # half of the expected loop time (estimated from two more untimed steps)
+    te = time.perf_counter()
+    for _ in range(2):
+        step()
+    fence()
+    est_step = (time.perf_counter() - te) / 2
+    probe, probe_stream = encoder.clock_probe(max(200, int(est_step * args.steps * 0.5e6)))
     t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record(mark_stream)
@@ -268,6 +288,9 @@ def main() -> None:
     marks[args.steps].record(mark_stream)
     fence()
     elapsed = time.perf_counter() - t0
+    probe_stream.synchronize()
+    probe_cycles, probe_ticks = (int(v) for v in probe.cpu().tolist())
+    shader_clock_ghz = probe_cycles / max(probe_ticks, 1) * 0.1
     step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -342,8 +365,18 @@ def main() -> None:
     }
     flops_per_forward = {kind: sum(parts.values()) for kind, parts in fam_flops.items()}
     terms = policy["terms"]
-    executed_per_forward = {kind: sum(f * (1 + (terms[fam] & 1) + ((terms[fam] >> 1) & 1)) for fam, f in parts.items())
-                            for kind, parts in fam_flops.items()}
+
+    def units(fam: str, kind: str) -> float:
+        """MFMA pipe time per algorithmic product, in 16-bit-MFMA units.  (hi, lo) bf16 kernels: one unit per evaluated
+        term.  The whole-layer kernel of the fp16 + e4m3 sets: a lo term of a K = hidden contraction is an e4m3 product
+        at twice the rate (0.5 unit); the MLP output projection (K = 32 per step) keeps 16-bit lo terms."""
+
+        n_lo = (terms[fam] & 1) + ((terms[fam] >> 1) & 1)
+        if policy["kernel_set"] in ("f16-f8", "f16-f8-w") and kind == "fused_layer_attnout_mlp_qkv" and fam != "mlp_out":
+            return 1.0 + 0.5 * n_lo
+        return 1.0 + n_lo
+
+    executed_per_forward = {kind: sum(f * units(fam, kind) for fam, f in parts.items()) for kind, parts in fam_flops.items()}
     roofline = None
     if dominant in flops_per_forward:
         entry = profile[dominant]
@@ -380,8 +413,16 @@ def main() -> None:
             # per-kernel figures (achieved, avg_launch_ms, traffic) are those of a launch over the whole batch on the whole
             # chip -- the form rocprofv3 sees and every rank of a multi-GPU run executes; `value` may come from two
             # half-batch launch sequences side by side (config.parallelism), whose launches each use half the CUs
-            "measured_as": "one launch sequence over the whole batch (HIP events around each launch, separate pass)",
+            "measured_as": "one launch sequence over the whole batch; avg_launch_ms is EVENT-BRACKETED (HIP events around each "
+            "launch in a separate pass: ~10 % above the launch's time inside the un-bracketed step -- rocprofv3 kernel-trace "
+            "averages of this command are in profiles/); traffic from the committed PMC passes (profiles/pmc_traffic.json)",
+            "avg_launch_ms_source": "event_bracketed",
+            # dominant kernel's time inside the UN-bracketed step: its event-bracketed share of the step's kernel time,
+            # applied to the measured step (one source = this run)
+            "avg_launch_ms_in_step": (one_pipeline["ms_per_step"] if one_pipeline else ms_per_step) * entry["total_ms"]
+            / max(sum(v["total_ms"] for v in profile.values()), 1e-9) / launches_per_forward,
         }
+        roofline["frac_in_step"] = flops_per_launch / (roofline["avg_launch_ms_in_step"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS
 
     line = {
         "metric": ("query-context pairs/sec @ mixed seq_len 128-2048, %s-v1" % args.model) if args.varlen
@@ -420,6 +461,8 @@ def main() -> None:
     }
     if one_pipeline is not None:
         line["one_pipeline"] = one_pipeline
+    line["shader_clock_ghz"] = {"value": shader_clock_ghz, "source": "one-wave probe (s_memtime / s_memrealtime) on its own stream "
+                                "during the first half of the timed loop; the 2.5 PFLOP/s peak assumes 2.4 GHz"}
     line["step_ms"] = {"median": float(np.median(step_ms)), "p10": float(np.percentile(step_ms, 10)),
                        "p90": float(np.percentile(step_ms, 90)), "source": "HIP events on the launch stream" + (" of the second half-batch" if pipes else "") + ", rank 0"}
     if world == 1 and not args.varlen and args.seq_len != 2048 and not args.no_long:
@@ -453,6 +496,51 @@ def main() -> None:
         line["seq_len_2048"] = {"value": long_pairs / dt, "unit": "pairs/s", "pairs": long_pairs, "steps": long_steps,
                                 "ms_per_step": dt * 1e3, "algorithmic_gflop_per_pair": flops_l / 1e9,
                                 "whole_forward_frac": long_pairs / dt * flops_l / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+    if world == 1 and not args.varlen and not args.no_other_dtype:
+        # the same workload with the OTHER checkpoint dtype, timed by the same command (sub-record, not the headline)
+        other = "bf16" if args.weights == "fp32" else "fp32"
+        state_o = synth_state_dict(dims, seed=7)
+        if other == "bf16":
+            state_o = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state_o.items()}
+        enc_o = HipEncoder(dims, device=device, precision=args.precision, chunk_rows=args.chunk_rows or None)
+        enc_o.load_state_dict(state_o)
+        policy_o = enc_o.effective_policy()
+
+        def step_o(two: bool):
+            if two and pipes:
+                for part, p_ids, p_cu, p_cu_np, p_max, p_keep, _plan in pipes:
+                    enc_o.forward_packed_on(part, p_ids, p_cu, p_cu_np, p_max, keep_prob=p_keep)
+            else:
+                enc_o.forward_packed(ids, cu, cu_np, max_len, keep_prob=keep_dev)
+
+        def timed_o(two: bool) -> float:
+            for _ in range(args.warmup):
+                step_o(two)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_o(two)
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t1) / args.steps
+
+        dt_two, dt_one = timed_o(True), timed_o(False)
+        enc_o.profile_enable(True)
+        enc_o.profile_reset()
+        for _ in range(prof_steps):
+            enc_o.forward_packed(ids, cu, cu_np, max_len)
+        prof_o = enc_o.profile_read()
+        enc_o.profile_enable(False)
+        dom_o = max(prof_o.items(), key=lambda kv: kv[1]["total_ms"])[0]
+        sub = {"value": n_pairs_rank / dt_two, "unit": "pairs/s", "ms_per_step": dt_two * 1e3, "steps": args.steps,
+               "one_pipeline": n_pairs_rank / dt_one, "checkpoint_dtype": other, "policy": policy_o,
+               "whole_forward_frac": n_pairs_rank / dt_two * flops_pair / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+               "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in prof_o.items()}}
+        if dom_o in flops_per_forward:
+            lpf = prof_o[dom_o]["launches"] / prof_steps
+            sub["roofline"] = {"kernel": dom_o, "avg_launch_ms": prof_o[dom_o]["avg_ms"], "avg_launch_ms_source": "event_bracketed",
+                               "frac": flops_per_forward[dom_o] / lpf / (prof_o[dom_o]["avg_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+        line[f"{other}_checkpoint"] = sub
+        enc_o.close()
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dims, state, args.seq_len)
     print(json.dumps(line), flush=True)

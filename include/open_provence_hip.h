@@ -195,6 +195,12 @@ int op_profile_read(op_handle* h, op_profile_entry* entries, int max_entries); /
 int op_profile_reset(op_handle* h);
 const char* op_profile_kind_name(int kind);
 
+/* Measurement hook: one wave spins for `spin_us` microseconds (of the constant 100 MHz counter) on `hip_stream` --
+ * a stream of its own, next to the timed work -- and writes out_dev[0] = shader cycles elapsed (s_memtime), out_dev[1] =
+ * 100 MHz ticks elapsed (s_memrealtime): out[0] / out[1] / 10 = the shader clock in GHz the chip HELD while the timed
+ * loop ran (the power limit, not the nominal 2.4 GHz, sets it: DESIGN.md section 4).  out_dev: two uint64. */
+int op_debug_clock_probe(op_handle* h, int spin_us, unsigned long long* out_dev, void* hip_stream);
+
 /* Replaces: nothing in the reference (it has no multi-GPU path); helper for SURVEY.md section 8e. */
 int op_device_count(int* count);
 

@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "op_profile_reset",
     "op_profile_kind_name",
     "op_device_count",
+    "op_debug_clock_probe",
     "op_destroy",
     "op_last_error",
 )
@@ -138,6 +139,8 @@ def load_library() -> ctypes.CDLL:
     lib.op_profile_reset.argtypes = [vp]
     lib.op_profile_kind_name.restype = ctypes.c_char_p
     lib.op_profile_kind_name.argtypes = [ci]
+    lib.op_debug_clock_probe.restype = ci
+    lib.op_debug_clock_probe.argtypes = [vp, ci, vp, vp]
     lib.op_device_count.restype = ci
     lib.op_device_count.argtypes = [ctypes.POINTER(ci)]
     lib.op_destroy.restype = None

@@ -1264,6 +1264,14 @@ int op_segment_means(op_handle* h, const float* keep_prob_dev, int n_values, con
   return OP_OK;
 }
 
+int op_debug_clock_probe(op_handle* h, int spin_us, unsigned long long* out_dev, void* hip_stream) {
+  if (!h || !out_dev || spin_us <= 0) return fail(h, OP_ERR_INVALID, "op_debug_clock_probe: bad argument");
+  OP_HIP(h, hipSetDevice(h->cfg.device_id));
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, (unsigned long long)spin_us * 100ull, out_dev);
+  OP_HIP(h, hipGetLastError());
+  return OP_OK;
+}
+
 int op_profile_reset(op_handle* h) {
   if (!h) return fail(nullptr, OP_ERR_INVALID, "op_profile_reset: NULL handle");
   int rc = drain_profile(h);

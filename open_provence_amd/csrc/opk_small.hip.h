@@ -485,6 +485,22 @@ __device__ inline float np_pairwise_sum_f32(const float* a, int n) {
   return ret;
 }
 
+// one wave: shader cycles and 100 MHz ticks over a spin of `ticks` ticks (op_debug_clock_probe)
+__global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long* __restrict__ out) {
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  const unsigned long long r0 = wall_clock64();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    r1 = wall_clock64();
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+  }
+}
+
 __global__ void segment_mean_kernel(const float* __restrict__ values, const int32_t* __restrict__ seg, int n_seg,
                                     int n_values, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

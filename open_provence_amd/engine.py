@@ -143,15 +143,9 @@ class HipEncoder:
         if handle is not None and handle.value:
             self.lib.op_destroy(handle)
             self._handle = ctypes.c_void_p()
-        st = getattr(self, "_split_state", None)
-        if st is not None:  # the CU-masked streams were created through the HIP runtime directly: destroy them here
-            self._split_state = None
-            for raw in st.get("raw_streams", []):
-                try:
-                    st["hip"].hipStreamSynchronize(ctypes.c_void_p(raw))
-                    st["hip"].hipStreamDestroy(ctypes.c_void_p(raw))
-                except Exception:  # pragma: no cover - interpreter shutdown
-                    pass
+        # (the two CU-masked streams of forward_packed_on stay alive for the life of the process: torch's caching allocator
+        # keeps events on them for the outputs handed over with record_stream, and destroying a stream under it faults)
+        self._split_state = None
 
     def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
         try:
@@ -423,6 +417,19 @@ class HipEncoder:
     @property
     def captured(self) -> torch.Tensor:
         return self._capture_result
+
+    def clock_probe(self, spin_us: int) -> "tuple[torch.Tensor, torch.cuda.Stream]":
+        """Start a one-wave probe on a stream of its own that spins for ``spin_us`` microseconds beside whatever runs
+        meanwhile; returns (uint64 tensor [shader cycles, 100 MHz ticks], its stream).  After synchronising that stream,
+        ``cycles / ticks / 10`` = the shader clock in GHz the chip held (measurement hook: bench.py)."""
+
+        with torch.cuda.device(self.device):
+            side = torch.cuda.Stream(self.device)
+            out = torch.zeros(2, dtype=torch.int64, device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            code = self.lib.op_debug_clock_probe(self._handle, int(spin_us), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+        _lib.check(self.lib, self._handle, code, "op_debug_clock_probe")
+        return out, side
 
     def profile_enable(self, enabled: bool) -> None:
         _lib.check(self.lib, self._handle, self.lib.op_profile_enable(self._handle, 1 if enabled else 0), "profile")

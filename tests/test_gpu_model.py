@@ -105,6 +105,7 @@ def test_from_pretrained_roundtrip_including_legacy_keys_and_bf16_weights(tmp_pa
     cfg = OpenProvenceConfig(
         base_model_config=meta["base_model_config"], tokenizer_name_or_path="x",
         pruning_config={"hidden_size": 128}, max_length=128, default_threadshold=0.2,
+        pruning_hidden_state="post_final_norm",  # pinned: an unstamped config.json would otherwise resolve to the 4.x convention
     )
     rows = rows_from_fixture(arrays)
     ref_model = OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
