@@ -515,14 +515,17 @@ class OpenProvenceModel:
         )
 
     # -- data parallelism over (query, block) rows -----------------------------------
-    def attach_process_group(self, group: Any | None = None, *, dst: int = 0, enabled: bool = True) -> None:
+    def attach_process_group(self, group: Any | None = None, *, dst: int = 0, enabled: bool = True,
+                             single_rank_gather: bool = False) -> None:
         """Shard every forward batch of ``process()`` / ``get_raw_predictions_batch`` over the ranks of a
         ``torch.distributed`` process group (backend "nccl" = RCCL over xGMI with one process per GPU; "gloo" in the
         CPU tests).  Every rank calls ``process()`` with the SAME arguments; each runs its token-balanced share of the
         rows (full weight replica per GPU, no data-path collective), ONE gather moves the keep-probabilities
         (4 B per token) + ranking logits to rank ``dst``, which post-processes and returns the result; the other
         ranks' ``process()`` returns ``None``.  The reference has no multi-GPU path (its jobs are independent:
-        standalone.py:2748-2756)."""
+        standalone.py:2748-2756).  The pipelined path of ``process()`` stays in force: every rank enqueues its share
+        asynchronously (pinned staging, on-device fragment means) and the gather moves 4 bytes per FRAGMENT.
+        ``single_rank_gather`` (test hook): run the sharded code path on a one-rank group as well."""
 
         import torch.distributed as dist
 
@@ -531,7 +534,8 @@ class OpenProvenceModel:
             return
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("attach_process_group needs an initialised torch.distributed process group")
-        self._dist = {"group": group, "dst": int(dst), "rank": dist.get_rank(group), "world": dist.get_world_size(group)}
+        self._dist = {"group": group, "dst": int(dst), "rank": dist.get_rank(group), "world": dist.get_world_size(group),
+                      "force": bool(single_rank_gather)}
 
     def _predict_rows(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
         """Rows of token ids -> (ranking_logits[B, nl] fp32 CPU, per-row keep probabilities fp32); sharded over the
@@ -569,8 +573,12 @@ class OpenProvenceModel:
 
     # -- asynchronous forward: launch now, collect later (host stages of the neighbouring batches overlap the GPU) -----
     def _can_pipeline(self) -> bool:
+        # (also with a process group attached: _launch_rows enqueues this rank's share, _collect_rows gathers)
+        return self._forward_is_native()
+
+    def _dist_info(self) -> dict[str, Any] | None:
         info = getattr(self, "_dist", None)
-        return self._forward_is_native() and not (info and info["world"] > 1)
+        return info if info and (info["world"] > 1 or info.get("force")) else None
 
     def _staging(self, slot: int, n_tokens: int, n_rows: int) -> dict[str, torch.Tensor]:
         """Pinned host staging buffers (two slots, grown on demand, reused across calls: pinning memory costs ms).
@@ -604,9 +612,29 @@ class OpenProvenceModel:
         over every range is taken there (``op_segment_means``: numpy's float32 pairwise order, bit for bit) and only
         4 bytes per range come back."""
 
+        info = self._dist_info()
+        shard = None
+        if info is not None:
+            # Data parallelism over the rows (SURVEY.md section 8e): the token-balanced plan every rank derives from the
+            # row lengths alone; this rank enqueues only its share -- same pinned staging, same asynchronous copies, same
+            # on-device fragment means as the single-GPU path -- and _collect_rows gathers 4 bytes per FRAGMENT (or per
+            # token, without segments) + the ranking logits on the post-processing rank.
+            from .sharding import ShardPlan
+
+            lengths = [len(r) for r in rows]
+            token_plan = ShardPlan(lengths, info["world"], width=1, num_labels=int(self.dims.num_labels))
+            mine = token_plan.local_rows(info["rank"])
+            shard = {"mine": mine, "n_rows_all": len(rows), "lengths": lengths, "shards": token_plan.shards,
+                     "counts_all": [len(sg) for sg in segments] if segments is not None else None}
+            rows = [rows[i] for i in mine]
+            if segments is not None:
+                segments = [segments[i] for i in mine]
         ids_np, cu_np, max_len = pack_rows(rows)
         self.encoder.check_ids(ids_np)
         total, n_rows, nl = int(cu_np[-1]), len(rows), int(self.dims.num_labels)
+        if n_rows == 0:  # (more ranks than rows) nothing to enqueue here; the gather still runs on every rank
+            return {"event": None, "pool": None, "total": 0, "rows": 0, "cu": cu_np, "seg_counts": [] if segments is not None else None,
+                    "alive": None, "shard": shard}
         slot = self.__dict__["_staging_slot"] = (self.__dict__.get("_staging_slot", -1) + 1) % 2
         pool = self._staging(slot, total, n_rows)
         dev = self._runtime_device
@@ -643,12 +671,14 @@ class OpenProvenceModel:
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev))
         return {"event": event, "pool": pool, "total": total, "rows": n_rows, "cu": cu_np, "seg_counts": seg_counts,
-                "alive": (ids_dev, cu_dev, keep_dev, rank_dev, seg_dev, means_dev)}
+                "alive": (ids_dev, cu_dev, keep_dev, rank_dev, seg_dev, means_dev), "shard": shard}
 
     def _collect_rows(self, handle: dict[str, Any]) -> tuple[torch.Tensor, list[Any]]:
         """-> (ranking logits, per row: its keep-probabilities, or -- launched with ``segments`` -- the list of its
         range means as Python floats)."""
 
+        if handle.get("shard") is not None:
+            return self._collect_rows_sharded(handle)
         handle["event"].synchronize()
         total, n_rows, nl, cu = handle["total"], handle["rows"], int(self.dims.num_labels), handle["cu"]
         rank = torch.from_numpy(handle["pool"]["rank_np"][: n_rows * nl].copy()).reshape(n_rows, nl)
@@ -663,6 +693,45 @@ class OpenProvenceModel:
             return rank, out
         keep = handle["pool"]["keep_np"][:total].copy()  # the slot is reused two launches later
         return rank, [keep[cu[i] : cu[i + 1]] for i in range(n_rows)]
+
+    def _collect_rows_sharded(self, handle: dict[str, Any]) -> tuple[torch.Tensor, list[Any]]:
+        """The group form of :meth:`_collect_rows`: wait for this rank's launch, then ONE gather of fixed-size payloads
+        (per-fragment means -- or, launched without segments, per-token keep-probabilities -- + ranking logits) to
+        rank ``dst`` (RCCL over xGMI with backend "nccl"; the payload is KBs).  Every rank calls this for the same
+        handles in the same order; ranks other than ``dst`` get zero placeholders (their ``process()`` result is
+        discarded)."""
+
+        import torch.distributed as dist
+
+        from .sharding import ShardPlan
+
+        info, shard = self._dist_info(), handle["shard"]
+        nl = int(self.dims.num_labels)
+        n_all, lengths, counts_all = shard["n_rows_all"], shard["lengths"], shard["counts_all"]
+        per_row = counts_all if counts_all is not None else lengths  # values per row in the payload
+        if handle["event"] is not None:
+            handle["event"].synchronize()
+        n_rows, n_val = handle["rows"], (sum(handle["seg_counts"]) if counts_all is not None else handle["total"])
+        if n_rows:
+            values = torch.from_numpy(handle["pool"]["keep_np"][:n_val].copy())
+            rank_local = torch.from_numpy(handle["pool"]["rank_np"][: n_rows * nl].copy()).reshape(n_rows, nl)
+        else:
+            values, rank_local = torch.zeros(0, dtype=torch.float32), torch.zeros((0, nl), dtype=torch.float32)
+        handle["alive"] = None
+        plan = ShardPlan(per_row, info["world"], width=1, num_labels=nl, shards=shard["shards"])  # the launch's row assignment
+        comm = self._runtime_device if dist.get_backend(info["group"]) == "nccl" else torch.device("cpu")
+        gathered = plan.gather(values.to(comm), rank_local.to(comm), dst=info["dst"], group=info["group"])
+        if gathered is None:
+            if counts_all is not None:
+                return torch.zeros((n_all, nl), dtype=torch.float32), [[0.0] * c for c in counts_all]
+            return torch.zeros((n_all, nl), dtype=torch.float32), [np.zeros(n, dtype=np.float32) for n in lengths]
+        vals, rank_all = gathered
+        flat = vals.reshape(-1).cpu().numpy()
+        cu = plan.cu
+        if counts_all is not None:
+            as_list = flat.tolist()  # float32 -> Python float, exact
+            return rank_all.cpu(), [as_list[cu[i] : cu[i + 1]] for i in range(n_all)]
+        return rank_all.cpu(), [flat[cu[i] : cu[i + 1]] for i in range(n_all)]
 
     def _predict_rows_local(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
         """This process's rows -> (ranking_logits[B, nl] fp32 CPU, per-row keep probabilities fp32).

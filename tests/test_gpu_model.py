@@ -523,6 +523,19 @@ def test_sharded_forward_over_a_one_rank_nccl_group_is_bit_identical():
         assert torch.equal(all_rank, rank)
         for i in range(len(rows)):
             assert torch.equal(per_row[i], prune[cu[i] : cu[i + 1]]), i
+        # process() with the group attached keeps its pipelined path (asynchronous launches, on-device fragment means,
+        # a gather of 4 bytes per fragment over RCCL): identical to the single-GPU process(), field for field
+        model, meta = _g3_model()
+        plain = [model.process(question=c["question"], context=c["context"], sentence_splitter=period_splitter, show_progress=False,
+                               return_sentence_metrics=True, return_sentence_texts=True, **c["kwargs"]) for c in meta["cases"]]
+        model.attach_process_group(None, dst=0, single_rank_gather=True)
+        assert model._can_pipeline() and model._dist_info() is not None
+        for case, want in zip(meta["cases"], plain):
+            got = model.process(question=case["question"], context=case["context"], sentence_splitter=period_splitter,
+                                show_progress=False, return_sentence_metrics=True, return_sentence_texts=True, **case["kwargs"])
+            for key in ("pruned_context", "reranking_score", "compression_rate", "kept_sentences", "removed_sentences", "sentence_probabilities"):
+                assert got[key] == want[key], key
+            assert_process_result_matches(got, case["expected"], prob_tol=1e-3, score_tol=1e-3)
     finally:
         dist.destroy_process_group()
 

@@ -230,3 +230,57 @@ def test_gather_on_a_real_sub_group_translates_the_root_rank(tmp_path):
     assert [t.shape[0] for t in got["legacy_rows"]] == lengths
     assert all(torch.all(t == float(i)) for i, t in enumerate(got["legacy_rows"]))
     assert torch.equal(got["legacy_rank"], torch.tensor([[float(i)] for i in range(len(lengths))]))
+
+
+def _collect_worker(rank, world, port, out_path):
+    """The group form of the pipelined collect (modeling._collect_rows_sharded) on fabricated launch handles: each
+    rank holds the fragment means + ranking logits of ITS rows, rank 0 must get every row's values in row order."""
+
+    import sys
+    from pathlib import Path
+    from types import SimpleNamespace
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from helpers import CharTokenizer, host_only_model
+
+    from open_provence_amd.sharding import ShardPlan
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = host_only_model(tokenizer=CharTokenizer())
+        model.dims = SimpleNamespace(num_labels=2)
+        model.attach_process_group(None, dst=0)
+        lengths = [40, 7, 512, 130, 64, 300, 9]
+        counts = [3, 1, 11, 4, 2, 7, 1]  # fragments per row
+        plan = ShardPlan(lengths, world, width=1, num_labels=2)
+        mine = plan.local_rows(rank)
+        for with_segments in (True, False):
+            per_row = counts if with_segments else lengths
+            vals = np.concatenate([np.arange(per_row[i], dtype=np.float32) + 1000.0 * i for i in mine]) if mine else np.zeros(0, np.float32)
+            rk = np.asarray([[float(i), -float(i)] for i in mine], dtype=np.float32).reshape(-1)
+            handle = {"event": None, "pool": {"keep_np": vals, "rank_np": rk}, "total": int(sum(lengths[i] for i in mine)),
+                      "rows": len(mine), "cu": None, "seg_counts": [counts[i] for i in mine] if with_segments else None, "alive": None,
+                      "shard": {"mine": mine, "n_rows_all": len(lengths), "lengths": lengths, "shards": plan.shards,
+                                "counts_all": counts if with_segments else None}}
+            rank_all, rows_out = model._collect_rows(handle)
+            assert rank_all.shape == (len(lengths), 2) and len(rows_out) == len(lengths)
+            if rank == 0:
+                assert torch.equal(rank_all, torch.tensor([[float(i), -float(i)] for i in range(len(lengths))]))
+                for i, got in enumerate(rows_out):
+                    want = (np.arange(per_row[i], dtype=np.float32) + 1000.0 * i)
+                    assert isinstance(got, list) == with_segments
+                    assert np.array_equal(np.asarray(got, dtype=np.float32), want), (with_segments, i)
+        if rank == 0:
+            torch.save({"ok": True}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_collect_gathers_fragment_means_in_row_order(tmp_path, world):
+    out_path = str(tmp_path / "collect.pt")
+    mp.spawn(_collect_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    assert torch.load(out_path)["ok"]
