@@ -39,6 +39,10 @@ from .pipeline import ContextState, FragmentRecord, RawPrediction
 from .splitters import SentenceSplitter, resolve_sentence_splitter
 
 LOGGER = logging.getLogger(__name__)
+# as the reference (standalone.py:160): the Rust tokenizer's own thread pool costs more than it returns on the ~10
+# sentences of one context (7 k voluntary context switches per 256 contexts measured); preprocess_workers is the
+# parallelism of this stage
+os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
 
 DEFAULT_SPLITTER_LANGUAGE = "auto"
 OpenProvenceRawPrediction = RawPrediction
@@ -1045,7 +1049,7 @@ class OpenProvenceModel:
 
     def _iter_jobs(
         self, queries, contexts, titles, splitter: SentenceSplitter, query_token_ids: list[list[int]], *,
-        strip_sentences: bool, timing: dict[str, float]
+        strip_sentences: bool, timing: dict[str, float], workers: int = 0
     ):
         """One job per (query, context), produced lazily: sentences (prefix + split or pre-split), their token lists
         and the prefix token counts (ref: _build_preprocess_jobs :2436-2519, _precompute_sentences_and_tokens :2198).
@@ -1055,37 +1059,71 @@ class OpenProvenceModel:
         consumer launches a forward asynchronously after every granule of jobs and comes back for the next ones, so the
         same overlap happens on one host thread."""
 
-        for q_idx, query in enumerate(queries):
-            query_token_ids.append([int(t) for t in self.tokenizer.encode(query, add_special_tokens=False)])
-            for c_idx, entry in enumerate(contexts[q_idx]):
-                if isinstance(entry, list):
-                    manual = [str(s) for s in entry if str(s).strip()]
-                    text = "".join(manual)
-                else:
-                    manual = None
-                    text = entry
-                prefix, title_is_first = self._resolve_prefix_sentences(titles[q_idx], c_idx)
-                payload = {"context_text": text, "prefix_sentences": prefix, "manual_sentences": manual}
-                t0 = perf_counter()
-                raw = pl.collect_candidate_sentences(payload, splitter)
-                t1 = perf_counter()
-                sentences = pl.normalize_sentences(raw, text, strip_sentences)
-                t2 = perf_counter()
-                token_lists = pl.tokenize_sentences(self.tokenizer, sentences)
-                t3 = perf_counter()
-                timing["sentence_collect_seconds"] += t1 - t0
-                timing["sentence_normalize_seconds"] += t2 - t1
-                timing["tokenize_seconds"] += t3 - t2
-                yield {
-                    "query_idx": q_idx,
-                    "context_idx": c_idx,
-                    "context_text": text,
-                    "prefix_sentences": prefix,
-                    "title_is_first_sentence": title_is_first,
-                    "prefix_token_counts": [len(t) for t in token_lists[: len(prefix)]],
-                    "sentences": sentences,
-                    "token_lists": token_lists,
-                }
+        def specs():
+            for q_idx, query in enumerate(queries):
+                query_token_ids.append([int(t) for t in self.tokenizer.encode(query, add_special_tokens=False)])
+                for c_idx, entry in enumerate(contexts[q_idx]):
+                    yield q_idx, c_idx, entry
+
+        def build(spec):
+            q_idx, c_idx, entry = spec
+            if isinstance(entry, list):
+                manual = [str(s) for s in entry if str(s).strip()]
+                text = "".join(manual)
+            else:
+                manual = None
+                text = entry
+            prefix, title_is_first = self._resolve_prefix_sentences(titles[q_idx], c_idx)
+            payload = {"context_text": text, "prefix_sentences": prefix, "manual_sentences": manual}
+            t0 = perf_counter()
+            raw = pl.collect_candidate_sentences(payload, splitter)
+            t1 = perf_counter()
+            sentences = pl.normalize_sentences(raw, text, strip_sentences)
+            t2 = perf_counter()
+            token_lists = pl.tokenize_sentences(self.tokenizer, sentences)
+            t3 = perf_counter()
+            return {
+                "query_idx": q_idx,
+                "context_idx": c_idx,
+                "context_text": text,
+                "prefix_sentences": prefix,
+                "title_is_first_sentence": title_is_first,
+                "prefix_token_counts": [len(t) for t in token_lists[: len(prefix)]],
+                "sentences": sentences,
+                "token_lists": token_lists,
+            }, (t1 - t0, t2 - t1, t3 - t2)
+
+        def account(times):
+            timing["sentence_collect_seconds"] += times[0]
+            timing["sentence_normalize_seconds"] += times[1]
+            timing["tokenize_seconds"] += times[2]
+
+        if workers <= 0:
+            for spec in specs():
+                job, times = build(spec)
+                account(times)
+                yield job
+            return
+        # preprocess_workers > 0: the reference runs this stage in DataLoader worker processes (standalone.py:3589,
+        # :2478-2519).  Here: worker THREADS with a bounded look-ahead, results yielded in order.  The expensive calls
+        # release the GIL where it matters -- a Hugging Face fast tokenizer (Rust `encode_batch`) and the Rust / C
+        # sentence splitters (fast-bunkai, nltk's regex core) -- and no process is forked next to a live HIP runtime.
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        window = max(2 * workers, 8)
+        with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="open-provence-prep") as pool:
+            inflight: deque = deque()
+            for spec in specs():
+                inflight.append(pool.submit(build, spec))
+                if len(inflight) >= window:
+                    job, times = inflight.popleft().result()
+                    account(times)
+                    yield job
+            while inflight:
+                job, times = inflight.popleft().result()
+                account(times)
+                yield job
 
     def _build_jobs(
         self, queries, contexts, titles, splitter: SentenceSplitter, *, strip_sentences: bool, timing: dict[str, float]
@@ -1218,7 +1256,8 @@ class OpenProvenceModel:
         Same parameters, input-shape dispatch and result keys as the reference's ``process``
         (standalone.py:3314-3808): ``pruned_context``, ``reranking_score``, ``compression_rate``, ``title``,
         ``timing``, ``performance_trace`` and, on request, ``kept_sentences`` / ``removed_sentences`` /
-        ``sentence_probabilities``.  ``preprocess_workers`` / ``torch_dataloader_kwargs`` are accepted for
+        ``sentence_probabilities``.  ``preprocess_workers`` / ``torch_dataloader_kwargs["num_workers"]`` start that many worker THREADS for the
+        split / tokenize stage; the other loader keys are accepted for
         compatibility; preprocessing runs in-process (the reference's worker processes only re-copied cached
         token ids) but the preprocess-batch heuristics that cap the forward batch are kept."""
 
@@ -1307,9 +1346,6 @@ class OpenProvenceModel:
             sep_token_ids = self.tokenizer.encode(self.tokenizer.sep_token or "", add_special_tokens=False)
 
             query_token_ids: list[list[int]] = []
-            job_stream = self._iter_jobs(
-                queries, contexts, titles, splitter, query_token_ids, strip_sentences=strip_sentences, timing=timing
-            )
             total_jobs = sum(len(per_query) for per_query in contexts)
 
             # effective preprocess batch (= cap of blocks per inference pass), as the reference computes it
@@ -1355,6 +1391,15 @@ class OpenProvenceModel:
                     f"default_workers={pl.default_preprocess_workers()}"
                 )
 
+            # Worker threads for the split / tokenize stage only on an explicit request (preprocess_workers=, the
+            # OPEN_PROVENCE_PREPROCESS_WORKERS variable or torch_dataloader_kwargs["num_workers"]): they pay off with
+            # GIL-releasing tokenizers / splitters, while pure-Python ones are served best by the lazy single-thread
+            # pipeline below (the reference's own default is 0 workers under 2000 jobs, standalone.py:2591-2592).
+            thread_workers = min(int(workers), 32) if (workers_explicit and workers > 0) else 0
+            job_stream = self._iter_jobs(
+                queries, contexts, titles, splitter, query_token_ids, strip_sentences=strip_sentences, timing=timing,
+                workers=thread_workers,
+            )
             states: dict[tuple[int, int], ContextState] = {}
             total_blocks = 0
             pending: list[Any] = []  # forwards in flight (pipelined native path)

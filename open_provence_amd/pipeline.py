@@ -277,8 +277,12 @@ def _int_list(ids: Any) -> list[int]:
     """``[int(t) for t in ids]`` without the per-token call when ``ids`` already is a list of Python ints (what HF
     fast tokenizers and this module's own stages hand over): the hot loops below copy ~500 ids per context."""
 
-    if type(ids) is list and (not ids or (type(ids[0]) is int and type(ids[-1]) is int and set(map(type, ids)) == {int})):
-        return ids  # the caller's list, NOT a copy: callers below never mutate it and copy where a row leaves this module
+    # First / last element only: a full scan costs more than the conversion it avoids (measured: +20 % on the preprocess
+    # stage).  A stray numpy integer inside such a list is harmless: rows enter the device through pack_rows, which
+    # converts through numpy.  The caller's list is returned, NOT a copy: callers below never mutate it and copy where a
+    # row leaves this module.
+    if type(ids) is list and (not ids or (type(ids[0]) is int and type(ids[-1]) is int)):
+        return ids
     return [int(t) for t in ids]
 
 

@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--preprocess-batch", type=int, default=None, help="explicit preprocess batch (default: the pipeline granule)")
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--tokenizer", default="char", choices=["char", "wordpiece"],
+                    help="char: the pure-Python tokenizer of the tests; wordpiece: a Hugging Face fast (Rust) tokenizer built offline")
+    ap.add_argument("--workers", type=int, default=None, help="preprocess_workers (worker threads of the split / tokenize stage)")
+    ap.add_argument("--chars-are-words", action="store_true", help="wordpiece: size the contexts in words (~tokens) instead of characters")
     args = ap.parse_args()
 
     from open_provence_amd.config import OpenProvenceConfig
@@ -54,13 +58,19 @@ def main():
     dims = named_dims("xsmall")
     cfg = OpenProvenceConfig(base_model_config=dims.to_base_model_config(), tokenizer_name_or_path="x",
                              pruning_config={"hidden_size": dims.hidden_size}, max_length=512)
-    model = OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=synth_state_dict(dims, 7))
+    if args.tokenizer == "wordpiece":
+        from helpers import build_wordpiece_tokenizer
+
+        tok = build_wordpiece_tokenizer(True)
+    else:
+        tok = CharTokenizer()
+    model = OpenProvenceModel(cfg, device="cuda", tokenizer=tok, state_dict=synth_state_dict(dims, 7))
     model.tokenizer.model_max_length = 512
     question, contexts = make_request(args.contexts, args.chars)
 
     def call():
         return model.process(question, contexts, threshold=0.1, batch_size=args.batch_size, sentence_splitter=period_splitter,
-                             show_progress=False, preprocess_batch_size=args.preprocess_batch)
+                             show_progress=False, preprocess_batch_size=args.preprocess_batch, preprocess_workers=args.workers)
 
     call()
     torch.cuda.synchronize()
@@ -78,7 +88,7 @@ def main():
         if best is None or dt < best[0]:
             best = (dt, out["timing"], usage)
     dt, timing, usage = best
-    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "wall_s": dt, "contexts_per_s": args.contexts / dt, "rusage": usage,
+    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "tokenizer": args.tokenizer, "workers": args.workers, "wall_s": dt, "contexts_per_s": args.contexts / dt, "rusage": usage,
                       "timing": {k: round(float(v), 5) for k, v in timing.items()}}))
     if args.profile:
         pr = cProfile.Profile()

@@ -93,3 +93,30 @@ def test_mismatched_lengths_raise():
         model.process(["a", "b"], ["only one"], sentence_splitter=period_splitter, show_progress=False)
     with pytest.raises(ValueError):
         model.process("q", "ctx", title="T", first_line_as_title=True, sentence_splitter=period_splitter, show_progress=False)
+
+
+def test_preprocess_workers_give_identical_results_in_order():
+    """``preprocess_workers=N`` (reference: DataLoader worker processes, standalone.py:3589) runs the split / tokenize stage
+    on N worker threads with a bounded look-ahead: same jobs, same order, same result as the single-thread pipeline."""
+
+    import json
+    import threading
+
+    from helpers import GOLDEN_DIR, assert_process_result_matches
+
+    meta = json.loads((GOLDEN_DIR / "g3_process_stub.json").read_text(encoding="utf-8"))
+    seen_threads = set()
+
+    def splitter(text):
+        seen_threads.add(threading.current_thread().name)
+        return period_splitter(text)
+
+    model = host_only_model(tokenizer=CharTokenizer(), max_length=meta["max_length"], forward=golden_stub_forward)
+    for case in meta["cases"]:
+        kwargs = dict(question=case["question"], context=case["context"], sentence_splitter=splitter, show_progress=False,
+                      return_sentence_metrics=True, return_sentence_texts=True, batch_size=4, **case["kwargs"])
+        res = model.process(preprocess_workers=3, **kwargs)
+        assert_process_result_matches(res, case["expected"], prob_tol=1e-6, score_tol=1e-6)
+        res = model.process(torch_dataloader_kwargs={"num_workers": 2}, **kwargs)
+        assert_process_result_matches(res, case["expected"], prob_tol=1e-6, score_tol=1e-6)
+    assert any(name.startswith("open-provence-prep") for name in seen_threads), seen_threads
