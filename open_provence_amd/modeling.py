@@ -454,18 +454,18 @@ class OpenProvenceModel:
     # ------------------------------------------------------------------------------------------
     @staticmethod
     def _extract_model_output(outputs: Any, key: str) -> torch.Tensor:
-        candidate = None
-        if isinstance(outputs, Mapping):
-            candidate = outputs.get(key)
-            if candidate is None and key == "ranking_logits":
-                candidate = outputs.get("logits")
-        if candidate is None:
-            candidate = getattr(outputs, key, None)
-            if candidate is None and key == "ranking_logits":
-                candidate = getattr(outputs, "logits", None)
-        if candidate is None:
-            raise KeyError(f"{key} not found in model outputs")
-        return candidate
+        """``key`` of a forward result that may be a Mapping or an attribute bag (the boundary contract of
+        standalone.py:1540-1555: the reference's tests replace ``forward`` by a plain dict); ``logits`` stands in for
+        ``ranking_logits``."""
+
+        names = (key, "logits") if key == "ranking_logits" else (key,)
+        for name in names:
+            value = outputs.get(name) if isinstance(outputs, Mapping) else None
+            if value is None:
+                value = getattr(outputs, name, None)
+            if value is not None:
+                return value
+        raise KeyError(f"{key} not found in model outputs")
 
     def forward(
         self,
@@ -842,15 +842,23 @@ class OpenProvenceModel:
             chunk_queries = queries[start : start + batch_size]
             rows = self._encode_texts([q + sep + "".join(c) for q, c in zip(chunk_queries, chunk)], truncate=True)
             rank, keeps = self._predict_rows(rows, None)
+            # the reference returns every row's probabilities at the padded batch width (standalone.py:1820-1823: softmax
+            # over the padded logits tensor); positions past the row's tokens carry softmax([0, 0])[1] = 0.5 here (the
+            # forward boundary zero-fills masked positions; the reference's values there are whatever the model makes of
+            # pad tokens, and no range ever addresses them)
+            width = max((len(r) for r in rows), default=0)
             for i, ctxs in enumerate(chunk):
                 if len(ctxs) == 0:
                     continue
+                probs = np.asarray(keeps[i], dtype=np.float32)
+                if len(probs) < width:
+                    probs = np.concatenate([probs, np.full(width - len(probs), 0.5, dtype=np.float32)])
                 results.append(
                     RawPrediction(
                         query=chunk_queries[i],
                         contexts=list(ctxs),
                         ranking_score=self._ranking_score(rank[i]),
-                        pruning_probs=keeps[i],
+                        pruning_probs=probs,
                         context_ranges=self._context_ranges_from_contexts(chunk_queries[i], ctxs),
                     )
                 )

@@ -121,26 +121,32 @@ def normalize_inputs(question: str | Sequence[str], context: Any) -> tuple[list[
 #         _resolve_titles :2412-2434, _resolve_prefix_sentences :1971-2005)
 # ---------------------------------------------------------------------------------------------
 def prepare_titles(title: Any, queries: list[str], contexts: list[list[Any]]) -> list[Any]:
-    n_queries = len(queries)
+    """The ``title=`` argument of ``process()`` -> one entry per query: ``None`` (no titles), the marker
+    ``"first_sentence"``, or one title string per context of that query.  Accepted shapes (the reference's contract,
+    standalone.py:2325-2360): a single string for every context; for ONE query a flat list with a title per context; for
+    several queries either a title per query (shared by its contexts) or a list of per-context titles per query."""
+
+    count = len(queries)
     if title is None:
-        return [None] * n_queries
+        return [None] * count
     if isinstance(title, str):
         if title == "first_sentence":
-            return ["first_sentence"] * n_queries
-        return [[title for _ in ctxs] for ctxs in contexts]
-    if isinstance(title, Sequence):
-        normalized: list[Any] = []
-        for entry in title:
-            if isinstance(entry, Sequence) and not isinstance(entry, str):
-                normalized.append([str(v) for v in entry])
-            else:
-                normalized.append(str(entry))
-        if n_queries == 1 and all(isinstance(item, str) for item in normalized):
-            return [[str(item) for item in normalized]]
-        if len(normalized) == n_queries and all(isinstance(item, list) for item in normalized):
-            return [list(map(str, item)) for item in normalized]
-        if len(normalized) == n_queries and all(isinstance(item, str) for item in normalized):
-            return [[value for _ in contexts[idx]] for idx, value in enumerate(normalized)]
+            return [title] * count
+        return [[title] * len(per_query) for per_query in contexts]
+    if not isinstance(title, Sequence):
+        raise ValueError("Unsupported title format")
+
+    def is_nested(entry: Any) -> bool:
+        return isinstance(entry, Sequence) and not isinstance(entry, str)
+
+    entries = [[str(v) for v in entry] if is_nested(entry) else str(entry) for entry in title]
+    nested = [isinstance(entry, list) for entry in entries]
+    if count == 1 and not any(nested):
+        return [entries]  # one query: the flat list is its per-context titles
+    if len(entries) == count and all(nested):
+        return entries
+    if len(entries) == count and not any(nested):
+        return [[entries[q]] * len(contexts[q]) for q in range(count)]
     raise ValueError("Unsupported title format")
 
 
