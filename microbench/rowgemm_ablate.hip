@@ -147,21 +147,21 @@ int main() {
   {
     // o: fp16 pieces [R/16][KS][512] then e4m3 pieces [R/16][KS/2][1 KiB]; Wo: fp16 slabs + e4m3 slabs; Wi / Wqkv: chunks
     // of (2 KS + KS) pieces; Wo(mlp): fp16 slabs
-    std::vector<u16> ob((size_t)R * H * 2), wob((size_t)H * H * 2), wib((size_t)2 * I * H * 2), wo2b((size_t)H * I), wqb((size_t)3 * H * H * 2);
+    std::vector<u16> ob((size_t)R * H * 2), wob((size_t)H * H * 2), wib((size_t)2 * I * H * 2), wo2b((size_t)H * I * 2), wqb((size_t)3 * H * H * 2);
     if (!zero_data) {
       fill_f16(ob.data(), (size_t)R * H, 11, 1.0f);
       fill_e4m3(reinterpret_cast<unsigned char*>(ob.data() + (size_t)R * H), (size_t)R * H, 12, 12);
       fill_f16(wob.data(), (size_t)H * H, 13, 0.06f);
-      fill_e4m3(reinterpret_cast<unsigned char*>(wob.data() + (size_t)H * H), (size_t)H * H, 14, 5);
+      fill_e4m3(reinterpret_cast<unsigned char*>(wob.data() + (size_t)H * H), (size_t)2 * H * H, 14, 5);  // e4m3(w) slabs, then e4m3(lo(w))
       fill_f16(wo2b.data(), wo2b.size(), 15, 0.03f);
-      const size_t CP = 2 * KS + KS;  // pieces per chunk
+      const size_t CP = 2 * KS + 2 * KS;  // pieces per packed chunk: fp16, e4m3(w), e4m3(lo(w))
       for (size_t c = 0; c < (size_t)2 * I / 32; ++c) {
         fill_f16(wib.data() + c * CP * 512, 2 * KS * 512, 100 + (unsigned)c, 0.06f);
-        fill_e4m3(reinterpret_cast<unsigned char*>(wib.data() + (c * CP + 2 * KS) * 512), KS * 1024, 300 + (unsigned)c, 5);
+        fill_e4m3(reinterpret_cast<unsigned char*>(wib.data() + (c * CP + 2 * KS) * 512), 2 * KS * 1024, 300 + (unsigned)c, 5);
       }
       for (size_t c = 0; c < (size_t)3 * H / 32; ++c) {
         fill_f16(wqb.data() + c * CP * 512, 2 * KS * 512, 500 + (unsigned)c, 0.06f);
-        fill_e4m3(reinterpret_cast<unsigned char*>(wqb.data() + (c * CP + 2 * KS) * 512), KS * 1024, 700 + (unsigned)c, 5);
+        fill_e4m3(reinterpret_cast<unsigned char*>(wqb.data() + (c * CP + 2 * KS) * 512), 2 * KS * 1024, 700 + (unsigned)c, 5);
       }
     }
     CHECK(hipMemcpy(d_o, ob.data(), ob.size() * 2, hipMemcpyHostToDevice));
@@ -216,15 +216,15 @@ int main() {
   auto launch = [&]() { hipLaunchKernelGGL((layer32_kernel<8, true, ABL_T != 0, 7>), dim3(R / 128), dim3(256), 0, 0, lp); };
 #else
 #ifdef ABL_F8
-  constexpr bool kF8 = true;
+  constexpr int kF8 = ABL_F8;  // 1: bf16-valued weights (ABL_T = 1), 2: fp32-valued weights (ABL_T = 3)
 #else
-  constexpr bool kF8 = false;
+  constexpr int kF8 = 0;
 #endif
   auto launch = [&]() {
     if (ABL_LAYER == 2)
       hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, ABL_T, ABL_T, 7, 4, 2, ABL_T, ABL_T, kF8>), dim3(R / 128), dim3(256), 0, 0, p);
     else
-      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, ABL_T, 0, 0, 4, 2, ABL_T, ABL_T>), dim3(R / 128), dim3(256), 0, 0, p);
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, ABL_T, 0, 0, 4, 2, ABL_T, ABL_T, kF8>), dim3(R / 128), dim3(256), 0, 0, p);
   };
 #endif
 #else

@@ -1049,10 +1049,14 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         const int ts = t > 0 ? t - 1 : 0;
         const int piece = wave + WAVES * u;  // wave-uniform
         const u16* src;
-        if (F8) {  // the chunk's fp16 + e4m3 pieces (not its weight-lo region), then plane 0 (fp16) of the slab
-          src = u < WI_PIECES / WAVES ? p.wi_pk + (size_t)(2 * tc + piece / CHUNK_PIECES8) * CHUNK_SRC + (piece % CHUNK_PIECES8) * 512
+        if constexpr (F8 != 0) {  // the chunk's fp16 + e4m3 pieces (not its weight-lo region), then plane 0 (fp16) of the slab
+          // (chunk index of the piece at compile time: CHUNK_PIECES8 is a multiple of WAVES, and a run-time division of
+          // the wave-uniform piece index by 24 is ~30 scalar instructions per DMA)
+          static_assert(CHUNK_PIECES8 % WAVES == 0, "a wave's pieces of one chunk");
+          constexpr int c8 = u >= CHUNK_PIECES8 / WAVES ? 1 : 0;
+          src = u < WI_PIECES / WAVES ? p.wi_pk + (size_t)(2 * tc + c8) * CHUNK_SRC + (piece - c8 * CHUNK_PIECES8) * 512
                                       : p.wo2_ks + (size_t)ts * (2 * NF1 * 512) + (piece - WI_PIECES) * 512;
-        } else if (u < WI_PIECES / WAVES) {  // [chunk 0..1][ks][frag]: hi pieces of the chunk-major pack
+        } else if constexpr (u < WI_PIECES / WAVES) {  // [chunk 0..1][ks][frag]: hi pieces of the chunk-major pack
           const int c = piece / (2 * KS), within = piece % (2 * KS);
           src = p.wi_pk + (size_t)(2 * tc + c) * CHUNK_SRC + (within >> 1) * 2048 + (within & 1) * 512;
         } else {
