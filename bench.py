@@ -543,6 +543,12 @@ def main() -> None:
         enc_o.close()
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dims, state, args.seq_len)
+    try:  # RCCL prints its banner through C stdio (block-buffered on a pipe): flush it so the JSON line comes last
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(line), flush=True)
     if grouped:
         dist.destroy_process_group()
