@@ -18,10 +18,11 @@ fp32 weights are what the CPU reference, the parity target, computes with.  The 
 reference's GPU default `dtype=bfloat16` makes of them at load time, standalone.py:219-233) are timed by the same
 command and reported as the `bf16_checkpoint` sub-record.
 
-On one GPU a step enqueues the batch as TWO independent launch sequences (the two halves of the pairs, each on its own
-HIP stream bound to one half of the CUs: ``HipEncoder.forward_packed_on``, ``--pipelines 1`` turns it off): +2.9 %
-pairs/s same-box, because the halves drift out of phase and one's memory phases fill the other's MFMA phases.  The
-same batch as one launch sequence is timed right after and reported as ``one_pipeline``.  The ranks of a multi-GPU run
+With the (hi, lo) bf16 kernel sets (``OPEN_PROVENCE_NO_F8=1``) a step on one GPU enqueues the batch as TWO independent
+launch sequences (the two halves of the pairs, each on its own HIP stream bound to one half of the CUs:
+``HipEncoder.forward_packed_on``; +2.9 % pairs/s same-box in round 2) and the same batch as one launch sequence is timed
+right after and reported as ``one_pipeline``.  The default fp16 + e4m3 kernel sets run the batch as ONE launch sequence
+(two measure the same; ``--pipelines 2`` forces them).  The ranks of a multi-GPU run
 do the same, each sequence followed on its own stream by the gather of its own half of the pairs (``ShardPlan.split``):
 one gather behind both sequences re-aligns them every step and loses 7 %.
 """
@@ -227,7 +228,10 @@ def main() -> None:
     # every rank, one plan per half), so the sequences never wait for each other: one gather behind both re-aligns
     # them every step and loses 7 %, one behind each keeps +1.9 % of the +2.9 % (measured on a one-rank RCCL group).
     # The plain single-GPU line also carries the one-sequence figure (`one_pipeline`).
-    want_pipes = args.pipelines or (2 if dims.hidden_size <= 256 else 1)
+    # (round 3: the fp16 + e4m3 whole-layer kernels take 132 KiB of LDS -- one block per CU whichever way the CUs are
+    # split -- and two sequences measure the same as one: 35.54 k vs 35.48 k, 43.13 k vs 43.03 k pairs/s; they run as one)
+    f8_set = policy["kernel_set"] in ("f16-f8", "f16-f8-w")
+    want_pipes = args.pipelines or (2 if (dims.hidden_size <= 256 and not f8_set) else 1)
     n_pipes = want_pipes if (not args.varlen and len(rows) >= 2) else 1
     keep_dev = torch.empty(total_tokens, dtype=torch.float32, device=device)
     pipes = []

@@ -119,10 +119,16 @@ class ShardPlan:
 
         if values.numel() != self.tokens[rank] * self.width or rank_logits.numel() != self.rows[rank] * self.num_labels:
             raise ValueError("local outputs do not match this rank's shard")
-        payload = torch.zeros(self.payload_size, dtype=torch.float32, device=values.device)
-        payload[: values.numel()] = values.reshape(-1)
+        # one payload buffer per (plan, device), zero-filled ONCE: the padding behind the values / logits is never
+        # written again, and a step of a long run only copies its two tensors in (no allocation, no fill)
+        cache = self.__dict__.setdefault("_payload_cache", {})
+        key = (str(values.device), int(rank))
+        payload = cache.get(key)
+        if payload is None:
+            payload = cache[key] = torch.zeros(self.payload_size, dtype=torch.float32, device=values.device)
+        payload[: values.numel()].copy_(values.reshape(-1))
         base = self.max_tokens * self.width
-        payload[base : base + rank_logits.numel()] = rank_logits.reshape(-1)
+        payload[base : base + rank_logits.numel()].copy_(rank_logits.reshape(-1))
         return payload
 
     def unpack(self, bucket: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -162,8 +168,13 @@ class ShardPlan:
         # torch.distributed.gather takes the GLOBAL rank of the destination: translate for a real sub-group
         dst_global = dist.get_global_rank(group, dst) if group is not None and group is not dist.group.WORLD else dst
         if me == dst:
-            bucket = torch.empty(self.world_size * self.payload_size, dtype=torch.float32, device=payload.device)
-            dist.gather(payload, gather_list=list(bucket.split(self.payload_size)), dst=dst_global, group=group)
+            cache = self.__dict__.setdefault("_bucket_cache", {})
+            key = str(payload.device)
+            if key not in cache:  # the root's receive bucket and its per-rank views, built once per plan
+                bucket = torch.empty(self.world_size * self.payload_size, dtype=torch.float32, device=payload.device)
+                cache[key] = (bucket, list(bucket.split(self.payload_size)))
+            bucket, views = cache[key]
+            dist.gather(payload, gather_list=views, dst=dst_global, group=group)
             return self.unpack(bucket)
         dist.gather(payload, gather_list=None, dst=dst_global, group=group)
         return None
