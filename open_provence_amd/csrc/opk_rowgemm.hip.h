@@ -64,7 +64,7 @@ struct RowGemmParams {
   const u16* a1_lo8;
   const u16* w1p8;
   // F8 = 2: the e4m3 slabs of lo(w) of the attention output weight are at w1p8 + k1_steps * 32 * hidden / 2; wo2_ks then
-  // holds [k-step][plane][NF1][512] with plane 1 = bf16(lo(w)); F8 = 1 reads plane 0 of the same pack
+  // holds [k-step][plane][NF1][512] with plane 1 = fp16(lo(w)); F8 = 1 reads plane 0 of the same pack
   float* x_io;
   int zero_a_lo;  // clear the lo fragments of the in-register (LayerNorm / split) operand: see rowgemm_kernel
   // RP_MLP: the whole MLP between phase 1 and the chunk loop, h kept on chip
@@ -175,8 +175,10 @@ __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows
 // k-streamed weights of the "f16 + fp8" kernel sets.  dst8 != nullptr (attention output projection, K = hidden): fp16
 // slabs dst16[ks][nf][512], e4m3 slabs dst8[K-step S][nf][half][1 KiB] and the same of lo(w) x 2^12 behind them
 // (dst8 + N K / 2).  dst8 == nullptr (MLP output projection, streamed 32 k at a time): dst16[ks][plane][nf][512] with
-// plane 0 = fp16(w), plane 1 = bf16(lo(w)) (multiplied on the bf16 shape against bf16(h): its exponent range holds the
-// unscaled lo part).  `permute` as pack_kstream_kernel.
+// plane 0 = fp16(w), plane 1 = fp16(lo(w)), UNSCALED: lo(w) ~ 2^-12 |w| sits in fp16's subnormal range for |w| < 0.25,
+// where the grid is 2^-24 -- an absolute error <= 2^-25 per weight, the bound this format accepts for small weights
+// anyway -- and the MFMA takes subnormal operands at full rate (default denormal mode); it multiplies the fp16 hi
+// fragment of h the main product uses.  `permute` as pack_kstream_kernel.
 __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst16,
                                        u16* __restrict__ dst8, int round_bf16, int* __restrict__ not_f16) {
   set_saturating_conversions();
@@ -203,7 +205,7 @@ __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int
     d8[(size_t)N * K + (g * 16 + i) * 16 + pbyte] = f2e4m3(wlo * (float)(1 << F8_LO_SHIFT));
   } else {
     dst16[((size_t)ks * 2 * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
-    dst16[((size_t)(ks * 2 + 1) * NF + nf) * 512 + g * 128 + i * 8 + e] = f2bf(wlo);
+    dst16[((size_t)(ks * 2 + 1) * NF + nf) * 512 + g * 128 + i * 8 + e] = f2h(wlo);
   }
 }
 #endif
@@ -388,8 +390,8 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
 // operand of the three K = hidden contractions (attention output projection, Wi, next q / k / v) is an e4m3 plane
 // multiplied at twice the rate on the K = 128 block-scaled MFMA, h (K = 32 per step) keeps a 16-bit lo fragment.
 // F8 = 2 (fp32-valued weights, kernel set 4): additionally every weight carries its lo part lo(w) = w - fp16(w) --
-// e4m3 x 2^12 for the K = hidden contractions (multiplied against e4m3(activation): 0.5 MFMA units), bf16 for the MLP
-// output projection (against bf16(h)) -- 2 MFMA units per product where the (hi, lo) bf16 kernels need 3; one Wi chunk +
+// e4m3 x 2^12 for the K = hidden contractions (multiplied against e4m3(activation): 0.5 MFMA units), unscaled fp16 for the
+// MLP output projection (against the fp16 hi fragment of h) -- 2 MFMA units per product where the (hi, lo) bf16 kernels need 3; one Wi chunk +
 // half a Wo slab per LDS stage (a stage of two chunks + a slab with their lo planes would be 96 KiB).
 template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0, int F8 = 0>
 __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : ((MF == 1 && WAVES == 8) ? 4 : 2)) void rowgemm_kernel(RowGemmParams p) {
@@ -1100,13 +1102,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       f32x4 acc_b[2][MF];  // accumulators of the pair's second chunk: [input | gate] fragment x row fragment
       uint2 hold_hi[MF], hold_lo[MF];
       bf16x8 h_hi[MF], h_lo[MF];
-      uint2 hold_b[MF];  // WLO: bf16(h), the operand of the product with bf16(lo(Wo))
-      bf16x8 h_b[MF];
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        hold_b[mf] = make_uint2(0u, 0u);
-        h_b[mf] = as_frag(make_uint4(0u, 0u, 0u, 0u));
-      }
       float g_prev[MF][4], g_cur[MF][4];  // GeGLU values of the chunk finished last / of this pair's first chunk
       float gx[MF * 4], gq[MF * 4];       // GeGLU in flight: inputs and the running polynomial / exponential / result
 #pragma unroll
@@ -1201,8 +1196,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         uint2 h2, l2;
         if constexpr (F8) split4_f16(g_prev[mf], h2, l2);
         else split4<H_LO>(g_prev[mf], h2, l2);
-        if constexpr (WLO)
-          h_b[mf] = as_frag(make_uint4(hold_b[mf].x, hold_b[mf].y, pack_bf16x2(g_prev[mf][0], g_prev[mf][1]), pack_bf16x2(g_prev[mf][2], g_prev[mf][3])));
         h_hi[mf] = as_frag(make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y));
         h_lo[mf] = as_frag(make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y));
       };
@@ -1213,7 +1206,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #endif
         if constexpr (F8) split4_f16(g_cur[mf], hold_hi[mf], hold_lo[mf]);
         else split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
-        if constexpr (WLO) hold_b[mf] = make_uint2(pack_bf16x2(g_cur[mf][0], g_cur[mf][1]), pack_bf16x2(g_cur[mf][2], g_cur[mf][3]));
       };
       auto chunk_step = [&](f32x4 (&acc)[2][MF], auto ks_tag, const bf16x8& w0, const bf16x8& w1) {
         constexpr int ks = decltype(ks_tag)::value;
@@ -1269,7 +1261,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, h_hi[mf], acc1[nf + 1][mf]);
       };
       // WLO: e4m3(LN(x)) x lo(Wi), and one output fragment of the slab with all three terms:
-      //   lo(h) x Wo + h x Wo on the fp16 shape, bf16(h) x bf16(lo(Wo)) on the bf16 shape (w1 = that plane's fragment)
+      //   lo(h) x Wo, h x lo(Wo) (w1 = that plane's fragment: unscaled fp16, see pack_kstream_f8_kernel) and h x Wo, all
+      //   on the fp16 shape
       auto chunk_step8w = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1) {
         constexpr int nf = decltype(nf_tag)::value, s8 = decltype(s8_tag)::value;
         const i32x8 w8 = f8_frag(w0, w1);
@@ -1281,7 +1274,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_lo[mf], acc1[nf][mf]);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w1, h_b[mf], acc1[nf][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w1, h_hi[mf], acc1[nf][mf]);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_hi[mf], acc1[nf][mf]);
       };
