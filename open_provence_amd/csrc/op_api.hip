@@ -394,7 +394,10 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       ap.window = window;
       ap.n_items = is_global ? plan.items_g : plan.items_l;
       ap.n_heads = h->nh;
-      ap.xcd_group = h->panel_path ? 1 : 0;  // XCD-aware block map: see attn_fp_kernel
+      // XCD-aware block map (see attn_fp_kernel): panel path; round 3: also the row path under the fp16 + e4m3 kernel sets
+      // (same-box A/B: sliding-window attention -5 %, whole forward +0.7 %; with the (hi, lo) bf16 whole-layer kernel
+      // it measured -1 % in round 2 and stays off there unless OP_FLAG_ATTN_XCD_GROUP asks for it)
+      ap.xcd_group = (h->panel_path || o_f8 || (h->cfg.flags & OP_FLAG_ATTN_XCD_GROUP)) ? 1 : 0;
       const unsigned item_span = 8u * opk::ATT_ITEM_GROUP;
       const dim3 grid((ap.xcd_group ? ((unsigned)ap.n_items + item_span - 1) / item_span * item_span : (unsigned)ap.n_items) *
                       (unsigned)h->nh);

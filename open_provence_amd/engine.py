@@ -30,6 +30,7 @@ _ENV_FLAGS = {
     "OPEN_PROVENCE_LAYER_M32": _lib.OP_FLAG_LAYER_M32,
     "OPEN_PROVENCE_NO_HEAD_FUSION": _lib.OP_FLAG_NO_HEAD_FUSION,
     "OPEN_PROVENCE_NO_F8": _lib.OP_FLAG_NO_F8,
+    "OPEN_PROVENCE_ATTN_XCD_GROUP": _lib.OP_FLAG_ATTN_XCD_GROUP,
 }
 
 

@@ -33,7 +33,31 @@ def test_bench_json_line_contract():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 1e-6
-    # single GPU, row-stationary model: the batch ran as two launch sequences, and the one-sequence figure is beside it
+    # the headline is the fp32-valued checkpoint on the fp16 + e4m3 kernel set (one launch sequence); the same command
+    # times the bf16-rounded weights as a sub-record, and reports the shader clock it held
+    assert line["config"]["checkpoint_dtype"] == "fp32" and line["config"]["policy"]["kernel_set"] == "f16-f8-w"
+    assert line["config"]["parallelism"] == "single GPU" and "one_pipeline" not in line
+    other = line["bf16_checkpoint"]
+    assert other["value"] > 0 and other["policy"]["kernel_set"] == "f16-f8" and other["checkpoint_dtype"] == "bf16"
+    assert 0.5 < line["shader_clock_ghz"]["value"] < 3.0
+    assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_launch_sequences_with_the_bf16_kernel_sets():
+    """OPEN_PROVENCE_NO_F8=1 (the (hi, lo) bf16 kernels): the batch runs as two launch sequences on CU-partitioned
+    streams and the one-sequence figure is reported beside it."""
+
+    import os
+
+    proc = subprocess.run(
+        [sys.executable, str(REPO_ROOT / "bench.py"), "--pairs", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+         "--no-long", "--no-other-dtype", "--weights", "bf16"],
+        capture_output=True, text=True, timeout=600, env={**os.environ, "OPEN_PROVENCE_NO_F8": "1"},
+    )
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert line["config"]["policy"]["kernel_set"] == "bf16-weights"
     assert "two independent" in line["config"]["parallelism"]
     assert line["one_pipeline"]["value"] > 0 and line["one_pipeline"]["unit"] == "pairs/s"
 
