@@ -9,7 +9,14 @@ namespace {
 template <int PI, int WAVES, int KT>
 void launch_one(hipStream_t st, const AttnFpParams& p, dim3 grid) {
   constexpr Policy P = kPolicies[PI];
-  hipLaunchKernelGGL((attn_fp_kernel<P.qk, P.pv, o_lo(P), WAVES, KT, false, P.fmt == 1>), grid, dim3(WAVES * 64), 0, st, p);
+  // Tile stages of the sliding-window layers: 2.  Three (requests two tiles ahead, counted end-of-tile wait; -DOPK_ATTN_
+  // LOCAL_STAGES=3) measured SLOWER, 0.773 vs 0.719 ms per forward for the six launches (same-box A/B, three
+  // alternations): the 48 KiB ring costs a resident block per CU, and residency hides the DMA latency better than depth.
+#ifndef OPK_ATTN_LOCAL_STAGES
+#define OPK_ATTN_LOCAL_STAGES 2
+#endif
+  constexpr int NST = KT == 1 ? OPK_ATTN_LOCAL_STAGES : 2;
+  hipLaunchKernelGGL((attn_fp_kernel<P.qk, P.pv, o_lo(P), WAVES, KT, false, P.fmt == 1, NST>), grid, dim3(WAVES * 64), 0, st, p);
 }
 
 template <int PI>

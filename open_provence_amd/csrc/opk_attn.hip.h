@@ -64,7 +64,10 @@ constexpr int ATT_ITEM_GROUP = 4;
 // ZP: lo(p) is cleared (a policy without the lo(p) x hi(v) term evaluated on the instantiation that has it).
 // OF8: the output is written for the "f16 + fp8" whole-layer kernel: hi = fp16 pieces, lo = e4m3 x 2^12 (a head's 64
 // dims are one 16-byte half-fragment per lane: the lane's 8 dims of both k-steps of the head).
-template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false, bool OF8 = false>
+// NST: LDS stages of the K / V^T tile ring.  2 (shipped): the next tile is requested while this one is multiplied.
+// 3 (experiment, see op_launch_attn.hip: slower): two tiles ahead, the end-of-tile wait counts the newest request out
+// (vmcnt retires in order) instead of draining everything.
+template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false, bool OF8 = false, int NST = 2>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) {
   if constexpr (OF8) set_saturating_conversions();
   constexpr int ATT_FP_BQ = WAVES * 32;
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
   constexpr int V_PIECES = 4 * KT * PV;             // [t 0..KT-1][plane][n 0..3]
   constexpr int STAGE = (K_PIECES + V_PIECES) * 512;
   static_assert(K_PIECES % WAVES == 0 && V_PIECES % WAVES == 0, "tile pieces must split evenly over the waves");
-  __shared__ __attribute__((aligned(16))) u16 sT[2][STAGE];
+  static_assert(NST == 2 || NST == 3, "two or three tile stages");
+  __shared__ __attribute__((aligned(16))) u16 sT[NST][STAGE];
 
   // work item -> (sequence, query block): binary search in the per-sequence prefix of ceil(len / ATT_FP_BQ)
   const int xcd_slot = blockIdx.x >> 3;
@@ -193,7 +197,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
 
   auto tile = [&](int kt, auto cur_tag) {
     constexpr int cur = decltype(cur_tag)::value;
-    stage_tile(kt + 1 <= kt_hi ? kt + 1 : kt, cur ^ 1);  // unconditional prefetch into the idle stage
+    // unconditional prefetch into the idle stage (NST = 3: of the tile after next, into the stage tile kt - 1 used)
+    if constexpr (NST == 2) stage_tile(kt + 1 <= kt_hi ? kt + 1 : kt, cur ^ 1);
+    else stage_tile(kt + 2 <= kt_hi ? kt + 2 : kt_hi, (cur + 2) % 3);
     const u16* st = &sT[cur][lane * 8];
     const int kbase = kt * TILE_KEYS;
     // wave-uniform tile classification: skip tiles entirely outside this wave's window (other waves of the block
@@ -316,14 +322,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
         }
       }
     }
-    __syncthreads();
+    if constexpr (NST == 2) {
+      __syncthreads();
+    } else {  // tile kt + 1 has landed (the request for kt + 2, issued at the top, may still fly); then all waves meet
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPW + VPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   };
 
   stage_tile(kt_lo, 0);
-  __syncthreads();
-  for (int kt = kt_lo; kt <= kt_hi; kt += 2) {
-    tile(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 <= kt_hi) tile(kt + 1, std::integral_constant<int, 1>{});
+  if constexpr (NST == 2) {
+    __syncthreads();
+    for (int kt = kt_lo; kt <= kt_hi; kt += 2) {
+      tile(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 <= kt_hi) tile(kt + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
+    stage_tile(kt_lo + 1 <= kt_hi ? kt_lo + 1 : kt_hi, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPW + VPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = kt_lo; kt <= kt_hi; kt += 3) {
+      tile(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 <= kt_hi) tile(kt + 1, std::integral_constant<int, 1>{});
+      if (kt + 2 <= kt_hi) tile(kt + 2, std::integral_constant<int, 2>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped prefetches of the last tiles)
   }
 
   if (active) {
