@@ -157,6 +157,7 @@ def main() -> None:
     parser.add_argument("--chunk-rows", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-long", action="store_true", help="skip the seq_len 2048 sub-record")
+    parser.add_argument("--no-base", action="store_true", help="skip the base-model (hidden 768, panel path) sub-record")
     parser.add_argument("--varlen", action="store_true",
                         help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
     parser.add_argument("--pipelines", type=int, default=0, choices=[0, 1, 2],
@@ -545,6 +546,43 @@ def main() -> None:
                                "frac": flops_per_forward[dom_o] / lpf / (prof_o[dom_o]["avg_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
         line[f"{other}_checkpoint"] = sub
         enc_o.close()
+    if world == 1 and not args.varlen and args.model == "xsmall" and not args.no_base:
+        # the panel path (hidden 768: base dims, 22 layers) on the same batch, both checkpoint dtypes (sub-record; the
+        # full record of that model is `bench.py --model base`)
+        dims_b = named_dims("base")
+        rows_b = synth_pair_batch(dims_b, args.pairs, args.seq_len, seed=1234)
+        ids_b_np, cu_b_np, max_b = pack_rows(rows_b)
+        ids_b, cu_b = torch.from_numpy(ids_b_np).to(device), torch.from_numpy(cu_b_np).to(device)
+        flops_b = algorithmic_flops_per_pair(dims_b, args.seq_len)
+        base_steps = max(5, args.steps // 10)
+        sub_b = {"unit": "pairs/s", "model": "base", "steps": base_steps, "algorithmic_gflop_per_pair": flops_b / 1e9}
+        for wdt in ("fp32", "bf16"):
+            state_b = synth_state_dict(dims_b, seed=7)
+            if wdt == "bf16":
+                state_b = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state_b.items()}
+            enc_b = HipEncoder(dims_b, device=device, precision=args.precision)
+            enc_b.load_state_dict(state_b)
+            del state_b
+            for _ in range(2):
+                enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(base_steps):
+                enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
+            torch.cuda.synchronize(device)
+            dt_b = (time.perf_counter() - t1) / base_steps
+            enc_b.profile_enable(True)
+            enc_b.profile_reset()
+            for _ in range(2):
+                enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
+            prof_b = enc_b.profile_read()
+            enc_b.profile_enable(False)
+            sub_b[f"{wdt}_checkpoint"] = {
+                "value": args.pairs / dt_b, "ms_per_step": dt_b * 1e3, "kernel_set": enc_b.effective_policy()["kernel_set"],
+                "whole_forward_frac": args.pairs / dt_b * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "kernel_ms_per_forward": {k: v["total_ms"] / 2 for k, v in prof_b.items()}}
+            enc_b.close()
+        line["base_model"] = sub_b
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dims, state, args.seq_len)
     try:  # RCCL prints its banner through C stdio (block-buffered on a pipe): flush it so the JSON line comes last

@@ -74,6 +74,9 @@ struct LayerWeights {
   // "f16 + fp8" kernel set (opk_common.hip.h): chunks of [fp16 plane | e4m3 plane] (Wqkv, Wi), fp16 k-streamed slabs
   // (attention Wo, MLP Wo) and the e4m3 K = 128 slabs of the attention Wo
   u16 *wqkv_f8 = nullptr, *wi_f8 = nullptr, *wo_f16 = nullptr, *wo_f8 = nullptr, *wo2_f16 = nullptr;
+  // the same kernel sets on the panel path: per weight fp16 slabs + e4m3 slabs (w, then lo(w)) (pack_panel_f8_kernel)
+  u16 *wqkv_p16 = nullptr, *wqkv_p8 = nullptr, *wo_p16 = nullptr, *wo_p8 = nullptr, *wi_p16 = nullptr, *wi_p8 = nullptr,
+      *wo2_p16 = nullptr, *wo2_p8 = nullptr;
 };
 
 struct ProfileEvent {
@@ -623,8 +626,15 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     if (h->panel_path) {
       // ---- panel path (hidden % 256 == 0): LayerNorm -> fragment-packed planes, k-streamed panel GEMMs ----
       const dim3 ln_grid((unsigned)(r_pad / 16));
+      const bool pf8 = o_f8;  // kernel sets 3 / 4: activations as fp16 pieces + e4m3 pieces (x 2^12) of their lo part
+      const bool wlo8 = h->pi == opl::PI_F16_F8_W;
       auto layer_norm_fp = [&](const float* w, bool with_lo, bool clear) -> int {
         OP_TRY(L.begin(PK_LN));
+        if (pf8) {
+          hipLaunchKernelGGL(ln_fp8_kernel, ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad, w ? 1 : 0, ws.ln_hi,
+                             ws.ln_lo);
+          return L.end();
+        }
         if (with_lo)
           hipLaunchKernelGGL((ln_fp_kernel<true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
                              w ? 1 : 0, ws.ln_hi);
@@ -643,7 +653,9 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         const unsigned per_xcd = ((unsigned)(r_pad / ROW_BM) + 7) / 8;  // row blocks each XCD owns
         const unsigned groups = (per_xcd + q.row_group - 1) / q.row_group;
         const dim3 grid(8u * groups * (unsigned)q.row_group * (unsigned)n_tiles);  // XCD-aware block map: see panel_gemm_kernel
-        if (epi == 102 ? !opl::launch_panel_qkv(st, q, h->pi, grid) : !opl::launch_panel(st, q, epi, h->pi, grid)) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
+        const bool ok = pf8 ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
+                            : (epi == 102 ? opl::launch_panel_qkv(st, q, h->pi, grid) : opl::launch_panel(st, q, epi, h->pi, grid));
+        if (!ok) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
         return L.end();
       };
       // layer 0: attn_norm is Identity -> plain split
@@ -657,11 +669,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       pp.rope_sin = h->rope_sin[is_global ? 1 : 0];
       pp.max_pos = h->max_pos;
       pp.a_fp = ws.ln_hi;
+      pp.a_lo8 = ws.ln_lo;
       pp.n_ksteps = H / 32;
-      pp.wp = lw.wqkv_pk;
+      pp.wp = pf8 ? lw.wqkv_p16 : lw.wqkv_pk;
+      pp.wp8 = lw.wqkv_p8;
+      pp.w8_lo_off = (size_t)3 * H * H / 2;  // u16 elements: the tensor's e4m3(w) slabs, then those of lo(w)
       pp.o0 = ws.q_hi;
       pp.o1 = ws.k_hi;
-      if (!(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION)) {  // q, k, v^T in one launch
+      if (pf8 || !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION)) {  // q, k, v^T in one launch
         pp.o2 = ws.vt_hi;
         pp.n_qk_tiles = 2 * H / 256;
         OP_TRY(panel(PK_GEMM_QKV_ROPE, 102, pp, 3 * H / 256));
@@ -674,20 +689,30 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       OP_TRY(clear_qkv());
       OP_TRY(attention(is_global));
       pp.a_fp = ws.o_hi;
-      pp.wp = lw.wo_ks;
+      pp.a_lo8 = ws.o_lo;
+      pp.wp = pf8 ? lw.wo_p16 : lw.wo_ks;
+      pp.wp8 = lw.wo_p8;
+      pp.w8_lo_off = (size_t)H * H / 2;
       pp.x = ws.x;
       pp.ld_out = H;
       OP_TRY(panel(PK_GEMM_ATTN_OUT, 100, pp, H / 256));
       OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp));
       pp.a_fp = ws.ln_hi;
-      pp.wp = lw.wi_pk;
+      pp.a_lo8 = ws.ln_lo;
+      pp.wp = pf8 ? lw.wi_p16 : lw.wi_pk;
+      pp.wp8 = lw.wi_p8;
+      pp.w8_lo_off = (size_t)2 * I * H / 2;
       pp.o0 = ws.h_hi;
+      pp.o0_lo8 = ws.h_lo;
       pp.ld_out = I;
       OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128));
       OP_TRY(clear_h());
       pp.a_fp = ws.h_hi;
+      pp.a_lo8 = ws.h_lo;
       pp.n_ksteps = I / 32;
-      pp.wp = lw.wo2_pk;
+      pp.wp = pf8 ? lw.wo2_p16 : lw.wo2_pk;
+      pp.wp8 = lw.wo2_p8;
+      pp.w8_lo_off = (size_t)H * I / 2;
       pp.ld_out = H;
       OP_TRY(panel(PK_GEMM_MLP_OUT, 101, pp, H / 256));
       continue;
@@ -908,7 +933,7 @@ int op_create(const op_config* cfg, op_handle** out) {
   const size_t HH = (size_t)H * H;
   OP_CREATE_TRY(dev_alloc(h, &h->any_lo_dev, OP_FAM_COUNT + 1));
   OP_CREATE_HIP(hipMemset(h->any_lo_dev, 0, (OP_FAM_COUNT + 1) * sizeof(int)));
-  h->f8_packs = h->row_path && (H / 32) % 4 == 0 && !(cfg->flags & OP_FLAG_NO_F8);
+  h->f8_packs = ((h->row_path && (H / 32) % 4 == 0) || h->panel_path) && !(cfg->flags & OP_FLAG_NO_F8);
   OP_CREATE_TRY(dev_alloc(h, &h->emb, (size_t)h->V * H));
   OP_CREATE_TRY(dev_alloc(h, &h->emb_norm, H));
   OP_CREATE_TRY(dev_alloc(h, &h->final_norm, H));
@@ -943,7 +968,17 @@ int op_create(const op_config* cfg, op_handle** out) {
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
-      if (h->f8_packs) {  // 4 bytes per weight element: fp16 + e4m3 + e4m3 of the lo part (bf16 for the MLP's Wo)
+      if (h->f8_packs && h->panel_path) {  // 4 bytes per weight element: fp16 + e4m3(w) + e4m3(lo(w))
+        OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_p16, 3 * HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_p8, 3 * HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo_p16, HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo_p8, HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wi_p16, (size_t)2 * I * H));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wi_p8, (size_t)2 * I * H));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo2_p16, (size_t)H * I));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo2_p8, (size_t)H * I));
+      }
+      if (h->f8_packs && h->row_path) {  // 4 bytes per weight element: fp16 + e4m3 + e4m3 of the lo part (fp16 for the MLP's Wo)
         OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_f8, 3 * HH * 2));
         OP_CREATE_TRY(dev_alloc(h, &lw.wi_f8, (size_t)2 * I * H * 2));
         OP_CREATE_TRY(dev_alloc(h, &lw.wo_f16, HH));
@@ -1002,6 +1037,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   u16* dst_ks = nullptr;  // additional k-streamed packing (attention Wo)
   u16* dst_p32 = nullptr; // additional packing for the 32x32x16 whole-layer kernel
   u16 *dst_f8a = nullptr, *dst_f8b = nullptr;  // "f16 + fp8" packs: chunked (a) or k-streamed fp16 (a) + e4m3 (b)
+  u16 *dst_p16 = nullptr, *dst_p8 = nullptr;   // ... on the panel path: fp16 slabs + e4m3 slabs
   int p32_mode = 0, p32_kmajor = 0;
   int pk_mode = -1;
   int family = -1;        // op_gemm_family of a GEMM weight
@@ -1048,21 +1084,25 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       dst_pk = lw.wqkv_pk; pk_mode = RE_QKV; family = OP_FAM_WQKV;
       dst_p32 = lw.wqkv_p32; p32_mode = L32_QKV; p32_kmajor = 0;
       dst_f8a = lw.wqkv_f8;
+      dst_p16 = lw.wqkv_p16; dst_p8 = lw.wqkv_p8;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
       dst_pk = nullptr; pk_mode = 101; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
       dst_p32 = lw.wo_p32; p32_mode = L32_RESID; p32_kmajor = 1;
       dst_f8a = lw.wo_f16; dst_f8b = lw.wo_f8;
+      dst_p16 = lw.wo_p16; dst_p8 = lw.wo_p8;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
       dst_pk = lw.wi_pk; pk_mode = RE_GEGLU; family = OP_FAM_WI;
       dst_p32 = lw.wi_p32; p32_mode = L32_GEGLU; p32_kmajor = 0;
       dst_f8a = lw.wi_f8;
+      dst_p16 = lw.wi_p16; dst_p8 = lw.wi_p8;
     } else if (t == "mlp.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo2_hi; dst_lo = lw.wo2_lo; expect(H, I);
       dst_pk = lw.wo2_pk; pk_mode = 100; family = OP_FAM_MLP_OUT;  // k-streamed
       dst_p32 = lw.wo2_p32; p32_mode = L32_RESID; p32_kmajor = 1;
       dst_f8a = lw.wo2_f16;
+      dst_p16 = lw.wo2_p16; dst_p8 = lw.wo2_p8;
     } else {
       return fail(h, OP_ERR_INVALID, "op_load_weight: unknown tensor name '%s'", name_c);
     }
@@ -1121,6 +1161,23 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, f32, n_tiles, K, mode,
                          H, I, dst, zero_lo, any_lo);
     };
+    if (dst_p16) {  // the fp16 + e4m3 packs of the same panels (kernel sets 3 / 4)
+      int* not_f16 = h->any_lo_dev + OP_FAM_COUNT;
+      const size_t lo_off = count;  // bytes of the whole tensor's e4m3(w) slabs: the lo(w) slabs follow
+      auto pack8 = [&](int n_tiles, int mode, int tile0) {
+        const size_t total = (size_t)n_tiles * 256 * K;
+        hipLaunchKernelGGL(pack_panel_f8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, f32, n_tiles, K, mode, H, I,
+                           dst_p16 + (size_t)tile0 * 256 * K, dst_p8 + (size_t)tile0 * 256 * K / 2, lo_off, zero_lo, not_f16);
+      };
+      if (pk_mode == RE_QKV) {
+        pack8(2 * H / 256, PE_QK, 0);
+        pack8(H / 256, PE_V, 2 * H / 256);
+      } else if (pk_mode == RE_GEGLU) {
+        pack8(I / 128, PE_GEGLU, 0);
+      } else {
+        pack8(H / 256, PE_RESIDUAL, 0);
+      }
+    }
     if (pk_mode == RE_QKV) {
       pack(2 * H / 256, PE_QK, dst_pk);
       pack(H / 256, PE_V, dst_pk + (size_t)(2 * H / 256) * (K / 32) * 2 * 8192);

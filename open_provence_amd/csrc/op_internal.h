@@ -75,5 +75,8 @@ bool launch_attn(hipStream_t st, const opk::AttnFpParams& p, int waves, int kt, 
 bool launch_panel(hipStream_t st, const opk::PanelParams& p, int epi, int pi, dim3 grid);
 // q, k and v^T panels of one layer in one launch (p.n_tiles = 3 H / 256, p.n_qk_tiles = 2 H / 256, p.o2 = v^T)
 bool launch_panel_qkv(hipStream_t st, const opk::PanelParams& p, int pi, dim3 grid);
+// the panel GEMMs in the fp16 + e4m3 format (kernel sets 3 / 4; wlo: the weights carry their lo part = set 4)
+bool launch_panel_f8(hipStream_t st, const opk::PanelParams& p, int epi, bool wlo, dim3 grid);
+bool launch_panel_f8_qkv(hipStream_t st, const opk::PanelParams& p, bool wlo, dim3 grid);
 
 }  // namespace opl

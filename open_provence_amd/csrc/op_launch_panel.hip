@@ -58,4 +58,27 @@ bool launch_panel(hipStream_t st, const PanelParams& p, int epi, int pi, dim3 gr
   }
 }
 
+// ---- "f16 + fp8" format (kernel sets 3 / 4 on the panel path): panel_f8_gemm_kernel / panel_f8_qkv_kernel ----------
+namespace {
+template <bool WLO>
+bool launch_f8_t(hipStream_t st, const PanelParams& p, int epi, dim3 grid) {
+  const dim3 block(256);
+  if (epi == PE_GEGLU) hipLaunchKernelGGL((panel_f8_gemm_kernel<PE_GEGLU, WLO, 1>), grid, block, 0, st, p);
+  else if (epi == 100 || epi == 101) hipLaunchKernelGGL((panel_f8_gemm_kernel<PE_RESIDUAL, WLO, 0>), grid, block, 0, st, p);
+  else return false;
+  return true;
+}
+}  // namespace
+
+bool launch_panel_f8(hipStream_t st, const PanelParams& p, int epi, bool wlo, dim3 grid) {
+  return wlo ? launch_f8_t<true>(st, p, epi, grid) : launch_f8_t<false>(st, p, epi, grid);
+}
+
+bool launch_panel_f8_qkv(hipStream_t st, const PanelParams& p, bool wlo, dim3 grid) {
+  // q, k and v^T keep their (hi, lo) bf16 pieces: the attention kernels read them
+  if (wlo) hipLaunchKernelGGL((panel_f8_qkv_kernel<true, 3, 1>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((panel_f8_qkv_kernel<false, 3, 1>), grid, dim3(256), 0, st, p);
+  return true;
+}
+
 }  // namespace opl

@@ -413,6 +413,52 @@ __global__ __launch_bounds__(256) void ln_fp_kernel(const float* __restrict__ x,
   }
 }
 
+// The same for the "f16 + fp8" kernel sets (panel path): out16 = fp16 pieces [rb][ks][512], out8 = e4m3 pieces
+// [rb][ks / 2][1 KiB] with a lane's 16 bytes = its 8 lo values (x 2^12) of the even k-step, then of the odd one
+// (opk_common.hip.h).  H % 64 == 0.
+__global__ __launch_bounds__(256) void ln_fp8_kernel(const float* __restrict__ x, const float* __restrict__ lnw, float eps, int H,
+                                                     int r_pad, int normalize, u16* __restrict__ out16, u16* __restrict__ out8) {
+  __shared__ __attribute__((aligned(16))) unsigned char stage[LN_MAX_CHUNKS * 8 * 4 * LN_FP_SLAB];  // H <= 1024
+  __shared__ __attribute__((aligned(16))) unsigned char stage8[LN_MAX_CHUNKS * 8 * 4 * 16 * 8];      // [ks][g][row][8 bytes]
+  set_saturating_conversions();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int rb = blockIdx.x;
+  const int KS = H >> 5;
+  const int nchunk = H >> 2;
+  RowVec rows[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    row_load(x + (size_t)(rb * 16 + wave * 4 + j) * H, H, lane, rows[j]);
+    if (normalize) row_layer_norm(rows[j], lnw, H, lane, eps);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+      const int c = lane + 64 * k;  // float4 chunk = columns 4c .. 4c+3 = k-step c/8, k-group (c%8)/2, half c%2
+      if (c < nchunk) {
+        const float v[4] = {rows[j].v[k].x, rows[j].v[k].y, rows[j].v[k].z, rows[j].v[k].w};
+        uint2 hi;
+        uint32_t lo8;
+        split4_f8(v, hi, lo8);
+        const int slab = (c >> 3) * 4 + ((c & 7) >> 1);
+        *reinterpret_cast<uint2*>(stage + slab * LN_FP_SLAB + (wave * 4 + j) * 16 + (c & 1) * 8) = hi;
+        *reinterpret_cast<uint32_t*>(stage8 + (slab * 16 + (wave * 4 + j)) * 8 + (c & 1) * 4) = lo8;
+      }
+    }
+  __syncthreads();
+  for (int ks = wave; ks < KS; ks += 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(stage + (ks * 4 + (lane >> 4)) * LN_FP_SLAB + (lane & 15) * 16);
+    *reinterpret_cast<uint4*>(out16 + ((size_t)rb * KS + ks) * 512 + lane * 8) = v;
+  }
+  for (int pk = wave; pk < (KS >> 1); pk += 4) {
+    const uint2 e = *reinterpret_cast<const uint2*>(stage8 + (((2 * pk) * 4 + (lane >> 4)) * 16 + (lane & 15)) * 8);
+    const uint2 o = *reinterpret_cast<const uint2*>(stage8 + (((2 * pk + 1) * 4 + (lane >> 4)) * 16 + (lane & 15)) * 8);
+    *reinterpret_cast<uint4*>(out8 + ((size_t)rb * (KS >> 1) + pk) * 512 + lane * 8) = make_uint4(e.x, e.y, o.x, o.y);
+  }
+}
+
 // Numerics of a narrower precision policy on a wider kernel instantiation: clear the lo plane of a fragment-packed
 // tensor (every odd unit of `unit` elements) so that the wider kernel's extra product term adds exact zeros.
 __global__ __launch_bounds__(256) void zero_odd_units_kernel(u16* __restrict__ base, int unit, size_t n_pairs) {

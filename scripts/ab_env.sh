@@ -1,8 +1,8 @@
 # same-box A/B of one environment switch: scripts/ab_env.sh VAR [bench args...]  (three alternations, default bench)
 VAR=$1; shift
 for i in 1 2 3; do
-  python bench.py --steps 60 --no-cpu-baseline --no-long "$@" > gpurun_out/abenv_off_$i.json 2>/dev/null
-  env $VAR=1 python bench.py --steps 60 --no-cpu-baseline --no-long "$@" > gpurun_out/abenv_on_$i.json 2>/dev/null
+  python bench.py --steps 60 --no-cpu-baseline --no-long --no-base "$@" > gpurun_out/abenv_off_$i.json 2>/dev/null
+  env $VAR=1 python bench.py --steps 60 --no-cpu-baseline --no-long --no-base "$@" > gpurun_out/abenv_on_$i.json 2>/dev/null
 done
 python - <<'PY'
 import json,glob

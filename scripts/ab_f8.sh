@@ -1,8 +1,8 @@
 # same-box A/B of the fp16 + e4m3 kernel sets against the (hi, lo) bf16 sets: W = bf16 | fp32 (checkpoint dtype)
 W=${1:-bf16}
 for i in 1 2 3; do
-  OPEN_PROVENCE_NO_F8=1 python bench.py --steps 60 --no-cpu-baseline --no-long --weights $W > gpurun_out/ab_${W}_nof8_$i.json 2>/dev/null
-  python bench.py --steps 60 --no-cpu-baseline --no-long --weights $W > gpurun_out/ab_${W}_f8_$i.json 2>/dev/null
+  OPEN_PROVENCE_NO_F8=1 python bench.py --steps 60 --no-cpu-baseline --no-long --no-base --weights $W > gpurun_out/ab_${W}_nof8_$i.json 2>/dev/null
+  python bench.py --steps 60 --no-cpu-baseline --no-long --no-base --weights $W > gpurun_out/ab_${W}_f8_$i.json 2>/dev/null
 done
 python - $W <<'PY'
 import json,glob,sys

@@ -41,6 +41,10 @@ def test_bench_json_line_contract():
     assert other["value"] > 0 and other["policy"]["kernel_set"] == "f16-f8" and other["checkpoint_dtype"] == "bf16"
     assert 0.5 < line["shader_clock_ghz"]["value"] < 3.0
     assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
+    # the panel path (base dims) as a sub-record, both checkpoint dtypes on the fp16 + e4m3 kernel sets
+    base = line["base_model"]
+    assert base["model"] == "base" and base["fp32_checkpoint"]["kernel_set"] == "f16-f8-w" and base["bf16_checkpoint"]["kernel_set"] == "f16-f8"
+    assert base["fp32_checkpoint"]["value"] > 0 and base["bf16_checkpoint"]["value"] > 0
 
 
 @pytest.mark.gpu
@@ -52,7 +56,7 @@ def test_bench_two_launch_sequences_with_the_bf16_kernel_sets():
 
     proc = subprocess.run(
         [sys.executable, str(REPO_ROOT / "bench.py"), "--pairs", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-         "--no-long", "--no-other-dtype", "--weights", "bf16"],
+         "--no-long", "--no-base", "--no-other-dtype", "--weights", "bf16"],
         capture_output=True, text=True, timeout=600, env={**os.environ, "OPEN_PROVENCE_NO_F8": "1"},
     )
     assert proc.returncode == 0, proc.stderr[-2000:]
@@ -69,7 +73,7 @@ def test_bench_multi_gpu_code_path_on_a_one_rank_group():
 
     proc = subprocess.run(
         [sys.executable, str(REPO_ROOT / "bench.py"), "--pairs", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-         "--no-long", "--exercise-gather"],
+         "--no-long", "--no-base", "--exercise-gather"],
         capture_output=True, text=True, timeout=600,
     )
     assert proc.returncode == 0, proc.stderr[-2000:]

@@ -185,3 +185,46 @@ def test_embedding_and_head_inside_the_first_and_last_kernels(fixture):
     # the bar, on every fixture (fp32 weights carry their lo planes: all-terms kernel set, two kernels per layer)
     rep = run_fixture_on_gpu(fixture, "bf16x3", capture=False)
     assert rep["prune_max_err"] < 1e-3 and rep["rank_max_err"] < 1e-3, rep
+
+
+@pytest.mark.parametrize("fixture", ["g2_gte_varlen", "g8_base_refinit"])
+@pytest.mark.parametrize("weights", ["bf16", "fp32"])
+def test_panel_path_f16_f8_kernel_sets(fixture, weights):
+    """hidden 768 (panel GEMMs): the default flags select the fp16 + e4m3 kernel sets there too -- "f16-f8" for
+    bf16-valued weights, "f16-f8-w" (the weights' lo part as a second e4m3 plane) for fp32-valued ones; every panel GEMM
+    (q / k / v, attention output, Wi + GeGLU, MLP output) and LayerNorm then runs its fp16 + e4m3 form and attention
+    writes o in that format.  Within 1e-3 of the oracle on the same weights, and close to the (hi, lo) bf16 sets."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import pad_rows
+    from oracle.modernbert_oracle import oracle_forward
+
+    arrays, meta = load_golden(fixture)
+    dims = dims_from_meta(meta)
+    state = state_from_fixture(arrays, meta)
+    if weights == "bf16":
+        state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v for k, v in state.items()}
+    rows = rows_from_fixture(arrays)
+    pre = bool(meta.get("prune_pre_final_norm", False))
+    expected = {("bf16", 0): "f16-f8", ("bf16", NO_F8): "bf16-weights", ("fp32", 0): "f16-f8-w", ("fp32", NO_F8): "bf16x3"}
+    outs = {}
+    for flags in (0, NO_F8):
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags, prune_pre_final_norm=pre)
+        enc.load_state_dict(state)
+        assert enc.effective_policy()["kernel_set"] == expected[(weights, flags)]
+        enc.profile_enable(True)
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        kinds = set(enc.profile_read())
+        assert {"gemm_qkv_rope", "gemm_attn_out", "gemm_wi_geglu", "gemm_mlp_out"} <= kinds, kinds  # the panel path ran
+        outs[flags] = (prune.cpu().numpy(), rank.cpu().numpy())
+        enc.close()
+    ids, mask = pad_rows(rows)
+    ref = oracle_forward(state, dims, ids, mask, prune_pre_final_norm=pre)
+    m = mask.bool().numpy()
+    for flags in (0, NO_F8):  # tolerance of the path: 1e-3 on logits against the CPU reference arithmetic
+        assert np.isfinite(outs[flags][0]).all() and np.isfinite(outs[flags][1]).all()
+        assert np.abs(outs[flags][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3, flags
+        assert np.abs(outs[flags][1] - ref.ranking_logits.numpy()).max() < 1e-3, flags
+    assert np.abs(outs[0][0] - outs[NO_F8][0]).max() < 5e-4
+    assert np.abs(outs[0][1] - outs[NO_F8][1]).max() < 5e-4
