@@ -556,13 +556,9 @@ def main() -> None:
         flops_b = algorithmic_flops_per_pair(dims_b, args.seq_len)
         base_steps = max(5, args.steps // 10)
         sub_b = {"unit": "pairs/s", "model": "base", "steps": base_steps, "algorithmic_gflop_per_pair": flops_b / 1e9}
-        for wdt in ("fp32", "bf16"):
-            state_b = synth_state_dict(dims_b, seed=7)
-            if wdt == "bf16":
-                state_b = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state_b.items()}
-            enc_b = HipEncoder(dims_b, device=device, precision=args.precision)
-            enc_b.load_state_dict(state_b)
-            del state_b
+        from open_provence_amd import _lib as _oplib
+
+        def timed_base(enc_b):
             for _ in range(2):
                 enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
             torch.cuda.synchronize(device)
@@ -570,18 +566,33 @@ def main() -> None:
             for _ in range(base_steps):
                 enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
             torch.cuda.synchronize(device)
-            dt_b = (time.perf_counter() - t1) / base_steps
+            return (time.perf_counter() - t1) / base_steps
+
+        for wdt in ("fp32", "bf16"):
+            state_b = synth_state_dict(dims_b, seed=7)
+            if wdt == "bf16":
+                state_b = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state_b.items()}
+            enc_b = HipEncoder(dims_b, device=device, precision=args.precision)
+            enc_b.load_state_dict(state_b)
+            dt_b = timed_base(enc_b)
             enc_b.profile_enable(True)
             enc_b.profile_reset()
             for _ in range(2):
                 enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
             prof_b = enc_b.profile_read()
             enc_b.profile_enable(False)
-            sub_b[f"{wdt}_checkpoint"] = {
-                "value": args.pairs / dt_b, "ms_per_step": dt_b * 1e3, "kernel_set": enc_b.effective_policy()["kernel_set"],
-                "whole_forward_frac": args.pairs / dt_b * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                "kernel_ms_per_forward": {k: v["total_ms"] / 2 for k, v in prof_b.items()}}
+            rec = {"value": args.pairs / dt_b, "ms_per_step": dt_b * 1e3, "kernel_set": enc_b.effective_policy()["kernel_set"],
+                   "whole_forward_frac": args.pairs / dt_b * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                   "kernel_ms_per_forward": {k: v["total_ms"] / 2 for k, v in prof_b.items()}}
             enc_b.close()
+            # the opt-in fp16 + e4m3 kernel sets of this path (OP_FLAG_PANEL_F8; off by default for their error at this depth)
+            enc_f = HipEncoder(dims_b, device=device, precision=args.precision, flags=_oplib.OP_FLAG_PANEL_F8)
+            enc_f.load_state_dict(state_b)
+            del state_b
+            dt_f = timed_base(enc_f)
+            rec["opt_in_panel_f8"] = {"value": args.pairs / dt_f, "ms_per_step": dt_f * 1e3, "kernel_set": enc_f.effective_policy()["kernel_set"]}
+            enc_f.close()
+            sub_b[f"{wdt}_checkpoint"] = rec
         line["base_model"] = sub_b
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dims, state, args.seq_len)

@@ -85,6 +85,7 @@ enum op_flags {
   OP_FLAG_NO_HEAD_FUSION = 256,   /* embedding + LayerNorm and final_norm + pruning head as their own launches on the row path too (A/B hook) */
   OP_FLAG_LAYER_M32 = 128,        /* whole-layer kernel on 32x32x16 MFMAs (hidden = 256): fewer cycles, more power per flop -- slower under the power limit (A/B hook) */
   OP_FLAG_ATTN_XCD_GROUP = 1024,  /* row path too: the XCD-grouped attention block map (the query blocks of a sequence-head follow each other on one XCD; default on the panel path only) (A/B hook) */
+  OP_FLAG_PANEL_F8 = 2048,        /* hidden 512 / 768 (panel GEMMs): select the fp16 + e4m3 kernel sets there too.  OFF by default: through 19-25 layers their error against the fp32 reference reaches 0.45-1.0e-3 on logits (the (hi, lo) bf16 sets: 0.2-0.5e-3), too close to the 1e-3 bar of the path for +2.5 % (bf16 checkpoint) / +14 % (fp32) pairs/s */
   OP_FLAG_NO_F8 = 512             /* never select kernel set 3 (fp16 hi + e4m3 lo operands in the whole-layer kernel): keep the (hi, lo) bf16 kernel sets (A/B and bit-identity test hook) */
 };
 

@@ -31,6 +31,7 @@ _ENV_FLAGS = {
     "OPEN_PROVENCE_NO_HEAD_FUSION": _lib.OP_FLAG_NO_HEAD_FUSION,
     "OPEN_PROVENCE_NO_F8": _lib.OP_FLAG_NO_F8,
     "OPEN_PROVENCE_ATTN_XCD_GROUP": _lib.OP_FLAG_ATTN_XCD_GROUP,
+    "OPEN_PROVENCE_PANEL_F8": _lib.OP_FLAG_PANEL_F8,
 }
 
 

@@ -39,10 +39,12 @@ from .pipeline import ContextState, FragmentRecord, RawPrediction
 from .splitters import SentenceSplitter, resolve_sentence_splitter
 
 LOGGER = logging.getLogger(__name__)
-# as the reference (standalone.py:160): the Rust tokenizer's own thread pool costs more than it returns on the ~10
-# sentences of one context (7 k voluntary context switches per 256 contexts measured); preprocess_workers is the
-# parallelism of this stage
-os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
+# The reference switches the Rust tokenizer's thread pool off (standalone.py:160: it tokenizes one context per call in
+# forked DataLoader workers).  Here nothing forks and the sentences of a whole group of contexts go through ONE call
+# (pipeline.tokenize_sentence_groups), which is what that pool is good at: 256 contexts x 11 sentences 95 ms -> 31 ms on
+# 8 cores.  (One context per call WITH the pool was the bad combination: 7 k voluntary context switches per 256 contexts.)
+# An explicit TOKENIZERS_PARALLELISM in the environment is honoured.
+os.environ.setdefault("TOKENIZERS_PARALLELISM", "true")
 
 DEFAULT_SPLITTER_LANGUAGE = "auto"
 OpenProvenceRawPrediction = RawPrediction
@@ -1057,7 +1059,7 @@ class OpenProvenceModel:
 
     def _iter_jobs(
         self, queries, contexts, titles, splitter: SentenceSplitter, query_token_ids: list[list[int]], *,
-        strip_sentences: bool, timing: dict[str, float], workers: int = 0
+        strip_sentences: bool, timing: dict[str, float], workers: int = 0, group_size: int = 32
     ):
         """One job per (query, context), produced lazily: sentences (prefix + split or pre-split), their token lists
         and the prefix token counts (ref: _build_preprocess_jobs :2436-2519, _precompute_sentences_and_tokens :2198).
@@ -1065,7 +1067,11 @@ class OpenProvenceModel:
 
         The reference hands this stage to DataLoader workers so that it overlaps the forward (:2681-2760); here the
         consumer launches a forward asynchronously after every granule of jobs and comes back for the next ones, so the
-        same overlap happens on one host thread."""
+        same overlap happens on one host thread.
+
+        Contexts are prepared in groups of ``group_size``: sentence splitting per context, then ONE tokenizer call over
+        the sentences of the whole group (``pipeline.tokenize_sentence_groups``; same ids, a fraction of the call
+        overhead, and a fast tokenizer's own thread pool gets a batch worth spreading)."""
 
         def specs():
             for q_idx, query in enumerate(queries):
@@ -1073,65 +1079,86 @@ class OpenProvenceModel:
                 for c_idx, entry in enumerate(contexts[q_idx]):
                     yield q_idx, c_idx, entry
 
-        def build(spec):
-            q_idx, c_idx, entry = spec
-            if isinstance(entry, list):
-                manual = [str(s) for s in entry if str(s).strip()]
-                text = "".join(manual)
-            else:
-                manual = None
-                text = entry
-            prefix, title_is_first = self._resolve_prefix_sentences(titles[q_idx], c_idx)
-            payload = {"context_text": text, "prefix_sentences": prefix, "manual_sentences": manual}
-            t0 = perf_counter()
-            raw = pl.collect_candidate_sentences(payload, splitter)
-            t1 = perf_counter()
-            sentences = pl.normalize_sentences(raw, text, strip_sentences)
+        def build_group(group):
+            """Jobs of a group of contexts: sentences per context, then ONE tokenizer call over all of them."""
+
+            prepared = []
+            t_collect = t_norm = 0.0
+            for q_idx, c_idx, entry in group:
+                if isinstance(entry, list):
+                    manual = [str(s) for s in entry if str(s).strip()]
+                    text = "".join(manual)
+                else:
+                    manual = None
+                    text = entry
+                prefix, title_is_first = self._resolve_prefix_sentences(titles[q_idx], c_idx)
+                payload = {"context_text": text, "prefix_sentences": prefix, "manual_sentences": manual}
+                t0 = perf_counter()
+                raw = pl.collect_candidate_sentences(payload, splitter)
+                t1 = perf_counter()
+                sentences = pl.normalize_sentences(raw, text, strip_sentences)
+                t2 = perf_counter()
+                t_collect += t1 - t0
+                t_norm += t2 - t1
+                prepared.append((q_idx, c_idx, text, prefix, title_is_first, sentences))
             t2 = perf_counter()
-            token_lists = pl.tokenize_sentences(self.tokenizer, sentences)
+            token_groups = pl.tokenize_sentence_groups(self.tokenizer, [p[5] for p in prepared])
             t3 = perf_counter()
-            return {
-                "query_idx": q_idx,
-                "context_idx": c_idx,
-                "context_text": text,
-                "prefix_sentences": prefix,
-                "title_is_first_sentence": title_is_first,
-                "prefix_token_counts": [len(t) for t in token_lists[: len(prefix)]],
-                "sentences": sentences,
-                "token_lists": token_lists,
-            }, (t1 - t0, t2 - t1, t3 - t2)
+            jobs = [
+                {
+                    "query_idx": q_idx,
+                    "context_idx": c_idx,
+                    "context_text": text,
+                    "prefix_sentences": prefix,
+                    "title_is_first_sentence": title_is_first,
+                    "prefix_token_counts": [len(t) for t in token_lists[: len(prefix)]],
+                    "sentences": sentences,
+                    "token_lists": token_lists,
+                }
+                for (q_idx, c_idx, text, prefix, title_is_first, sentences), token_lists in zip(prepared, token_groups)
+            ]
+            return jobs, (t_collect, t_norm, t3 - t2)
 
         def account(times):
             timing["sentence_collect_seconds"] += times[0]
             timing["sentence_normalize_seconds"] += times[1]
             timing["tokenize_seconds"] += times[2]
 
+        def groups():
+            it = specs()
+            while True:
+                group = list(itertools.islice(it, max(1, int(group_size))))
+                if not group:
+                    return
+                yield group
+
         if workers <= 0:
-            for spec in specs():
-                job, times = build(spec)
+            for group in groups():
+                jobs, times = build_group(group)
                 account(times)
-                yield job
+                yield from jobs
             return
         # preprocess_workers > 0: the reference runs this stage in DataLoader worker processes (standalone.py:3589,
-        # :2478-2519).  Here: worker THREADS with a bounded look-ahead, results yielded in order.  The expensive calls
-        # release the GIL where it matters -- a Hugging Face fast tokenizer (Rust `encode_batch`) and the Rust / C
-        # sentence splitters (fast-bunkai, nltk's regex core) -- and no process is forked next to a live HIP runtime.
+        # :2478-2519).  Here: worker THREADS with a bounded look-ahead over GROUPS of contexts, results yielded in order.
+        # The expensive calls release the GIL where it matters -- a Hugging Face fast tokenizer (Rust `encode_batch`) and
+        # the Rust / C sentence splitters (fast-bunkai, nltk's regex core) -- and no process is forked next to a live HIP
+        # runtime.
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
 
-        window = max(2 * workers, 8)
+        window = max(2 * workers, 4)
         with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="open-provence-prep") as pool:
             inflight: deque = deque()
-            for spec in specs():
-                inflight.append(pool.submit(build, spec))
+            for group in groups():
+                inflight.append(pool.submit(build_group, group))
                 if len(inflight) >= window:
-                    job, times = inflight.popleft().result()
+                    jobs, times = inflight.popleft().result()
                     account(times)
-                    yield job
+                    yield from jobs
             while inflight:
-                job, times = inflight.popleft().result()
+                jobs, times = inflight.popleft().result()
                 account(times)
-                yield job
+                yield from jobs
 
     def _build_jobs(
         self, queries, contexts, titles, splitter: SentenceSplitter, *, strip_sentences: bool, timing: dict[str, float]
@@ -1406,7 +1433,7 @@ class OpenProvenceModel:
             thread_workers = min(int(workers), 32) if (workers_explicit and workers > 0) else 0
             job_stream = self._iter_jobs(
                 queries, contexts, titles, splitter, query_token_ids, strip_sentences=strip_sentences, timing=timing,
-                workers=thread_workers,
+                workers=thread_workers, group_size=min(32, max(1, preprocess_batch)),
             )
             states: dict[tuple[int, int], ContextState] = {}
             total_blocks = 0
@@ -1426,17 +1453,16 @@ class OpenProvenceModel:
                     break
                 inference_jobs: list[dict[str, Any]] = []
                 t_asm = perf_counter()
-                for job in batch_jobs:
-                    t0 = perf_counter()
-                    fragments = pl.fragmentize(
-                        self.tokenizer,
-                        job["token_lists"],
-                        job["context_text"],
-                        max_fragment_tokens,
-                        strip_sentences=strip_sentences,
-                        respect_sentence_boundaries=respect_sentence_boundaries,
-                    )
-                    timing["fragment_decode_seconds"] += perf_counter() - t0
+                t0 = perf_counter()
+                fragments_per_job = pl.fragmentize_many(  # one batch_decode over the fragments of the whole batch
+                    self.tokenizer,
+                    [(job["token_lists"], job["context_text"]) for job in batch_jobs],
+                    max_fragment_tokens,
+                    strip_sentences=strip_sentences,
+                    respect_sentence_boundaries=respect_sentence_boundaries,
+                )
+                timing["fragment_decode_seconds"] += perf_counter() - t0
+                for job, fragments in zip(batch_jobs, fragments_per_job):
                     q_idx, c_idx = job["query_idx"], job["context_idx"]
                     blocks = self._assemble_blocks_from_fragments(len(query_token_ids[q_idx]), len(sep_token_ids), fragments)
                     states[(q_idx, c_idx)] = ContextState(

@@ -3,8 +3,8 @@ M=${1:-base}
 W=${2:-bf16}
 S=${3:-20}
 for i in 1 2; do
-  OPEN_PROVENCE_NO_F8=1 timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-other-dtype --weights $W > gpurun_out/abp_${M}_${W}_nof8_$i.json 2>gpurun_out/abp_err.log
-  timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-other-dtype --weights $W > gpurun_out/abp_${M}_${W}_f8_$i.json 2>>gpurun_out/abp_err.log
+  timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-other-dtype --weights $W > gpurun_out/abp_${M}_${W}_nof8_$i.json 2>gpurun_out/abp_err.log
+  OPEN_PROVENCE_PANEL_F8=1 timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-other-dtype --weights $W > gpurun_out/abp_${M}_${W}_f8_$i.json 2>>gpurun_out/abp_err.log
 done
 python - $M $W <<'PY'
 import json,glob,sys

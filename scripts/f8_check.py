@@ -16,6 +16,7 @@ from open_provence_amd.synthetic import pad_rows  # noqa: E402
 from oracle.modernbert_oracle import oracle_forward  # noqa: E402
 
 NO_F8 = 512
+PANEL_F8 = 2048  # the panel path (hidden 512 / 768) takes the fp16 + e4m3 sets on request only
 
 
 def run(fixture: str, weights: str) -> None:
@@ -27,7 +28,7 @@ def run(fixture: str, weights: str) -> None:
     rows = rows_from_fixture(arrays)
     pre = bool(meta.get("prune_pre_final_norm", False))
     outs = {}
-    for label, flags in (("f8", 0), ("bf16", NO_F8)):
+    for label, flags in (("f8", PANEL_F8), ("bf16", NO_F8)):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags, prune_pre_final_norm=pre)
         enc.load_state_dict(state)
         ks = enc.effective_policy()["kernel_set"]

@@ -41,9 +41,9 @@ def test_bench_json_line_contract():
     assert other["value"] > 0 and other["policy"]["kernel_set"] == "f16-f8" and other["checkpoint_dtype"] == "bf16"
     assert 0.5 < line["shader_clock_ghz"]["value"] < 3.0
     assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
-    # the panel path (base dims) as a sub-record, both checkpoint dtypes on the fp16 + e4m3 kernel sets
+    # the panel path (base dims) as a sub-record, both checkpoint dtypes: default flags = the (hi, lo) bf16 kernel sets
     base = line["base_model"]
-    assert base["model"] == "base" and base["fp32_checkpoint"]["kernel_set"] == "f16-f8-w" and base["bf16_checkpoint"]["kernel_set"] == "f16-f8"
+    assert base["model"] == "base" and base["fp32_checkpoint"]["kernel_set"] == "bf16x3" and base["bf16_checkpoint"]["kernel_set"] == "bf16-weights"
     assert base["fp32_checkpoint"]["value"] > 0 and base["bf16_checkpoint"]["value"] > 0
 
 

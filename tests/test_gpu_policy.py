@@ -19,6 +19,7 @@ NO_POLICY_KERNELS = 16  # OP_FLAG_NO_POLICY_KERNELS
 NO_LAYER_FUSION = 32    # OP_FLAG_NO_LAYER_FUSION: two fused kernels per layer (the shape the all-terms set has too)
 LAYER_M32 = 128         # OP_FLAG_LAYER_M32: the whole-layer kernel on 32x32x16 MFMAs (hidden = 256)
 NO_F8 = 512             # OP_FLAG_NO_F8: keep the (hi, lo) bf16 whole-layer kernel (kernel set "bf16-weights")
+PANEL_F8 = 2048         # OP_FLAG_PANEL_F8: the fp16 + e4m3 kernel sets on the panel path (hidden 512 / 768) too -- opt-in
 
 
 @pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
@@ -190,10 +191,11 @@ def test_embedding_and_head_inside_the_first_and_last_kernels(fixture):
 @pytest.mark.parametrize("fixture", ["g2_gte_varlen", "g8_base_refinit"])
 @pytest.mark.parametrize("weights", ["bf16", "fp32"])
 def test_panel_path_f16_f8_kernel_sets(fixture, weights):
-    """hidden 768 (panel GEMMs): the default flags select the fp16 + e4m3 kernel sets there too -- "f16-f8" for
+    """hidden 768 (panel GEMMs): OP_FLAG_PANEL_F8 selects the fp16 + e4m3 kernel sets there too -- "f16-f8" for
     bf16-valued weights, "f16-f8-w" (the weights' lo part as a second e4m3 plane) for fp32-valued ones; every panel GEMM
     (q / k / v, attention output, Wi + GeGLU, MLP output) and LayerNorm then runs its fp16 + e4m3 form and attention
-    writes o in that format.  Within 1e-3 of the oracle on the same weights, and close to the (hi, lo) bf16 sets."""
+    writes o in that format.  Within 1e-3 of the oracle on the same weights (3-layer fixtures), and close to the (hi, lo)
+    bf16 sets, which stay the default on this path (the format's error at the published depths: include/open_provence_hip.h)."""
 
     from open_provence_amd.engine import HipEncoder
     from open_provence_amd.synthetic import pad_rows
@@ -206,9 +208,9 @@ def test_panel_path_f16_f8_kernel_sets(fixture, weights):
         state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v for k, v in state.items()}
     rows = rows_from_fixture(arrays)
     pre = bool(meta.get("prune_pre_final_norm", False))
-    expected = {("bf16", 0): "f16-f8", ("bf16", NO_F8): "bf16-weights", ("fp32", 0): "f16-f8-w", ("fp32", NO_F8): "bf16x3"}
+    expected = {("bf16", PANEL_F8): "f16-f8", ("bf16", 0): "bf16-weights", ("fp32", PANEL_F8): "f16-f8-w", ("fp32", 0): "bf16x3"}
     outs = {}
-    for flags in (0, NO_F8):
+    for flags in (PANEL_F8, 0):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags, prune_pre_final_norm=pre)
         enc.load_state_dict(state)
         assert enc.effective_policy()["kernel_set"] == expected[(weights, flags)]
@@ -222,9 +224,9 @@ def test_panel_path_f16_f8_kernel_sets(fixture, weights):
     ids, mask = pad_rows(rows)
     ref = oracle_forward(state, dims, ids, mask, prune_pre_final_norm=pre)
     m = mask.bool().numpy()
-    for flags in (0, NO_F8):  # tolerance of the path: 1e-3 on logits against the CPU reference arithmetic
+    for flags in (PANEL_F8, 0):  # tolerance of the path: 1e-3 on logits against the CPU reference arithmetic
         assert np.isfinite(outs[flags][0]).all() and np.isfinite(outs[flags][1]).all()
         assert np.abs(outs[flags][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3, flags
         assert np.abs(outs[flags][1] - ref.ranking_logits.numpy()).max() < 1e-3, flags
-    assert np.abs(outs[0][0] - outs[NO_F8][0]).max() < 5e-4
-    assert np.abs(outs[0][1] - outs[NO_F8][1]).max() < 5e-4
+    assert np.abs(outs[0][0] - outs[PANEL_F8][0]).max() < 5e-4
+    assert np.abs(outs[0][1] - outs[PANEL_F8][1]).max() < 5e-4

@@ -354,3 +354,49 @@ def test_device_side_fragment_means_path_equals_the_token_path():
         state.raw_blocks = raws_means
         got, got_rank = score_fragments(state, True)
         assert dict(got) == dict(want) and got_rank == want_rank
+
+
+@pytest.mark.parametrize("kind", ["char", "wordpiece"])
+def test_grouped_tokenize_and_decode_equal_the_per_context_calls(kind):
+    """``tokenize_sentence_groups`` / ``fragmentize_many`` (one tokenizer call per GROUP of contexts) return exactly what
+    the per-context calls of the reference's stage return (standalone.py:2198-2259): same ids, same fragment records --
+    including a context whose sentences decode to nothing (first fragment resurrected) and an empty group."""
+
+    from helpers import build_wordpiece_tokenizer
+    from open_provence_amd import pipeline as pl
+
+    tok = CharTokenizer() if kind == "char" else build_wordpiece_tokenizer(True)
+    groups = [
+        ["alpha beta gamma. ", "delta epsilon zeta eta theta iota kappa lambda mu. ", "nu"],
+        ["   "],
+        [],
+        ["omega " * 40, "alpha."],
+        ["beta"],
+    ]
+    grouped = pl.tokenize_sentence_groups(tok, groups)
+    single = [pl.tokenize_sentences(tok, g) for g in groups]
+    assert grouped == single and [len(g) for g in grouped] == [len(g) for g in groups]
+    contexts = [(ids, "".join(g)) for ids, g in zip(grouped, groups)]
+    for strip in (False, True):
+        for respect in (False, True):
+            many = pl.fragmentize_many(tok, contexts, 7, strip_sentences=strip, respect_sentence_boundaries=respect)
+            one = [pl.fragmentize(tok, ids, text, 7, strip_sentences=strip, respect_sentence_boundaries=respect) for ids, text in contexts]
+            assert many == one
+            assert all(len(records) >= 1 for records in many)
+
+
+def test_grouped_tokenize_falls_back_when_the_tokenizer_drops_rows():
+    """A tokenizer that does not answer one row per sentence for a flat batch is called per group, as before."""
+
+    from open_provence_amd import pipeline as pl
+
+    class Lossy(CharTokenizer):
+        def __call__(self, texts, **kw):
+            out = super().__call__(texts, **kw)
+            if len(texts) > 2:
+                out["input_ids"] = out["input_ids"][:-1]
+            return out
+
+    tok = Lossy()
+    groups = [["ab", "cd"], ["ef"], ["gh", "ij"]]
+    assert pl.tokenize_sentence_groups(tok, groups) == [pl.tokenize_sentences(tok, g) for g in groups]
