@@ -1059,7 +1059,7 @@ class OpenProvenceModel:
 
     def _iter_jobs(
         self, queries, contexts, titles, splitter: SentenceSplitter, query_token_ids: list[list[int]], *,
-        strip_sentences: bool, timing: dict[str, float], workers: int = 0, group_size: int = 32
+        strip_sentences: bool, timing: dict[str, float], workers: int = 0, group_size: int = 64
     ):
         """One job per (query, context), produced lazily: sentences (prefix + split or pre-split), their token lists
         and the prefix token counts (ref: _build_preprocess_jobs :2436-2519, _precompute_sentences_and_tokens :2198).
@@ -1433,7 +1433,7 @@ class OpenProvenceModel:
             thread_workers = min(int(workers), 32) if (workers_explicit and workers > 0) else 0
             job_stream = self._iter_jobs(
                 queries, contexts, titles, splitter, query_token_ids, strip_sentences=strip_sentences, timing=timing,
-                workers=thread_workers, group_size=min(32, max(1, preprocess_batch)),
+                workers=thread_workers, group_size=min(64, max(1, preprocess_batch)),
             )
             states: dict[tuple[int, int], ContextState] = {}
             total_blocks = 0

@@ -400,3 +400,45 @@ def test_grouped_tokenize_falls_back_when_the_tokenizer_drops_rows():
     tok = Lossy()
     groups = [["ab", "cd"], ["ef"], ["gh", "ij"]]
     assert pl.tokenize_sentence_groups(tok, groups) == [pl.tokenize_sentences(tok, g) for g in groups]
+
+
+def test_fast_decode_backend_only_for_stock_tokenizers_and_equal_to_batch_decode():
+    """``decode_fragment_texts`` takes the Rust ``decode_batch`` shortcut for a stock fast tokenizer only, after checking
+    it against ``batch_decode`` on the first batch; a subclass that overrides decoding keeps its own ``batch_decode``."""
+
+    from helpers import build_wordpiece_tokenizer
+    from open_provence_amd import pipeline as pl
+
+    tok = build_wordpiece_tokenizer(True)
+    seqs = tok(["The tower is tall.", "It was built long ago!", "boats carry fish and salt", "zzz qqq"], add_special_tokens=False)["input_ids"]
+    seqs.append([1] + seqs[0] + [2])  # special tokens are skipped
+    expected = tok.batch_decode(seqs, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+    assert pl.decode_fragment_texts(tok, seqs) == expected
+    assert getattr(tok, pl._FAST_DECODE_ATTR) is tok._tokenizer  # the shortcut was accepted
+    assert pl.decode_fragment_texts(tok, []) == []
+
+    class Shouting(type(tok)):
+        def batch_decode(self, sequences, **kw):
+            return [t.upper() for t in super().batch_decode(sequences, **kw)]
+
+    loud = build_wordpiece_tokenizer(True)
+    loud.__class__ = Shouting
+    assert pl.decode_fragment_texts(loud, seqs) == [t.upper() for t in expected]
+    assert getattr(loud, pl._FAST_DECODE_ATTR) is False
+    assert pl.decode_fragment_texts(CharTokenizer(), [[5, 6, 7]]) == CharTokenizer().batch_decode([[5, 6, 7]], skip_special_tokens=True, clean_up_tokenization_spaces=False)
+
+
+def test_fast_encode_backend_equals_the_public_call_and_respects_backend_truncation():
+    from helpers import build_wordpiece_tokenizer
+    from open_provence_amd import pipeline as pl
+
+    tok = build_wordpiece_tokenizer(True)
+    groups = [["The tower is tall.", "It was built long ago!"], ["boats carry fish and salt " * 30], ["zzz qqq", "a"]]
+    expected = [tok(list(g), add_special_tokens=False)["input_ids"] for g in groups]
+    assert pl.tokenize_sentence_groups(tok, groups) == expected
+    assert getattr(tok, pl._FAST_ENCODE_ATTR) is tok._tokenizer
+    # a truncation left enabled on the backend (someone called the tokenizer with truncation=True in between) switches
+    # the shortcut off for that call: the public call resets it, as the reference's per-context call does
+    tok._tokenizer.enable_truncation(max_length=4)
+    assert pl.tokenize_sentence_groups(tok, groups) == expected
+    assert tok._tokenizer.truncation is None
