@@ -522,7 +522,7 @@ class OpenProvenceModel:
 
     # -- data parallelism over (query, block) rows -----------------------------------
     def attach_process_group(self, group: Any | None = None, *, dst: int = 0, enabled: bool = True,
-                             single_rank_gather: bool = False) -> None:
+                             single_rank_gather: bool = False, shard: str = "jobs") -> None:
         """Shard every forward batch of ``process()`` / ``get_raw_predictions_batch`` over the ranks of a
         ``torch.distributed`` process group (backend "nccl" = RCCL over xGMI with one process per GPU; "gloo" in the
         CPU tests).  Every rank calls ``process()`` with the SAME arguments; each runs its token-balanced share of the
@@ -531,7 +531,16 @@ class OpenProvenceModel:
         ranks' ``process()`` returns ``None``.  The reference has no multi-GPU path (its jobs are independent:
         standalone.py:2748-2756).  The pipelined path of ``process()`` stays in force: every rank enqueues its share
         asynchronously (pinned staging, on-device fragment means) and the gather moves 4 bytes per FRAGMENT.
-        ``single_rank_gather`` (test hook): run the sharded code path on a one-rank group as well."""
+        ``single_rank_gather`` (test hook): run the sharded code path on a one-rank group as well.
+
+        ``shard`` selects what ``process()`` divides among the ranks:
+
+        * ``"jobs"`` (default): the (query, context) JOBS.  Every rank splits, tokenizes, assembles, runs and
+          post-processes only its own contexts (deterministic cost-balanced assignment, ``pipeline.assign_jobs``) through
+          the plain single-GPU pipeline, and ONE ``gather_object`` at the end moves the per-context results to ``dst``:
+          the host stages -- most of the time of a call with short contexts -- scale with the ranks too.
+        * ``"rows"``: every rank runs the whole host pipeline and only the forward batches are divided (as described
+          above).  ``get_raw_predictions_batch`` always shards rows."""
 
         import torch.distributed as dist
 
@@ -540,8 +549,10 @@ class OpenProvenceModel:
             return
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("attach_process_group needs an initialised torch.distributed process group")
+        if shard not in ("jobs", "rows"):
+            raise ValueError("shard must be 'jobs' or 'rows'")
         self._dist = {"group": group, "dst": int(dst), "rank": dist.get_rank(group), "world": dist.get_world_size(group),
-                      "force": bool(single_rank_gather)}
+                      "force": bool(single_rank_gather), "shard": shard, "local_only": False}
 
     def _predict_rows(self, rows: list[list[int]], type_rows: list[list[int]] | None) -> tuple[torch.Tensor, list[np.ndarray]]:
         """Rows of token ids -> (ranking_logits[B, nl] fp32 CPU, per-row keep probabilities fp32); sharded over the
@@ -549,7 +560,7 @@ class OpenProvenceModel:
         result is discarded)."""
 
         info = getattr(self, "_dist", None)
-        if not info or info["world"] <= 1:
+        if not info or info["world"] <= 1 or info.get("local_only"):
             return self._predict_rows_local(rows, type_rows)
         import torch.distributed as dist
 
@@ -584,6 +595,8 @@ class OpenProvenceModel:
 
     def _dist_info(self) -> dict[str, Any] | None:
         info = getattr(self, "_dist", None)
+        if info and info.get("local_only"):  # inside a job-sharded process(): this rank's forward batches are its own
+            return None
         return info if info and (info["world"] > 1 or info.get("force")) else None
 
     def _staging(self, slot: int, n_tokens: int, n_rows: int) -> dict[str, torch.Tensor]:
@@ -1059,7 +1072,8 @@ class OpenProvenceModel:
 
     def _iter_jobs(
         self, queries, contexts, titles, splitter: SentenceSplitter, query_token_ids: list[list[int]], *,
-        strip_sentences: bool, timing: dict[str, float], workers: int = 0, group_size: int = 64
+        strip_sentences: bool, timing: dict[str, float], workers: int = 0, group_size: int = 64,
+        owned: Sequence[Sequence[bool]] | None = None,
     ):
         """One job per (query, context), produced lazily: sentences (prefix + split or pre-split), their token lists
         and the prefix token counts (ref: _build_preprocess_jobs :2436-2519, _precompute_sentences_and_tokens :2198).
@@ -1077,7 +1091,8 @@ class OpenProvenceModel:
             for q_idx, query in enumerate(queries):
                 query_token_ids.append([int(t) for t in self.tokenizer.encode(query, add_special_tokens=False)])
                 for c_idx, entry in enumerate(contexts[q_idx]):
-                    yield q_idx, c_idx, entry
+                    if owned is None or owned[q_idx][c_idx]:  # job-sharded call: the other ranks' contexts are skipped
+                        yield q_idx, c_idx, entry
 
         def build_group(group):
             """Jobs of a group of contexts: sentences per context, then ONE tokenizer call over all of them."""
@@ -1255,6 +1270,39 @@ class OpenProvenceModel:
             self._store_raw_predictions(chunk, ranges_per_job, queries, states, rank, keeps)
         return waited
 
+    def _gather_job_results(self, result, owned, info):
+        """Job-sharded ``process()``: every rank sends the post-processed fields of the contexts it owns to rank
+        ``dst`` (one ``gather_object``; the payload is the texts and a few floats per context), which writes them into
+        its own full-size result lists -- the entries of contexts a rank does not own are placeholders until then."""
+
+        import torch.distributed as dist
+
+        fields = [f for f in (result.pruned_contexts, result.reranking_scores, result.compression_rates, result.kept_sentences,
+                              result.removed_sentences, result.titles, result.sentence_probabilities)]
+        mine = {
+            (q, c): tuple(None if f is None else f[q][c] for f in fields)
+            for q, per_query in enumerate(owned) for c, own in enumerate(per_query) if own
+        }
+        group, dst, rank, world = info["group"], info["dst"], info["rank"], info["world"]
+        if world <= 1 and not info.get("force"):
+            return result
+        dst_global = dist.get_global_rank(group, dst) if group is not None and group is not dist.group.WORLD else dst
+        gathered = [None] * world if rank == dst else None
+        device = getattr(self, "device", None)
+        ctx = torch.cuda.device(device) if (device is not None and torch.device(device).type == "cuda") else contextlib.nullcontext()
+        with ctx:  # (the NCCL backend moves pickled objects through tensors on the CURRENT device)
+            dist.gather_object(mine, gathered, dst=dst_global, group=group)
+        if rank != dst:
+            return result
+        for part_rank, part in enumerate(gathered):
+            if part_rank == rank or not part:
+                continue
+            for (q, c), values in part.items():
+                for f, v in zip(fields, values):
+                    if f is not None:
+                        f[q][c] = v
+        return result
+
     # ------------------------------------------------------------------------------------------
     # process()
     # ------------------------------------------------------------------------------------------
@@ -1382,6 +1430,18 @@ class OpenProvenceModel:
 
             query_token_ids: list[list[int]] = []
             total_jobs = sum(len(per_query) for per_query in contexts)
+            # job-level sharding (attach_process_group(shard="jobs")): this rank prepares, runs and post-processes only
+            # the contexts it owns; the forward batches below are then purely local
+            job_shard = getattr(self, "_dist", None)
+            if not (job_shard and job_shard.get("shard") == "jobs" and (job_shard["world"] > 1 or job_shard.get("force"))):
+                job_shard = None
+            owned = None
+            if job_shard is not None:
+                owner = pl.assign_jobs(contexts, job_shard["world"])
+                owned = [[r == job_shard["rank"] for r in per_query] for per_query in owner]
+                total_jobs = sum(sum(per_query) for per_query in owned)
+                job_shard["local_only"] = True
+                stack.callback(job_shard.__setitem__, "local_only", False)
 
             # effective preprocess batch (= cap of blocks per inference pass), as the reference computes it
             workers = self._resolve_preprocess_workers(preprocess_workers)
@@ -1433,7 +1493,7 @@ class OpenProvenceModel:
             thread_workers = min(int(workers), 32) if (workers_explicit and workers > 0) else 0
             job_stream = self._iter_jobs(
                 queries, contexts, titles, splitter, query_token_ids, strip_sentences=strip_sentences, timing=timing,
-                workers=thread_workers, group_size=min(64, max(1, preprocess_batch)),
+                workers=thread_workers, group_size=min(64, max(1, preprocess_batch)), owned=owned,
             )
             states: dict[tuple[int, int], ContextState] = {}
             total_blocks = 0
@@ -1514,6 +1574,10 @@ class OpenProvenceModel:
                 zero_score_when_empty=zero_score_when_empty,
             )
             result = pl.PostprocessResult(pruned_l, scores_l, rates_l, kept_l, removed_l, titles_l, probs_l)
+            if job_shard is not None:
+                t_gather = perf_counter()
+                result = self._gather_job_results(result, owned, job_shard)
+                post_time += perf_counter() - t_gather
 
         preprocess_time = sum(timing.values())
         trace = ProcessPerformanceTrace(

@@ -257,6 +257,26 @@ def collect_candidate_sentences(example: Mapping[str, Any], splitter: SentenceSp
     return sentences
 
 
+def assign_jobs(contexts: Sequence[Sequence[Any]], world: int) -> list[list[int]]:
+    """Owner rank of every (query, context) job of a request, the same on every rank: longest-processing-time-first
+    over the contexts' character counts (the cost of splitting, tokenizing and running a context grows with its
+    text), ties and equal loads broken by index."""
+
+    world = max(1, int(world))
+    costs = []
+    for q_idx, per_query in enumerate(contexts):
+        for c_idx, entry in enumerate(per_query):
+            size = sum(len(str(s)) for s in entry) if isinstance(entry, (list, tuple)) else len(str(entry))
+            costs.append((size + 64, q_idx, c_idx))  # + a per-context constant: many tiny contexts are not free
+    owner = [[0] * len(per_query) for per_query in contexts]
+    loads = [0] * world
+    for size, q_idx, c_idx in sorted(costs, key=lambda t: (-t[0], t[1], t[2])):
+        rank = min(range(world), key=lambda r: (loads[r], r))
+        loads[rank] += size
+        owner[q_idx][c_idx] = rank
+    return owner
+
+
 def normalize_sentences(raw_sentences: Sequence[str], context_text: str, strip_sentences: bool) -> list[str]:
     out: list[str] = []
     for entry in raw_sentences:

@@ -529,14 +529,18 @@ def test_sharded_forward_over_a_one_rank_nccl_group_is_bit_identical():
         model, meta = _g3_model()
         plain = [model.process(question=c["question"], context=c["context"], sentence_splitter=period_splitter, show_progress=False,
                                return_sentence_metrics=True, return_sentence_texts=True, **c["kwargs"]) for c in meta["cases"]]
-        model.attach_process_group(None, dst=0, single_rank_gather=True)
-        assert model._can_pipeline() and model._dist_info() is not None
-        for case, want in zip(meta["cases"], plain):
-            got = model.process(question=case["question"], context=case["context"], sentence_splitter=period_splitter,
-                                show_progress=False, return_sentence_metrics=True, return_sentence_texts=True, **case["kwargs"])
-            for key in ("pruned_context", "reranking_score", "compression_rate", "kept_sentences", "removed_sentences", "sentence_probabilities"):
-                assert got[key] == want[key], key
-            assert_process_result_matches(got, case["expected"], prob_tol=1e-3, score_tol=1e-3)
+        # shard="rows": forward batches divided (ShardPlan.gather of fragment means); shard="jobs" (the default): contexts
+        # divided, the per-context results moved by one gather_object -- pickled through tensors on the GPU under NCCL
+        for shard in ("rows", "jobs"):
+            model.attach_process_group(None, dst=0, single_rank_gather=True, shard=shard)
+            assert model._can_pipeline() and model._dist_info() is not None
+            for case, want in zip(meta["cases"], plain):
+                got = model.process(question=case["question"], context=case["context"], sentence_splitter=period_splitter,
+                                    show_progress=False, return_sentence_metrics=True, return_sentence_texts=True, **case["kwargs"])
+                for key in ("pruned_context", "reranking_score", "compression_rate", "kept_sentences", "removed_sentences", "sentence_probabilities"):
+                    assert got[key] == want[key], (shard, key)
+                assert_process_result_matches(got, case["expected"], prob_tol=1e-3, score_tol=1e-3)
+            assert model._dist_info() is not None  # the job-sharded call restored the group for row-sharded entry points
     finally:
         dist.destroy_process_group()
 

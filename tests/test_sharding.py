@@ -95,9 +95,10 @@ def test_shard_plan_round_trip_vectorised():
             assert torch.equal(tok, values) and torch.equal(rk, ranks)
 
 
-def _process_worker(rank, world, port, out_path):
+def _process_worker(rank, world, port, out_path, shard):
     """process() with the golden stub forward on every rank of a gloo group: rank 0's result must equal the
-    single-process result exactly; the other ranks return None."""
+    single-process result exactly; the other ranks return None.  ``shard``: "jobs" (every rank prepares, runs and
+    post-processes its own contexts, one gather_object of the results) or "rows" (forward batches divided only)."""
 
     import json
     import sys
@@ -112,7 +113,7 @@ def _process_worker(rank, world, port, out_path):
     try:
         meta = json.loads((GOLDEN_DIR / "g3_process_stub.json").read_text(encoding="utf-8"))
         model = host_only_model(tokenizer=CharTokenizer(), max_length=meta["max_length"], forward=golden_stub_forward)
-        model.attach_process_group(None, dst=0)
+        model.attach_process_group(None, dst=0, shard=shard)
         results = []
         for case in meta["cases"]:
             res = model.process(question=case["question"], context=case["context"], sentence_splitter=period_splitter,
@@ -131,13 +132,14 @@ def _process_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_process_sharded_over_two_gloo_ranks_matches_golden(tmp_path):
+@pytest.mark.parametrize("shard,world", [("jobs", 2), ("jobs", 3), ("rows", 2)])
+def test_process_sharded_over_gloo_ranks_matches_golden(tmp_path, shard, world):
     import json
 
     from helpers import GOLDEN_DIR, assert_process_result_matches
 
     out_path = str(tmp_path / "proc.pt")
-    mp.spawn(_process_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_process_worker, args=(world, _free_port(), out_path, shard), nprocs=world, join=True)
     results = torch.load(out_path, weights_only=False)
     meta = json.loads((GOLDEN_DIR / "g3_process_stub.json").read_text(encoding="utf-8"))
     assert len(results) == len(meta["cases"])
@@ -284,3 +286,24 @@ def test_pipelined_collect_gathers_fragment_means_in_row_order(tmp_path, world):
     out_path = str(tmp_path / "collect.pt")
     mp.spawn(_collect_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
     assert torch.load(out_path)["ok"]
+
+
+def test_assign_jobs_is_deterministic_complete_and_balanced():
+    """Job-level sharding of process(): every (query, context) has exactly one owner, the same on every rank, and the
+    owners' character loads differ by at most one context."""
+
+    from open_provence_amd.pipeline import assign_jobs
+
+    rng = np.random.default_rng(3)
+    contexts = [["x" * int(n) for n in rng.integers(1, 4000, size=37)], [["ab" * 50, "c" * 10]], [], ["y" * 5]]
+    for world in (1, 2, 3, 8):
+        owner = assign_jobs(contexts, world)
+        assert owner == assign_jobs(contexts, world)
+        assert [len(o) for o in owner] == [len(c) for c in contexts]
+        assert all(0 <= r < world for per in owner for r in per)
+        loads = [0] * world
+        for per_q, per_o in zip(contexts, owner):
+            for entry, r in zip(per_q, per_o):
+                loads[r] += (sum(len(s) for s in entry) if isinstance(entry, list) else len(entry)) + 64
+        assert max(loads) - min(loads) <= 4000 + 64
+    assert assign_jobs([["a", "b"]], 1) == [[0, 0]]
