@@ -39,12 +39,12 @@ from .pipeline import ContextState, FragmentRecord, RawPrediction
 from .splitters import SentenceSplitter, resolve_sentence_splitter
 
 LOGGER = logging.getLogger(__name__)
-# The reference switches the Rust tokenizer's thread pool off (standalone.py:160: it tokenizes one context per call in
-# forked DataLoader workers).  Here nothing forks and the sentences of a whole group of contexts go through ONE call
-# (pipeline.tokenize_sentence_groups), which is what that pool is good at: 256 contexts x 11 sentences 95 ms -> 31 ms on
-# 8 cores.  (One context per call WITH the pool was the bad combination: 7 k voluntary context switches per 256 contexts.)
-# An explicit TOKENIZERS_PARALLELISM in the environment is honoured.
-os.environ.setdefault("TOKENIZERS_PARALLELISM", "true")
+# As the reference (standalone.py:160), the Rust tokenizer's own thread pool is off unless the environment says otherwise.
+# The parallelism of the split / tokenize stage is this module's worker threads, each encoding the sentences of a whole
+# GROUP of contexts with one GIL-free `encode_batch` (pipeline.tokenize_sentence_groups): 4 threads without the pool
+# measure 8.5 k / 10.9 k contexts/s at 1024 / 4096 contexts for 1.1 s of CPU time, the pool without threads 6.0-7.6 k /
+# 7.2 k for 2.9 s (it spins on every core of the host), both together 6.1 k.
+os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
 
 DEFAULT_SPLITTER_LANGUAGE = "auto"
 OpenProvenceRawPrediction = RawPrediction
@@ -1073,7 +1073,7 @@ class OpenProvenceModel:
     def _iter_jobs(
         self, queries, contexts, titles, splitter: SentenceSplitter, query_token_ids: list[list[int]], *,
         strip_sentences: bool, timing: dict[str, float], workers: int = 0, group_size: int = 64,
-        owned: Sequence[Sequence[bool]] | None = None,
+        owned: Sequence[Sequence[bool]] | None = None, fragment_args: Mapping[str, Any] | None = None,
     ):
         """One job per (query, context), produced lazily: sentences (prefix + split or pre-split), their token lists
         and the prefix token counts (ref: _build_preprocess_jobs :2436-2519, _precompute_sentences_and_tokens :2198).
@@ -1132,12 +1132,20 @@ class OpenProvenceModel:
                 }
                 for (q_idx, c_idx, text, prefix, title_is_first, sentences), token_lists in zip(prepared, token_groups)
             ]
-            return jobs, (t_collect, t_norm, t3 - t2)
+            t_frag = 0.0
+            if fragment_args is not None:  # fragments of the group too (one decode call), off the consumer's thread
+                t4 = perf_counter()
+                fragments = pl.fragmentize_many(self.tokenizer, [(job["token_lists"], job["context_text"]) for job in jobs], **fragment_args)
+                for job, records in zip(jobs, fragments):
+                    job["fragments"] = records
+                t_frag = perf_counter() - t4
+            return jobs, (t_collect, t_norm, t3 - t2, t_frag)
 
         def account(times):
             timing["sentence_collect_seconds"] += times[0]
             timing["sentence_normalize_seconds"] += times[1]
             timing["tokenize_seconds"] += times[2]
+            timing["fragment_decode_seconds"] += times[3]
 
         def groups():
             it = specs()
@@ -1491,9 +1499,13 @@ class OpenProvenceModel:
             # GIL-releasing tokenizers / splitters, while pure-Python ones are served best by the lazy single-thread
             # pipeline below (the reference's own default is 0 workers under 2000 jobs, standalone.py:2591-2592).
             thread_workers = min(int(workers), 32) if (workers_explicit and workers > 0) else 0
+            if not workers_explicit and total_jobs >= 128 and hasattr(getattr(self.tokenizer, "_tokenizer", None), "encode_batch"):
+                thread_workers = 4  # a Hugging Face fast tokenizer: its Rust batch calls run outside the GIL
             job_stream = self._iter_jobs(
                 queries, contexts, titles, splitter, query_token_ids, strip_sentences=strip_sentences, timing=timing,
                 workers=thread_workers, group_size=min(64, max(1, preprocess_batch)), owned=owned,
+                fragment_args=dict(max_fragment_tokens=max_fragment_tokens, strip_sentences=strip_sentences,
+                                   respect_sentence_boundaries=respect_sentence_boundaries) if thread_workers > 0 else None,
             )
             states: dict[tuple[int, int], ContextState] = {}
             total_blocks = 0
@@ -1513,15 +1525,18 @@ class OpenProvenceModel:
                     break
                 inference_jobs: list[dict[str, Any]] = []
                 t_asm = perf_counter()
-                t0 = perf_counter()
-                fragments_per_job = pl.fragmentize_many(  # one batch_decode over the fragments of the whole batch
-                    self.tokenizer,
-                    [(job["token_lists"], job["context_text"]) for job in batch_jobs],
-                    max_fragment_tokens,
-                    strip_sentences=strip_sentences,
-                    respect_sentence_boundaries=respect_sentence_boundaries,
-                )
-                timing["fragment_decode_seconds"] += perf_counter() - t0
+                if batch_jobs and "fragments" in batch_jobs[0]:  # the worker threads decoded them with their group
+                    fragments_per_job = [job["fragments"] for job in batch_jobs]
+                else:
+                    t0 = perf_counter()
+                    fragments_per_job = pl.fragmentize_many(  # one batch_decode over the fragments of the whole batch
+                        self.tokenizer,
+                        [(job["token_lists"], job["context_text"]) for job in batch_jobs],
+                        max_fragment_tokens,
+                        strip_sentences=strip_sentences,
+                        respect_sentence_boundaries=respect_sentence_boundaries,
+                    )
+                    timing["fragment_decode_seconds"] += perf_counter() - t0
                 for job, fragments in zip(batch_jobs, fragments_per_job):
                     q_idx, c_idx = job["query_idx"], job["context_idx"]
                     blocks = self._assemble_blocks_from_fragments(len(query_token_ids[q_idx]), len(sep_token_ids), fragments)

@@ -120,3 +120,37 @@ def test_preprocess_workers_give_identical_results_in_order():
         res = model.process(torch_dataloader_kwargs={"num_workers": 2}, **kwargs)
         assert_process_result_matches(res, case["expected"], prob_tol=1e-6, score_tol=1e-6)
     assert any(name.startswith("open-provence-prep") for name in seen_threads), seen_threads
+
+
+def test_fast_tokenizer_requests_take_worker_threads_by_default_and_change_nothing():
+    """From 128 jobs on, a request with a Hugging Face fast tokenizer prepares its groups of contexts (split, one
+    ``encode_batch``, one ``decode_batch`` per group) on four worker threads without being asked to -- same result as
+    ``preprocess_workers=0``, field for field."""
+
+    import threading
+
+    from helpers import build_wordpiece_tokenizer
+
+    words = "the tower is tall boats carry fish and salt to north city harbour many years ago it was new".split()
+    contexts = [
+        " ".join(f"{words[(i * 7 + j * 3 + k) % len(words)]}" for k in range(5 + (i + j) % 6)).capitalize() + "."
+        for i in range(140) for j in range(1)
+    ]
+    contexts = [" ".join(contexts[(i + d) % len(contexts)] for d in range(1 + i % 4)) for i in range(140)]
+    seen = set()
+
+    def splitter(text):
+        seen.add(threading.current_thread().name)
+        return period_splitter(text)
+
+    model = host_only_model(tokenizer=build_wordpiece_tokenizer(True), max_length=64, forward=golden_stub_forward)
+    kwargs = dict(question="which boats carry salt?", context=contexts, sentence_splitter=splitter, show_progress=False,
+                  return_sentence_metrics=True, return_sentence_texts=True, batch_size=16, threshold=0.4)
+    default = model.process(**kwargs)
+    assert any(name.startswith("open-provence-prep") for name in seen), seen
+    seen.clear()
+    single = model.process(preprocess_workers=0, **kwargs)
+    assert not any(name.startswith("open-provence-prep") for name in seen), seen
+    for key in ("pruned_context", "reranking_score", "compression_rate", "kept_sentences", "removed_sentences", "sentence_probabilities", "title"):
+        assert default[key] == single[key], key
+    assert sum(len(k) for k in default["kept_sentences"]) > 0 and sum(len(r) for r in default["removed_sentences"]) > 0
