@@ -700,6 +700,37 @@ def default_preprocess_workers() -> int:
     return 0 if total is None else max(0, int(total) - 1)
 
 
+# GiB of device memory below which a preprocess batch is capped at the paired size (ref :2600-2607); above the last: 192
+_DEVICE_BATCH_CAPS = ((12.0, 64), (20.0, 128))
+_SMALL_REQUEST_JOBS = 2_000  # below this many jobs the reference starts no worker at all (ref :2591-2592)
+
+
+def _implicit_worker_count(jobs: int, requested: int) -> int:
+    """Workers when the caller gave none: nothing for a small request, else the configured count clipped to the host
+    (all cores but one; the whole host when nothing is configured), never more workers than jobs."""
+
+    host = max(0, default_preprocess_workers())
+    if jobs < _SMALL_REQUEST_JOBS:
+        return 0
+    count = min(requested or host, host)
+    return min(count, jobs) if jobs else count
+
+
+def _implicit_preprocess_batch(jobs: int, batch: int, inference_batch: int, device_memory_bytes: int | None) -> int:
+    """Preprocess batch when the caller gave none: bounded by the device-memory table (or 32..96 around the inference
+    batch without a device figure), by the inference batch and by the number of jobs."""
+
+    if device_memory_bytes:
+        gib = device_memory_bytes / float(1024**3)
+        cap = next((size for limit, size in _DEVICE_BATCH_CAPS if gib < limit), 192)
+    else:
+        cap = min(96, max(32, inference_batch))
+    bounds = [batch, cap, max(1, inference_batch)]
+    if jobs:
+        bounds.append(jobs)
+    return min(bounds)
+
+
 def auto_tune_preprocess_loader(
     *,
     total_jobs: int,
@@ -712,36 +743,21 @@ def auto_tune_preprocess_loader(
     prefetch_explicit: bool,
     device_memory_bytes: int | None,
 ) -> tuple[int, int, int | None]:
+    """(workers, preprocess batch, prefetch factor) as the reference settles them (ref :2567-2623; keyword interface kept:
+    the reference's tests call it by keyword).  Explicit values pass through; the implicit ones come from the two rules
+    above, and the prefetch factor is ceil(batch / workers) clipped to 2..8 whenever workers run."""
+
     jobs = max(0, int(total_jobs))
     workers = max(0, int(current_workers))
     batch = max(1, int(current_preprocess_batch))
-    prefetch = current_prefetch if prefetch_explicit else None
-
     if not workers_explicit:
-        cpu_limit = max(0, default_preprocess_workers())
-        workers = min(workers or cpu_limit, cpu_limit)
-        if jobs < 2_000:
-            workers = 0
-        elif workers == 0 and cpu_limit > 0:
-            workers = min(cpu_limit, 4)
-        if jobs:
-            workers = min(workers, jobs)
-
+        workers = _implicit_worker_count(jobs, workers)
     if not batch_explicit:
-        cap: int | None = None
-        if device_memory_bytes:
-            gib = device_memory_bytes / float(1024**3)
-            cap = 64 if gib < 12 else (128 if gib < 20 else 192)
-        target = cap or min(96, max(32, inference_batch_size))
-        batch = min(batch, target, max(1, inference_batch_size))
-        if jobs:
-            batch = min(batch, jobs)
-
-    workers = max(workers, 0)
-    if workers == 0 and not prefetch_explicit:
-        prefetch = None
-    elif workers > 0 and not prefetch_explicit:
-        prefetch = max(2, min(8, math.ceil(batch / workers)))
+        batch = _implicit_preprocess_batch(jobs, batch, inference_batch_size, device_memory_bytes)
+    if prefetch_explicit:
+        prefetch = current_prefetch
+    else:
+        prefetch = max(2, min(8, math.ceil(batch / workers))) if workers > 0 else None
     return workers, batch, prefetch
 
 
