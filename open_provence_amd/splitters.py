@@ -216,24 +216,23 @@ def create_auto_sentence_splitter(
 def resolve_sentence_splitter(
     splitter: SentenceSplitter | Mapping[str, SentenceSplitter] | None, language: str | None, default_language: str | None = "auto"
 ) -> SentenceSplitter:
-    """callable | {language: callable} | None -> callable (ref: _resolve_sentence_splitter, standalone.py:2007-2039)."""
+    """callable | {language: callable} | None -> callable (ref: _resolve_sentence_splitter, standalone.py:2007-2039;
+    the error messages are the reference's: its callers match on them)."""
 
-    if isinstance(splitter, Mapping):
+    if callable(splitter) and not isinstance(splitter, Mapping):
+        return splitter
+    if isinstance(splitter, Mapping):  # the caller's own registry, keyed by language
         if language is None:
             raise ValueError("language must be provided when sentence_splitter is a mapping")
-        if language in splitter:
+        try:
             return splitter[language]
-        raise ValueError(f"No sentence splitter registered for language '{language}'")
-    if callable(splitter):
-        return splitter
-    lang = language if language is not None else default_language
-    normalized = str(lang if lang is not None else "auto").lower()
-    if normalized == "auto":
-        return create_auto_sentence_splitter()
-    if normalized == "ja":
-        return fast_bunkai_sentence_splitter
-    if normalized == "en":
-        return english_sentence_splitter
-    raise ValueError(
-        f"Unsupported language code for sentence splitting: '{lang}'. Supported values are 'auto', 'en', and 'ja'."
-    )
+        except KeyError:
+            raise ValueError(f"No sentence splitter registered for language '{language}'") from None
+    wanted = next((v for v in (language, default_language) if v is not None), "auto")
+    builtin = {"auto": create_auto_sentence_splitter, "ja": lambda: fast_bunkai_sentence_splitter, "en": lambda: english_sentence_splitter}
+    make = builtin.get(str(wanted).lower())
+    if make is None:
+        raise ValueError(
+            f"Unsupported language code for sentence splitting: '{wanted}'. Supported values are 'auto', 'en', and 'ja'."
+        )
+    return make()
