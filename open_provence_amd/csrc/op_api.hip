@@ -94,6 +94,7 @@ struct op_handle {
   int pi = 0;                      // curated kernel set that runs `eff` (index into opl::kPolicies)
   bool emulate = false;            // eff is not curated: kernel set 0 with the unused lo operands cleared
   bool resolved = false;           // eff / pi / emulate are valid (set by op_weights_ready)
+  float* f16_fit_dev = nullptr;    // [2] lost / total weight energy of the tensor being packed for the "f16 + fp8" sets
   int* any_lo_dev = nullptr;       // [OP_FAM_COUNT] device flags: some weight of the family has a non-zero lo element
                                    // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value (no "f16 + fp8" set)
   bool f8_packs = false;           // the "f16 + fp8" weight packs exist (row path, hidden a multiple of 128)
@@ -931,8 +932,10 @@ int op_create(const op_config* cfg, op_handle** out) {
       h->n_cus = prop.multiProcessorCount;
   }
   const size_t HH = (size_t)H * H;
-  OP_CREATE_TRY(dev_alloc(h, &h->any_lo_dev, OP_FAM_COUNT + 1));
-  OP_CREATE_HIP(hipMemset(h->any_lo_dev, 0, (OP_FAM_COUNT + 1) * sizeof(int)));
+  OP_CREATE_TRY(dev_alloc(h, &h->any_lo_dev, OP_FAM_COUNT + 3));  // + the fp16-fit flags of the "f16 + fp8" packs (note_f16_fit)
+  OP_CREATE_HIP(hipMemset(h->any_lo_dev, 0, (OP_FAM_COUNT + 3) * sizeof(int)));
+  OP_CREATE_TRY(dev_alloc(h, &h->f16_fit_dev, 2));
+  OP_CREATE_HIP(hipMemset(h->f16_fit_dev, 0, 2 * sizeof(float)));
   // panel path: opt-in (OP_FLAG_PANEL_F8) -- at the depth of the published models (19-25 layers) the format's error
   // reaches 0.45-1.0e-3 on logits, the (hi, lo) bf16 sets stay at 0.2-0.5e-3 (scripts/f8_depth_check.py)
   h->f8_packs = ((h->row_path && (H / 32) % 4 == 0) || (h->panel_path && (cfg->flags & OP_FLAG_PANEL_F8))) && !(cfg->flags & OP_FLAG_NO_F8);
@@ -1169,7 +1172,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       auto pack8 = [&](int n_tiles, int mode, int tile0) {
         const size_t total = (size_t)n_tiles * 256 * K;
         hipLaunchKernelGGL(pack_panel_f8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, f32, n_tiles, K, mode, H, I,
-                           dst_p16 + (size_t)tile0 * 256 * K, dst_p8 + (size_t)tile0 * 256 * K / 2, lo_off, zero_lo, not_f16);
+                           dst_p16 + (size_t)tile0 * 256 * K, dst_p8 + (size_t)tile0 * 256 * K / 2, lo_off, zero_lo, not_f16, h->f16_fit_dev);
       };
       if (pk_mode == RE_QKV) {
         pack8(2 * H / 256, PE_QK, 0);
@@ -1179,6 +1182,8 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       } else {
         pack8(H / 256, PE_RESIDUAL, 0);
       }
+      hipLaunchKernelGGL(weight_energy_kernel, dim3(256), dim3(256), 0, 0, f32, count, h->f16_fit_dev);
+      hipLaunchKernelGGL(f16_fit_close_tensor_kernel, dim3(1), dim3(1), 0, 0, not_f16, h->f16_fit_dev);
     }
     if (pk_mode == RE_QKV) {
       pack(2 * H / 256, PE_QK, dst_pk);
@@ -1202,9 +1207,11 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     if (dst_f8a) {  // "f16 + fp8" kernel set; raises the not-fp16 flag (any_lo_dev[OP_FAM_COUNT]) for a weight it cannot hold exactly
       int* not_f16 = h->any_lo_dev + OP_FAM_COUNT;
       if (pk_mode == 100 || pk_mode == 101)
-        hipLaunchKernelGGL(pack_kstream_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_f8a, dst_f8b, zero_lo, not_f16);
+        hipLaunchKernelGGL(pack_kstream_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_f8a, dst_f8b, zero_lo, not_f16, h->f16_fit_dev);
       else
-        hipLaunchKernelGGL(pack_rowgemm_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_f8a, zero_lo, not_f16);
+        hipLaunchKernelGGL(pack_rowgemm_f8_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_f8a, zero_lo, not_f16, h->f16_fit_dev);
+      hipLaunchKernelGGL(weight_energy_kernel, dim3(256), dim3(256), 0, 0, f32, count, h->f16_fit_dev);
+      hipLaunchKernelGGL(f16_fit_close_tensor_kernel, dim3(1), dim3(1), 0, 0, not_f16, h->f16_fit_dev);
     }
     if (dst_p32)  // the 32x32x16 whole-layer kernel's order (hi plane; that kernel runs only when the lo planes are zero)
       hipLaunchKernelGGL(pack_layer32_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, p32_mode, p32_kmajor, H, I,
@@ -1227,7 +1234,9 @@ namespace {
 // exactly those terms -- or kernel set 0 with the unused lo operands cleared.
 int resolve_policy(op_handle* h) {
   if (h->resolved) return OP_OK;
-  int any_lo[OP_FAM_COUNT + 1] = {0};  // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value
+  // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value; [+ 2]: some weight TENSOR sits on fp16's subnormal grid
+  // (note_f16_fit in opk_common.hip.h): the "f16 + fp8" sets cannot represent it
+  int any_lo[OP_FAM_COUNT + 3] = {0};
   OP_HIP(h, hipSetDevice(h->cfg.device_id));
   OP_HIP(h, hipMemcpy(any_lo, h->any_lo_dev, sizeof(any_lo), hipMemcpyDeviceToHost));
   Policy e = h->req;
@@ -1247,7 +1256,8 @@ int resolve_policy(op_handle* h) {
       }
     // bf16-valued weights that are also exact fp16 values, on the whole-layer kernel's shapes: the "f16 + fp8" kernel
     // set evaluates the same terms at 1.5 instead of 2 MFMA units per product (op_internal.h)
-    const bool f8_ok = !h->emulate && h->f8_packs && !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32));
+    const bool f8_ok = !h->emulate && h->f8_packs && !any_lo[OP_FAM_COUNT + 2] &&
+                       !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32));
     if (f8_ok && h->pi == opl::PI_BF16_WEIGHTS && !any_lo[OP_FAM_COUNT]) h->pi = opl::PI_F16_F8;
     // every term requested and carried (fp32-valued weights): the same format with the weights' lo part as a third
     // plane -- one kernel per layer at 2 MFMA units per product instead of two kernels at 3

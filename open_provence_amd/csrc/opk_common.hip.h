@@ -167,8 +167,17 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 
 constexpr int F8_LO_SHIFT = 12;                   // lo planes are stored x 2^12
-constexpr int F8_SCALE_LO = 127 - F8_LO_SHIFT;    // e8m0 block scale 2^-12 of the lo operand
-constexpr int F8_SCALE_ONE = 127;                 // e8m0 2^0 (weights)
+constexpr int F8_SCALE_LO = 127 - F8_LO_SHIFT;    // e8m0 block scale 2^-12 of an activation's lo plane
+constexpr int F8_SCALE_ONE = 127;                 // e8m0 2^0 (the e4m3 copy of an activation)
+// The e4m3 planes of a WEIGHT are stored x 2^6 (its lo plane x 2^18): e4m3's normal range is [2^-6, 448], and the
+// weights of a trained checkpoint sit around 0.02 -- unshifted, half of them would fall on e4m3's subnormal grid
+// (step 2^-9) and weights below 2^-10 would vanish from the lo product altogether.  Shifted, everything in
+// [2^-12, 7] keeps its 3 mantissa bits (a larger weight saturates in the correction term only).  On reference-initialised
+// weights the format's error drops 2.4x (scripts/precision_emulate.py: f16+2f8 4.3e-6 -> 1.8e-6, (hi, lo) bf16 0.9e-6);
+// on O(1) weights nothing changes.
+constexpr int F8_W_SHIFT = 6;
+constexpr int F8_SCALE_W = 127 - F8_W_SHIFT;                     // e4m3(w x 2^6)
+constexpr int F8_SCALE_W_LO = 127 - F8_LO_SHIFT - F8_W_SHIFT;    // e4m3(lo(w) x 2^18)
 
 __device__ __forceinline__ void set_saturating_conversions() {
   asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // MODE.FP16_OVFL: f16 / fp8 conversions clamp to max normal
@@ -182,11 +191,17 @@ __device__ __forceinline__ i32x8 f8_frag(bf16x8 half0, bf16x8 half1) {
   const uint4 a = __builtin_bit_cast(uint4, half0), b = __builtin_bit_cast(uint4, half1);
   return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
 }
-// D += X8 * Y8 (e4m3 x e4m3, K = 128); LO_IS_Y: which operand is the 2^12-scaled lo plane (the other is a weight)
+// D += X8 * Y8 (e4m3 x e4m3, K = 128): lo(activation) x e4m3(weight); LO_IS_Y: which operand is the activation's lo plane
 template <bool LO_IS_Y>
 __device__ __forceinline__ f32x4 mfma8(i32x8 x, i32x8 y, f32x4 c) {
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, c, 0, 0, 0, LO_IS_Y ? F8_SCALE_ONE : F8_SCALE_LO, 0,
-                                                          LO_IS_Y ? F8_SCALE_LO : F8_SCALE_ONE);
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, c, 0, 0, 0, LO_IS_Y ? F8_SCALE_W : F8_SCALE_LO, 0,
+                                                          LO_IS_Y ? F8_SCALE_LO : F8_SCALE_W);
+}
+// ... e4m3(activation) x lo(weight); LO_IS_Y: which operand is the WEIGHT's lo plane
+template <bool LO_IS_Y>
+__device__ __forceinline__ f32x4 mfma8w(i32x8 x, i32x8 y, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, c, 0, 0, 0, LO_IS_Y ? F8_SCALE_ONE : F8_SCALE_W_LO, 0,
+                                                          LO_IS_Y ? F8_SCALE_W_LO : F8_SCALE_ONE);
 }
 
 // two fp32 -> one dword of two fp16 (RNE): v_cvt_pk_f16_f32
@@ -240,6 +255,22 @@ __device__ __forceinline__ unsigned char f2e4m3(float v) {
   return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
 }
 __device__ __forceinline__ u16 f2h(float v) { return __builtin_bit_cast(u16, (_Float16)v); }
+
+// How well a weight fits the fp16 plane of the "f16 + fp8" sets.  flags[0]: a weight of magnitude >= 2^-14 is not an
+// fp16 value (kernel set 3 needs every weight exact; set 4 carries the difference in its lo plane).  fit[0]: sum of the
+// SQUARED differences of the weights below 2^-14 that miss fp16's subnormal grid (spacing 2^-24): neither plane can hold
+// that difference (it is below e4m3's reach even shifted), so a tensor made of such weights -- e.g. an output projection
+// scaled down by 2^-10 -- would be multiplied at fp16 single-pass accuracy (measured 2e-3 .. 4e-3 on logits), while the
+// handful of tiny weights of a normally scaled tensor are harmless.  f16_fit_close_tensor_kernel (opk_small.hip.h)
+// compares fit[0] with the tensor's energy fit[1] (weight_energy_kernel) and raises flags[2] when the lost part exceeds
+// 2^-36 of it (the format's own relative error is ~2^-16, i.e. 2^-32 in energy); the library then keeps the (hi, lo)
+// bf16 sets for the model.
+__device__ __forceinline__ void note_f16_fit(float v, _Float16 hv, int* __restrict__ flags, float* __restrict__ fit) {
+  const float d = v - (float)hv;
+  if (d == 0.f) return;
+  if (fabsf(v) >= 6.103515625e-05f) flags[0] = 1;
+  else atomicAdd(fit, d * d * 1.1529215e18f);  // x 2^60: d^2 <= 2^-50 would underflow the sum's precision otherwise
+}
 
 // ---- hand-placed LDS fragment reads -------------------------------------------------------------------------
 // While a global_load_lds DMA is in flight hipcc (ROCm 7.2) cannot count lgkmcnt: every wait it inserts in front of

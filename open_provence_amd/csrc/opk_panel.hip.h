@@ -72,7 +72,7 @@ __global__ void pack_panel_kernel(const float* __restrict__ src, int n_tiles, in
 // round_bf16: the requested policy has no hi x lo(weight) term -- the weight IS its bf16 rounding.
 __global__ void pack_panel_f8_kernel(const float* __restrict__ src, int n_tiles, int K, int mode, int H, int I,
                                      u16* __restrict__ dst16, u16* __restrict__ dst8, size_t lo_off_bytes, int round_bf16,
-                                     int* __restrict__ not_f16) {
+                                     int* __restrict__ not_f16, float* __restrict__ fit) {
   set_saturating_conversions();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_tiles * 256 * K;
@@ -89,12 +89,12 @@ __global__ void pack_panel_f8_kernel(const float* __restrict__ src, int n_tiles,
   float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
   if (round_bf16) v = bf2f(f2bf(v));
   const _Float16 hv = (_Float16)v;
-  if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;
+  note_f16_fit(v, hv, not_f16, fit);
   dst16[(((size_t)tile * KS + ks) * 16 + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
   const int s8 = ks >> 2, hh = (ks & 3) >> 1, pbyte = 8 * (ks & 1) + e;
   unsigned char* d8 = reinterpret_cast<unsigned char*>(dst8 + ((((size_t)tile * NS8 + s8) * 16 + nf) * 2 + hh) * 512);
-  d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v);
-  d8[lo_off_bytes + (g * 16 + i) * 16 + pbyte] = f2e4m3((v - (float)hv) * (float)(1 << F8_LO_SHIFT));
+  d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v * (float)(1 << F8_W_SHIFT));
+  d8[lo_off_bytes + (g * 16 + i) * 16 + pbyte] = f2e4m3((v - (float)hv) * (float)(1 << (F8_LO_SHIFT + F8_W_SHIFT)));
 }
 #endif
 
@@ -534,7 +534,7 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
           const i32x8 w8f = f8_frag(w0, w1);
 #pragma unroll
           for (int mf = 0; mf < 2; ++mf)
-            acc[nf][mf] = SWAPPED ? mfma8<false>(w8f, h8_prev[mf], acc[nf][mf]) : mfma8<true>(h8_prev[mf], w8f, acc[nf][mf]);
+            acc[nf][mf] = SWAPPED ? mfma8w<false>(w8f, h8_prev[mf], acc[nf][mf]) : mfma8w<true>(h8_prev[mf], w8f, acc[nf][mf]);
         }
       }
     });

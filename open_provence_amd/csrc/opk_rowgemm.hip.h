@@ -147,7 +147,7 @@ __global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, i
 // bf16 sets; every bf16 value in [2^-14, 65504] is an fp16 value).  Smaller weights land on the fp16 subnormal grid:
 // absolute error <= 2^-25 per weight, ~1e-6 on a logit.
 __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows, int K, int mode, int H, int I,
-                                       u16* __restrict__ dst, int round_bf16, int* __restrict__ not_f16) {
+                                       u16* __restrict__ dst, int round_bf16, int* __restrict__ not_f16, float* __restrict__ fit) {
   set_saturating_conversions();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_rows * K;
@@ -164,12 +164,12 @@ __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows
   float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
   if (round_bf16) v = bf2f(f2bf(v));  // a policy without the hi x lo(weight) term: the weight IS its bf16 rounding
   const _Float16 hv = (_Float16)v;
-  if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;  // (below 2^-14: fp16 subnormal grid, |error| <= 2^-25)
+  note_f16_fit(v, hv, not_f16, fit);
   dst[((size_t)c * CP + ks * 2 + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
   const int s8 = ks >> 2, hh = (ks & 3) >> 1, pbyte = 8 * (ks & 1) + e;
   unsigned char* d8 = reinterpret_cast<unsigned char*>(dst + ((size_t)c * CP + 2 * KS + (nf * NS8 + s8) * 2 + hh) * 512);
-  d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v);
-  d8[(size_t)4 * NS8 * 1024 + (g * 16 + i) * 16 + pbyte] = f2e4m3((v - (float)hv) * (float)(1 << F8_LO_SHIFT));
+  d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v * (float)(1 << F8_W_SHIFT));
+  d8[(size_t)4 * NS8 * 1024 + (g * 16 + i) * 16 + pbyte] = f2e4m3((v - (float)hv) * (float)(1 << (F8_LO_SHIFT + F8_W_SHIFT)));
 }
 
 // k-streamed weights of the "f16 + fp8" kernel sets.  dst8 != nullptr (attention output projection, K = hidden): fp16
@@ -180,7 +180,7 @@ __global__ void pack_rowgemm_f8_kernel(const float* __restrict__ src, int n_rows
 // anyway -- and the MFMA takes subnormal operands at full rate (default denormal mode); it multiplies the fp16 hi
 // fragment of h the main product uses.  `permute` as pack_kstream_kernel.
 __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst16,
-                                       u16* __restrict__ dst8, int round_bf16, int* __restrict__ not_f16) {
+                                       u16* __restrict__ dst8, int round_bf16, int* __restrict__ not_f16, float* __restrict__ fit) {
   set_saturating_conversions();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * K) return;
@@ -195,14 +195,14 @@ __global__ void pack_kstream_f8_kernel(const float* __restrict__ src, int N, int
   float v = src[(size_t)row * K + ks * 32 + g * 8 + e];
   if (round_bf16) v = bf2f(f2bf(v));
   const _Float16 hv = (_Float16)v;
-  if ((float)hv != v && fabsf(v) >= 6.103515625e-05f) *not_f16 = 1;  // (below 2^-14: fp16 subnormal grid, |error| <= 2^-25)
+  note_f16_fit(v, hv, not_f16, fit);
   const float wlo = v - (float)hv;
   if (dst8 != nullptr) {
     dst16[((size_t)ks * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
     const int s8 = ks >> 2, hh = (ks & 3) >> 1, pbyte = 8 * (ks & 1) + e;
     unsigned char* d8 = reinterpret_cast<unsigned char*>(dst8 + (((size_t)s8 * NF + nf) * 2 + hh) * 512);
-    d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v);
-    d8[(size_t)N * K + (g * 16 + i) * 16 + pbyte] = f2e4m3(wlo * (float)(1 << F8_LO_SHIFT));
+    d8[(g * 16 + i) * 16 + pbyte] = f2e4m3(v * (float)(1 << F8_W_SHIFT));
+    d8[(size_t)N * K + (g * 16 + i) * 16 + pbyte] = f2e4m3(wlo * (float)(1 << (F8_LO_SHIFT + F8_W_SHIFT)));
   } else {
     dst16[((size_t)ks * 2 * NF + nf) * 512 + g * 128 + i * 8 + e] = __builtin_bit_cast(u16, hv);
     dst16[((size_t)(ks * 2 + 1) * NF + nf) * 512 + g * 128 + i * 8 + e] = f2h(wlo);
@@ -360,7 +360,7 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
       if constexpr (C::is_wlo(cs)) {  // e4m3(activation) x lo(weight): the scaled operand is the weight
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
-          acc[nf][mf] = SWAPPED ? mfma8<false>(w8, a_h8[mf][s8], acc[nf][mf]) : mfma8<true>(a_h8[mf][s8], w8, acc[nf][mf]);
+          acc[nf][mf] = SWAPPED ? mfma8w<false>(w8, a_h8[mf][s8], acc[nf][mf]) : mfma8w<true>(a_h8[mf][s8], w8, acc[nf][mf]);
       } else {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
               constexpr int nf8 = (NF1 / 2) * (j & 1) + (st - NF1 - NF1 / 2);
               const i32x8 w8 = f8_frag(w0, w1);
 #pragma unroll
-              for (int mf = 0; mf < MF; ++mf) acc1[nf8][mf] = mfma8<false>(w8, a_h8[mf][j >> 1], acc1[nf8][mf]);
+              for (int mf = 0; mf < MF; ++mf) acc1[nf8][mf] = mfma8w<false>(w8, a_h8[mf][j >> 1], acc1[nf8][mf]);
             }
             return;
           }
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         constexpr int nf = decltype(nf_tag)::value, s8 = decltype(s8_tag)::value;
         const i32x8 w8 = f8_frag(w0, w1);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = mfma8<false>(w8, a_h8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = mfma8w<false>(w8, a_h8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
       };
       auto slab_one = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1) {
         constexpr int nf = decltype(nf_tag)::value;

@@ -531,6 +531,21 @@ __device__ inline float np_pairwise_sum_f32(const float* a, int n) {
   return ret;
 }
 
+// "f16 + fp8" packs, per weight tensor (note_f16_fit in opk_common.hip.h): the tensor's energy (x 2^60, as the lost part),
+// and the verdict once its pack kernels have run
+__global__ __launch_bounds__(256) void weight_energy_kernel(const float* __restrict__ w, size_t n, float* __restrict__ fit) {
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += w[i] * w[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(fit + 1, acc * 1.1529215e18f);
+}
+__global__ void f16_fit_close_tensor_kernel(int* __restrict__ flags, float* __restrict__ fit) {
+  if (fit[0] > fit[1] * 1.4551915e-11f) flags[2] = 1;  // 2^-36
+  fit[0] = 0.f;
+  fit[1] = 0.f;
+}
+
 // one wave: shader cycles and 100 MHz ticks over a spin of `ticks` ticks (op_debug_clock_probe)
 __global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long* __restrict__ out) {
   const unsigned long long c0 = __builtin_readcyclecounter();

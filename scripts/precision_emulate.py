@@ -73,12 +73,15 @@ def make_mm(scheme: str, families: set[str] | None = None):
             bh, bl = split_pair(b, torch.bfloat16)
             al, bl = rne(al, torch.bfloat16), rne(bl, torch.bfloat16)
             return ah @ bh + al @ bh + ah @ bl
-        if sch in ("f16+f8", "f16+2f8", "f16+f8s"):
+        if sch.split(":")[0] in ("f16+f8", "f16+2f8", "f16+f8s"):
+            # optional ":LS/WS/AS": shift of the lo planes, of the e4m3 weight plane, of the e4m3 activation plane (2^x)
+            base, _, opts = sch.partition(":")
+            ls, ws, as_ = (int(v) for v in opts.split("/")) if opts else (LO_SHIFT, 0, 0)
             ah, al = split_pair(a, torch.float16)
             bh, bl = split_pair(b, torch.float16)
-            out = ah @ bh + f8(al, LO_SHIFT) @ f8(bh)
-            if sch == "f16+2f8":
-                out = out + f8(ah) @ f8(bl, LO_SHIFT)
+            out = ah @ bh + f8(al, ls) @ f8(bh, ws)
+            if base == "f16+2f8":
+                out = out + f8(ah, as_) @ f8(bl, ls + ws)
             return out
         if sch == "bf16+f8":
             ah, al = split_pair(a, torch.bfloat16)

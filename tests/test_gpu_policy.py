@@ -230,3 +230,37 @@ def test_panel_path_f16_f8_kernel_sets(fixture, weights):
         assert np.abs(outs[flags][1] - ref.ranking_logits.numpy()).max() < 1e-3, flags
     assert np.abs(outs[0][0] - outs[PANEL_F8][0]).max() < 5e-4
     assert np.abs(outs[0][1] - outs[PANEL_F8][1]).max() < 5e-4
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp32"])
+def test_tiny_scaled_weight_tensor_keeps_the_bf16_kernel_sets(weights):
+    """The fp16 plane of the "f16 + fp8" sets has fp16's exponent range: a weight TENSOR scaled down into fp16's subnormal
+    range (here two MLP output projections x 2^-10, their Wi x 32 so that the layer keeps its scale) cannot be
+    represented -- run on that format the logits are off by 2e-3 .. 4e-3.  The pack kernels count such weights per tensor
+    (note_f16_fit) and the library then keeps the (hi, lo) bf16 sets, whose exponent range is fp32's: within 1e-3."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import pad_rows
+    from oracle.modernbert_oracle import oracle_forward
+
+    arrays, meta = load_golden("g1_xsmall")
+    dims = dims_from_meta(meta)
+    rows = rows_from_fixture(arrays)
+    ids, mask = pad_rows(rows)
+    m = mask.bool().numpy()
+    for scale, expected in ((1.0, {"bf16": "f16-f8", "fp32": "f16-f8-w"}), (32.0, {"bf16": "bf16-weights", "fp32": "bf16x3"})):
+        state = state_from_fixture(arrays, meta)
+        for layer in (1, 4):
+            state[f"ranking_model.model.layers.{layer}.mlp.Wi.weight"] = state[f"ranking_model.model.layers.{layer}.mlp.Wi.weight"] * scale
+            state[f"ranking_model.model.layers.{layer}.mlp.Wo.weight"] = state[f"ranking_model.model.layers.{layer}.mlp.Wo.weight"] / (scale * scale)
+        if weights == "bf16":
+            state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v for k, v in state.items()}
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+        enc.load_state_dict(state)
+        assert enc.effective_policy()["kernel_set"] == expected[weights], scale
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        enc.close()
+        ref = oracle_forward(state, dims, ids, mask)
+        assert np.abs(prune.cpu().numpy() - ref.pruning_logits.numpy()[m]).max() < 1e-3, scale
+        assert np.abs(rank.cpu().numpy() - ref.ranking_logits.numpy()).max() < 1e-3, scale
