@@ -182,6 +182,12 @@ constexpr int F8_SCALE_W_LO = 127 - F8_LO_SHIFT - F8_W_SHIFT;    // e4m3(lo(w) x
 __device__ __forceinline__ void set_saturating_conversions() {
   asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // MODE.FP16_OVFL: f16 / fp8 conversions clamp to max normal
 }
+// ... and back to IEEE overflow, for a phase that converts to fp16 only: an activation beyond fp16's range (|h| >= 65520)
+// then becomes Inf and the forward's outputs NaN -- loud -- instead of a silently clamped operand (the e4m3 lo planes are
+// what needs the clamp: there an overflow would be NaN for a harmless loss of the correction term)
+__device__ __forceinline__ void set_overflowing_conversions() {
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0");
+}
 
 // the 16-bit product of this kernel set: operands carry fp16 bits in the registers the bf16 kernels use
 __device__ __forceinline__ f32x4 mfma16h(bf16x8 x, bf16x8 y, f32x4 c) {

@@ -1405,6 +1405,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // stage 0 has landed
       OPK_STAMP(2);
+      if constexpr (F8 != 0) set_overflowing_conversions();  // the MLP loop converts h to fp16 only: out of range = Inf, not 65504
       if constexpr (WLO) {
         // ---- fp32-valued weights: half-iterations.  Half hb of iteration t streams stage hb = [chunk 2t + hb | half hb
         // of slab t-1]: the chunk's KS fp16 steps + 2 x KS/2 e4m3 steps (lo(LN(x)) x Wi, LN(x) x lo(Wi)), then NF1 / 2
@@ -1487,6 +1488,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       }
       __builtin_amdgcn_s_barrier();  // every wave is done with the ring: the chunk loop may reuse stage 0
       OPK_STAMP(3);
+      if constexpr (F8 != 0) set_saturating_conversions();
       if constexpr (EPI == RE_NONE) {
         if (FIN_HEAD && p.fin_ln != nullptr) final_head();
         else residual_ln(no_, yes_, no_, nullptr);  // acc1 = x + o Wo^T + h Wo^T: the layer's output

@@ -1252,6 +1252,14 @@ class OpenProvenceModel:
         scores = torch.sigmoid(rank_scores.to(torch.float32)).tolist()  # = _ranking_score row by row (ref :2913-2916)
         for i, job in enumerate(chunk):
             reduced = isinstance(keeps[i], list)  # per-fragment means from the device (see _launch_rows)
+            if scores[i] != scores[i] or (reduced and any(m != m for m in keeps[i])):
+                # The fp16 + e4m3 kernel sets turn an MLP activation beyond fp16's range into Inf on purpose
+                # (csrc/opk_common.hip.h: set_overflowing_conversions) so that it ends up here and not in a pruned text.
+                raise RuntimeError(
+                    "the forward returned NaN for a (query, context) block: either the checkpoint holds non-finite weights or an "
+                    "activation left the fp16 range of the default kernel set -- rerun with OPEN_PROVENCE_NO_F8=1 "
+                    "(the (hi, lo) bf16 kernels have fp32's range)"
+                )
             states[(job["query_idx"], job["context_idx"])].raw_blocks.append(
                 (
                     job["block_idx"],

@@ -264,3 +264,44 @@ def test_tiny_scaled_weight_tensor_keeps_the_bf16_kernel_sets(weights):
         ref = oracle_forward(state, dims, ids, mask)
         assert np.abs(prune.cpu().numpy() - ref.pruning_logits.numpy()[m]).max() < 1e-3, scale
         assert np.abs(rank.cpu().numpy() - ref.ranking_logits.numpy()).max() < 1e-3, scale
+
+
+def test_activation_beyond_fp16_range_is_loud_on_the_f8_sets_and_fine_on_the_bf16_sets():
+    """MLP activations h = GeGLU(...) of 1e5 .. 1e6 (Wi x 512 in two layers; their Wo x 2^-18, rounded to multiples of
+    2^-24 so that fp16's subnormal grid holds them exactly and the load-time guard of the previous test stays quiet).
+    The fp16 operand plane cannot hold such an h: the whole-layer kernel converts it with IEEE overflow (Inf), so the
+    outputs come back non-finite -- process() raises on that -- instead of being computed from a quietly clamped operand;
+    the (hi, lo) bf16 sets (OP_FLAG_NO_F8) have fp32's range and match the oracle."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import pad_rows
+    from oracle.modernbert_oracle import oracle_forward
+
+    arrays, meta = load_golden("g1_xsmall")
+    dims = dims_from_meta(meta)
+    rows = rows_from_fixture(arrays)
+    state = state_from_fixture(arrays, meta)
+    scale = 512.0
+    for layer in (1, 4):
+        wi, wo = f"ranking_model.model.layers.{layer}.mlp.Wi.weight", f"ranking_model.model.layers.{layer}.mlp.Wo.weight"
+        state[wi] = state[wi] * scale
+        # x 2^-18, on fp16's subnormal grid exactly (multiples of 2^-24): representable, so the format is selected
+        state[wo] = torch.round(state[wo] / (scale * scale) * 2.0**24) / 2.0**24
+    ids, mask = pad_rows(rows)
+    ref = oracle_forward(state, dims, ids, mask)
+    m = mask.bool().numpy()
+    outs = {}
+    for flags in (0, NO_F8):
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
+        enc.load_state_dict(state)
+        outs[flags] = enc.effective_policy()["kernel_set"]
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        p, r = prune.cpu().numpy(), rank.cpu().numpy()
+        enc.close()
+        if flags == 0:
+            assert outs[flags] == "f16-f8-w"
+            assert not np.isfinite(p).all() or not np.isfinite(r).all()  # Inf / NaN, not a quietly clamped operand
+        else:
+            assert np.abs(p - ref.pruning_logits.numpy()[m]).max() < 1e-3 and np.abs(r - ref.ranking_logits.numpy()).max() < 1e-3
+    assert outs[NO_F8] == "bf16x3"
