@@ -85,7 +85,7 @@ def physical_cores() -> int:
 def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
     """The CPU oracle (torch fp32, SDPA attention = what the reference executes on a CPU device) timed on this
     box's host cores on a bounded sample of the same workload: batch 32 (the reference's default batch_size) x
-    seq_len at the best thread count, plus one pass at batch 256 and a single-thread figure."""
+    seq_len at the best thread count (chosen on that batch), plus one pass at batch 256 and a single-thread figure."""
 
     from oracle.modernbert_oracle import oracle_forward
     from open_provence_amd.synthetic import pad_rows
@@ -110,9 +110,9 @@ def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
         # thread count that serves the CPU best on this box (oversubscription hurts the small GEMMs)
         best_threads, best_rate = default_threads, 0.0
         candidates = sorted({t for t in (8, 16, 32, 64, n_phys, default_threads) if 0 < t <= max(default_threads, n_phys)})
-        for threads in candidates:
+        for threads in candidates:  # probed on the batch that is then timed (one pass of batch 32 per candidate)
             torch.set_num_threads(threads)
-            rate, _ = timed(8, 0.0, 1)
+            rate, _ = timed(32, 0.0, 1)
             if rate > best_rate:
                 best_threads, best_rate = threads, rate
         torch.set_num_threads(best_threads)
@@ -131,7 +131,7 @@ def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
         "batch_256_pairs_per_s": rate256,
         "single_thread_pairs_per_s": rate1,
         "sample": f"oracle/modernbert_oracle.py (torch-CPU fp32, SDPA): {iters32} x batch 32 x seq_len {seq_len} on {best_threads} threads "
-        f"(best of {candidates} on a batch-8 probe), one pass of batch 256 on the same threads, one pass of batch 2 on 1 thread; "
+        f"(best of {candidates}, one pass of batch 32 each), one pass of batch 256 on the same threads, one pass of batch 2 on 1 thread; "
         f"{n_phys} physical cores / {os.cpu_count()} logical CPUs",
     }
 
