@@ -287,6 +287,15 @@ int main() {
       x[3] += (double)(s[14] - s[3]);
       ++nx;
     }
+#ifdef OPK_SEG_TIMING
+    {
+      double sg[3] = {0, 0, 0};
+      for (int b = 0; b < blocks; ++b)
+        for (int i = 0; i < 3; ++i) sg[i] += (double)t[(size_t)b * 16 + 11 + i];
+      printf("  MLP loop segments per block: chunk 2t %.0f | chunk 2t+1 + GeGLU %.0f | slab + GeGLU %.0f\n", sg[0] / blocks, sg[1] / blocks, sg[2] / blocks);
+    }
+    nx = 0;
+#endif
     if (nx)
       printf("  LayerNorm 1: row fragment 0 done at +%.0f | LayerNorm 2: fragment 0 +%.0f, arithmetic +%.0f, DMA/RoPE wait +%.0f (then the row stores)\n",
              x[0] / nx, x[1] / nx, x[2] / nx, x[3] / nx);

@@ -467,8 +467,16 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       ln_fill3 = p.fin_pw[KS * 32 + ln_i];
     }
   }
+#ifdef OPK_SEG_TIMING
+#define OPK_SEG_DUMP() for (int i_ = 0; i_ < 3; ++i_) p.dbg[(size_t)blockIdx.x * 16 + 11 + i_] = opk_seg[i_];
+#else
+#define OPK_SEG_DUMP()
+#endif
 #ifdef OPK_TIMING
   unsigned long long opk_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, opk_wait = 0, opk_wait2 = 0, opk_wait1 = 0, opk_x[4] = {0, 0, 0, 0};
+#ifdef OPK_SEG_TIMING
+  unsigned long long opk_seg[3] = {0, 0, 0}, opk_seg_t = 0;
+#endif
 #define OPK_STAMP(i) opk_ts[i] = __builtin_readcyclecounter()
 #define OPK_DUMP()                                                                              \
   do {                                                                                          \
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       p.dbg[(size_t)blockIdx.x * 16 + 9] = opk_wait2;                                           \
       p.dbg[(size_t)blockIdx.x * 16 + 10] = opk_wait1;                                          \
       for (int i_ = 0; i_ < 4; ++i_) p.dbg[(size_t)blockIdx.x * 16 + 11 + i_] = opk_x[i_];     \
+      OPK_SEG_DUMP()                                                                            \
       p.dbg[(size_t)blockIdx.x * 16 + 15] = wall_clock64() - opk_rt0;                           \
     }                                                                                           \
   } while (0)
@@ -1348,6 +1357,13 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           f32x4 nb[2][MF];
           frag_stream2<2 * CS + NS, DEPTH8, Off8>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
             constexpr int s = decltype(step_tag)::value;
+#ifdef OPK_SEG_TIMING  // cycles of the three segments of an iteration (chunk 2t | chunk 2t+1 + GeGLU | slab + GeGLU)
+            if constexpr (s == 0 || s == CS || s == 2 * CS) {
+              const unsigned long long now = __builtin_readcyclecounter();
+              if constexpr (s > 0) opk_seg[s == CS ? 0 : 1] += now - opk_seg_t;
+              opk_seg_t = now;
+            }
+#endif
 #ifndef OPK_ABL_NO_DMA
             if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
 #endif
@@ -1369,6 +1385,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
               interleave_n(std::integral_constant<int, 4 * MF>{}, std::integral_constant<int, 3>{});
             }
           });
+#ifdef OPK_SEG_TIMING
+          opk_seg[2] += __builtin_readcyclecounter() - opk_seg_t;
+#endif
           if constexpr (!SLAB) static_for<KS>([&](auto sl) { geglu_slice(nb, g_prev, sl, pack_h); });  // first pair: no slab to ride on
         } else
         frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
