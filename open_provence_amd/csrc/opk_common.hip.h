@@ -401,6 +401,39 @@ __device__ __forceinline__ void frag_stream2(uint32_t lds_addr, Body&& body) {
   });
 }
 
+// The same stream over a two-stage ring WITHOUT a drain at the stage boundary: the SETS register sets stay in flight
+// across it -- the reads for the first SETS steps of the NEXT unit (other stage, offsets OffNext) are issued behind the
+// last SETS steps of this one, and the next unit starts on operands that are already there (PRIME = false).  What the
+// caller's body must do for that to be legal (the whole-layer kernel's MLP loop does): a barrier at its step 0 before
+// it requests the DMA into the other stage (every wave has then finished reading the unit that lived there), and
+// `s_waitcnt vmcnt(0)` + a second barrier at its step NSTEPS - SETS (the first read of the next unit follows that step:
+// every wave's share of it has landed).  NSTEPS % SETS == 0 keeps the set of step 0 the same in every unit.
+template <int NSTEPS, int SETS, class Off, class OffNext, bool PRIME, bool CONTINUE, class Body>
+__device__ __forceinline__ void frag_stream2_ring(uint32_t lds_cur, uint32_t lds_next, bf16x8 (&w)[SETS][2], Body&& body) {
+  static_assert(NSTEPS % SETS == 0 && NSTEPS >= SETS, "the register sets line up across units");
+  if constexpr (PRIME)
+    static_for<SETS>([&](auto t) {
+      constexpr int s = decltype(t)::value;
+      w[s][0] = lds_read_frag<Off::at(s, 0)>(lds_cur);
+      w[s][1] = lds_read_frag<Off::at(s, 1)>(lds_cur);
+    });
+  static_for<NSTEPS>([&](auto t) {
+    constexpr int s = decltype(t)::value;
+    constexpr int set = s % SETS;
+    constexpr int ahead = CONTINUE ? SETS - 1 : ((NSTEPS - 1 - s) < SETS - 1 ? (NSTEPS - 1 - s) : SETS - 1);
+    lds_wait2<2 * ahead>(w[set][0], w[set][1]);
+    body(t, w[set][0], w[set][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (s + SETS < NSTEPS) {
+      w[set][0] = lds_read_frag<Off::at(s + SETS, 0)>(lds_cur);
+      w[set][1] = lds_read_frag<Off::at(s + SETS, 1)>(lds_cur);
+    } else if constexpr (CONTINUE) {
+      w[set][0] = lds_read_frag<OffNext::at(s + SETS - NSTEPS, 0)>(lds_next);
+      w[set][1] = lds_read_frag<OffNext::at(s + SETS - NSTEPS, 1)>(lds_next);
+    }
+  });
+}
+
 // Stores of tensors that the launch writing them never reads back (q / k / v^T / o / h pieces, the residual stream's
 // write-back) are non-temporal (global_store ... nt).  As ordinary stores they displace the next block's operands from
 // the XCD's L2: in the whole-layer kernel the phase that starts a block (operand fetch + attention-output projection)

@@ -166,12 +166,16 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
 
   auto stage_slab = [&](int ks, int stage) {
     const u16* src = wtile + (size_t)ks * SLAB_SRC;
-#pragma unroll
-    for (int u = 0; u < WAVE_PIECES; ++u) {
-      const int piece = wave + 4 * u;  // stage = [plane][nf] pieces, same order as the source (which has 2 planes)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 512 + lane * 8),
-                                       (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
-    }
+    // stage = [plane][nf] pieces, same order as the source (which has 2 planes).  A wave copies groups of four consecutive
+    // pieces: one pointer / M0 per group, the other three through the DMA's immediate offset, which moves the global and the
+    // LDS address alike (microbench/dma_offset_probe.hip) -- three scalar instructions less per piece
+    static_assert(WAVE_PIECES % 4 == 0, "groups of four pieces");
+    static_for<WAVE_PIECES>([&](auto u_tag) {
+      constexpr int u = decltype(u_tag)::value;
+      const int piece0 = 4 * (wave + 4 * (u / 4));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece0 * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(&sW[stage][piece0 * 512]), 16, (u % 4) * 1024, 0);
+    });
   };
   const u16* a_base = p.a_fp + ((size_t)(m0 >> 4) * nks * 2) * 512 + lane * 8;
   const size_t a_block = (size_t)nks * 2 * 512;

@@ -505,6 +505,19 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   constexpr int WAVE_PIECES = STAGE / (WAVES * 512);
   auto stage_chunk = [&](int chunk, int stage) {
     const u16* src = p.wp + (size_t)chunk * CHUNK_SRC;
+    if constexpr (F8 != 0) {
+      // groups of GS consecutive pieces per wave: one pointer and one M0 per group, the rest through the DMA's immediate
+      // offset (it moves both addresses; the stage mirrors the packed chunk) -- see stage_piece of the MLP loop
+      constexpr int PIECES = STAGE / 512;
+      constexpr int GS = (PIECES / 4) % WAVES == 0 ? 4 : ((PIECES / 2) % WAVES == 0 ? 2 : 1);
+      static_for<WAVE_PIECES>([&](auto u_tag) {
+        constexpr int u = decltype(u_tag)::value;
+        const int piece0 = GS * (wave + WAVES * (u / GS));  // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece0 * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(&sW[stage][piece0 * 512]), 16, (u % GS) * 1024, 0);
+      });
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < WAVE_PIECES; ++u) {
       const int piece = wave + WAVES * u;              // wave-uniform
@@ -1061,12 +1074,35 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         const int piece = wave + WAVES * u;  // wave-uniform
         const u16* src;
         if constexpr (F8 != 0) {  // the chunk's fp16 + e4m3 pieces (not its weight-lo region), then plane 0 (fp16) of the slab
-          // (chunk index of the piece at compile time: CHUNK_PIECES8 is a multiple of WAVES, and a run-time division of
-          // the wave-uniform piece index by 24 is ~30 scalar instructions per DMA)
-          static_assert(CHUNK_PIECES8 % WAVES == 0, "a wave's pieces of one chunk");
-          constexpr int c8 = u >= CHUNK_PIECES8 / WAVES ? 1 : 0;
-          src = u < WI_PIECES / WAVES ? p.wi_pk + (size_t)(2 * tc + c8) * CHUNK_SRC + (piece - c8 * CHUNK_PIECES8) * 512
-                                      : p.wo2_ks + (size_t)ts * (2 * NF1 * 512) + (piece - WI_PIECES) * 512;
+          // A wave copies GROUPS of four consecutive 1 KiB pieces: one base pointer and one M0 per group, the other three
+          // pieces through the instruction's immediate offset -- it moves the global AND the LDS address
+          // (microbench/dma_offset_probe.hip), and the stage mirrors the packed chunk piece for piece.  Per DMA that is
+          // no scalar instruction instead of three (s_add_u32 / s_addc_u32 on the pointer, s_add_i32 on M0): the loop
+          // issued 45 of them per iteration.  The region of a group (chunk 2t, chunk 2t+1, slab) is a compile-time fact
+          // when all waves' groups of that round fall into the same one, else a wave-uniform select.
+          constexpr auto fits = [](int gs) {
+            return CHUNK_PIECES8 % gs == 0 && (UNIT_PIECES - WI_PIECES) % gs == 0 && (UNIT_PIECES / gs) % WAVES == 0;
+          };
+          constexpr int GS = fits(4) ? 4 : (fits(2) ? 2 : 1);  // pieces per group (4 on the hidden-256 kernels)
+          constexpr int j = u / GS, q = u % GS;
+          const int piece0 = GS * (wave + WAVES * j);  // wave-uniform
+          constexpr int lo_piece = GS * (WAVES * j), hi_piece = GS * (WAVES - 1 + WAVES * j) + GS - 1;  // over the waves
+          constexpr auto region = [](int pc) { return pc < CHUNK_PIECES8 ? 0 : (pc < WI_PIECES ? 1 : 2); };
+          // (integer selects on wave-uniform values: a pointer chosen by control flow would put the DMA under a branch,
+          // and the compiler drains a DMA issued under a branch at the join)
+          constexpr int r_lo = region(lo_piece), r_hi = region(hi_piece);
+          const int in_chunk1 = r_lo == r_hi ? (r_lo == 1 ? 1 : 0) : (piece0 >= CHUNK_PIECES8 ? 1 : 0);
+          const size_t off_wi = (size_t)(2 * tc + in_chunk1) * CHUNK_SRC + (size_t)(piece0 - in_chunk1 * CHUNK_PIECES8) * 512;
+          const size_t off_slab = (size_t)ts * (2 * NF1 * 512) + (size_t)(piece0 - WI_PIECES) * 512;
+          const uintptr_t a_wi = reinterpret_cast<uintptr_t>(p.wi_pk) + 2 * off_wi, a_slab = reinterpret_cast<uintptr_t>(p.wo2_ks) + 2 * off_slab;
+          uintptr_t a0;
+          if constexpr (r_hi <= 1) a0 = a_wi;
+          else if constexpr (r_lo == 2) a0 = a_slab;
+          else a0 = piece0 < WI_PIECES ? a_wi : a_slab;
+          const u16* src0 = reinterpret_cast<const u16*>(a0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + lane * 8),
+                                           (__attribute__((address_space(3))) void*)(&sW[stage][piece0 * 512]), 16, q * 1024, 0);
+          return;
         } else if constexpr (u < WI_PIECES / WAVES) {  // [chunk 0..1][ks][frag]: hi pieces of the chunk-major pack
           const int c = piece / (2 * KS), within = piece % (2 * KS);
           src = p.wi_pk + (size_t)(2 * tc + c) * CHUNK_SRC + (within >> 1) * 2048 + (within & 1) * 512;
@@ -1083,16 +1119,24 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         constexpr int u = decltype(u_tag)::value;
         const int cc = c < 2 * n_pairs ? c : 2 * n_pairs - 1;  // clamped: the tail stages carry only a slab half
         const int ts = (c >> 1) > 0 ? (c >> 1) - 1 : 0;
-        const int piece = wave + WAVES * u;  // wave-uniform
-        const u16* src;
-        if (u < CHUNK_PIECES8 / WAVES) {
-          src = p.wi_pk + (size_t)cc * CHUNK_SRC + piece * 512;
-        } else {
-          const int q = piece - CHUNK_PIECES8, plane = q / (NF1 / 2), n = q % (NF1 / 2);
-          src = p.wo2_ks + ((size_t)(ts * 2 + plane) * NF1 + (c & 1) * (NF1 / 2) + n) * 512;
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
-                                         (__attribute__((address_space(3))) void*)(&sW[stage][piece * 512]), 16, 0, 0);
+        // groups of four consecutive pieces per wave, as stage_piece: the chunk (CHUNK_PIECES8 pieces), then the two runs
+        // of NF1 / 2 slab fragments (plane 0, plane 1) -- every run is a multiple of four pieces
+        constexpr auto fits = [](int gs) { return CHUNK_PIECES8 % gs == 0 && (NF1 / 2) % gs == 0 && (UNIT_PIECES / gs) % WAVES == 0; };
+        constexpr int GS = fits(4) ? 4 : (fits(2) ? 2 : 1);
+        constexpr int j = u / GS, q4 = u % GS;
+        const int piece0 = GS * (wave + WAVES * j);  // wave-uniform
+        constexpr int lo_piece = GS * (WAVES * j), hi_piece = GS * (WAVES - 1 + WAVES * j) + GS - 1;
+        constexpr bool all_chunk = hi_piece < CHUNK_PIECES8, all_slab = lo_piece >= CHUNK_PIECES8;
+        const size_t off_chunk = (size_t)cc * CHUNK_SRC + (size_t)piece0 * 512;
+        const int qs = piece0 - CHUNK_PIECES8, plane = qs / (NF1 / 2), n = qs % (NF1 / 2);  // (powers of two: shifts)
+        const size_t off_slab = ((size_t)(ts * 2 + plane) * NF1 + (c & 1) * (NF1 / 2) + n) * 512;
+        const uintptr_t a_chunk = reinterpret_cast<uintptr_t>(p.wi_pk) + 2 * off_chunk, a_slab = reinterpret_cast<uintptr_t>(p.wo2_ks) + 2 * off_slab;
+        uintptr_t a0;
+        if constexpr (all_chunk) a0 = a_chunk;
+        else if constexpr (all_slab) a0 = a_slab;
+        else a0 = piece0 < CHUNK_PIECES8 ? a_chunk : a_slab;  // (integer select: no DMA under a branch)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const u16*>(a0) + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(&sW[stage][piece0 * 512]), 16, q4 * 1024, 0);
       };
       if constexpr (WLO) static_for<UNIT_DMA>([&](auto u) { stage_piece_w(u, 0, 0); });
       else stage_unit(0, 0);  // flies while the LayerNorm below runs
@@ -1313,8 +1357,16 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       // The stage index is a RUNTIME value here (one copy of the loop body): the fragment reads are inline asm with
       // the stage's base address in a register, so the compiler has no DMA-vs-read aliasing to resolve, and a body
       // unrolled by two would permute the 128 accumulator registers between its copies on every back edge.
-      auto macro = [&](int t, int cur, auto slab_tag) {
+      // F8 (bf16-valued weights): the fragment-read pipeline is NOT drained at the stage boundary (frag_stream2_ring):
+      // `last_tag` = the unit after this one is the tail slab, not another macro-iteration
+      struct TailOff8 {
+        static constexpr int at(int s, int j) { return 2 * F8Chunk<KS>::BYTES + (s * 2 + j) * 1024; }
+      };
+      constexpr int RING_SETS = 4;
+      bf16x8 wq[RING_SETS][2];
+      auto macro = [&](int t, int cur, auto slab_tag, auto last_tag) {
         constexpr bool SLAB = decltype(slab_tag)::value;  // false only for t = 0
+        constexpr bool LAST = decltype(last_tag)::value;
         using Off = MlpStreamOff<KS, NF1, SLAB>;
         constexpr int NS = Off::NS;
         // The next stage's DMA instructions are spread over the first steps of the stream, one per step: issued in
@@ -1355,8 +1407,16 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           using C8 = F8Chunk<KS>;
           constexpr int CS = C8::STEPS;
           f32x4 nb[2][MF];
-          frag_stream2<2 * CS + NS, DEPTH8, Off8>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+          constexpr int NSTEPS8 = 2 * CS + NS;
+          auto unit_body = [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
             constexpr int s = decltype(step_tag)::value;
+#ifdef OPK_RING_STREAM
+            // step 0: every wave is past the unit that lived in the other stage -> its DMA may start;
+            // step NSTEPS8 - RING_SETS: this wave's share of the next unit has landed, then all waves meet -- the reads of
+            // the next unit's first steps follow this step
+            if constexpr (s == 0) asm volatile("s_barrier" ::: "memory");
+            if constexpr (s == NSTEPS8 - RING_SETS) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 #ifdef OPK_SEG_TIMING  // cycles of the three segments of an iteration (chunk 2t | chunk 2t+1 + GeGLU | slab + GeGLU)
             if constexpr (s == 0 || s == CS || s == 2 * CS) {
               const unsigned long long now = __builtin_readcyclecounter();
@@ -1384,7 +1444,17 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
               geglu_slice(nb, g_prev, std::integral_constant<int, s - 2 * CS>{}, pack_h);
               interleave_n(std::integral_constant<int, 4 * MF>{}, std::integral_constant<int, 3>{});
             }
-          });
+          };
+#ifdef OPK_RING_STREAM
+          {
+            const uint32_t base_cur = cur ? lds_stage[1] : lds_stage[0], base_next = cur ? lds_stage[0] : lds_stage[1];
+            using OffNextSlab = MlpStreamOff8<KS, NF1, true>;
+            if constexpr (LAST) frag_stream2_ring<NSTEPS8, RING_SETS, Off8, TailOff8, !SLAB, true>(base_cur, base_next, wq, unit_body);
+            else frag_stream2_ring<NSTEPS8, RING_SETS, Off8, OffNextSlab, !SLAB, true>(base_cur, base_next, wq, unit_body);
+          }
+#else
+          frag_stream2<NSTEPS8, DEPTH8, Off8>(cur ? lds_stage[1] : lds_stage[0], unit_body);
+#endif
 #ifdef OPK_SEG_TIMING
           opk_seg[2] += __builtin_readcyclecounter() - opk_seg_t;
 #endif
@@ -1407,6 +1477,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           }
           interleave_step();
         });
+#ifdef OPK_RING_STREAM
+        if constexpr (F8) return;  // (its two barriers sit inside the unit: no drain here)
+#endif
 #ifdef OPK_TIMING
         const unsigned long long opk_w0 = __builtin_readcyclecounter();
 #endif
@@ -1487,12 +1560,23 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           half_iter(2 * n_pairs + 1, h1, no_, na, nb);
         }
       } else {
-      macro(0, 0, no_);
+      macro(0, 0, no_, no_);
+#ifdef OPK_RING_STREAM
+      if constexpr (F8) {  // the last iteration hands its read pipeline to the tail slab: peeled
+        if (n_pairs > 2) {
+          int t = 1;
+          do {
+            macro(t, t & 1, yes_, no_);
+          } while (++t < n_pairs - 1);
+        }
+        macro(n_pairs - 1, 1, yes_, yes_);  // (n_pairs is even)
+      } else
+#endif
       {  // n_pairs is even (checked on the host): at least one more iteration, and the tail reads stage 0.  Written as
         // do-while: around a loop that may run zero times the compiler parks accumulator values in scratch.
         int t = 1;
         do {
-          macro(t, t & 1, yes_);
+          macro(t, t & 1, yes_, no_);
         } while (++t < n_pairs);
       }
       }
@@ -1501,6 +1585,13 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         struct TailOff {
           static constexpr int at(int s, int j) { return (F8 ? 2 * F8Chunk<KS>::BYTES : 2 * KS * 2048) + (s * 2 + j) * 1024; }
         };
+#ifdef OPK_RING_STREAM
+        if constexpr (F8)
+          frag_stream2_ring<NF1 / 2, RING_SETS, TailOff8, TailOff8, false, false>(lds_stage[0], lds_stage[0], wq, [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+            slab_pair(std::integral_constant<int, 2 * decltype(step_tag)::value>{}, w0, w1);
+          });
+        else
+#endif
         frag_stream2<NF1 / 2, DEPTH, TailOff>(lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           slab_pair(std::integral_constant<int, 2 * decltype(step_tag)::value>{}, w0, w1);
         });

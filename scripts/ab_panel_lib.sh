@@ -1,8 +1,8 @@
 # same-box A/B of two library builds on a panel-path model: scripts/ab_panel_lib.sh <other .so> <model> <bf16|fp32> [steps]
 LIB=$1; M=${2:-base}; W=${3:-bf16}; S=${4:-20}
 for i in 1 2; do
-  OPEN_PROVENCE_HIP_LIB=$LIB timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-other-dtype --weights $W > gpurun_out/abpl_other_$i.json 2>gpurun_out/abpl_err.log
-  timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-other-dtype --weights $W > gpurun_out/abpl_tree_$i.json 2>>gpurun_out/abpl_err.log
+  OPEN_PROVENCE_HIP_LIB=$LIB timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-base --no-other-dtype --weights $W > gpurun_out/abpl_other_$i.json 2>gpurun_out/abpl_err.log
+  timeout 600 python bench.py --model $M --steps $S --no-cpu-baseline --no-long --no-base --no-other-dtype --weights $W > gpurun_out/abpl_tree_$i.json 2>>gpurun_out/abpl_err.log
 done
 python - $M $W <<'PY'
 import json,glob,sys
