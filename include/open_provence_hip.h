@@ -148,10 +148,14 @@ size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int 
  * terms that are identically zero for this checkpoint), terms_out[OP_FAM_COUNT], and *kernel_set =
  * index of the curated kernel set that implements them with exactly those MFMA passes (0 = all
  * terms, 1 = bf16 weights, 2 = single pass, 3 = the terms of 1 with the whole-layer kernel's
- * operands carried as fp16 hi + e4m3 lo -- 1.5 instead of 2 MFMA units per product, selected for
- * hidden <= 256 when every GEMM weight is exactly an fp16 value and OP_FLAG_NO_F8 is clear), or -1
- * when the policy runs on the all-terms kernels with cleared lo operands (same numerics, no
- * speed-up). */
+ * operands carried as fp16 hi + e4m3 lo -- 1.5 instead of 2 MFMA units per product, 4 = the terms
+ * of 0 in that format with the weights' lo part as a second e4m3 plane -- 2 units instead of 3 and
+ * one kernel per layer instead of two), or -1 when the policy runs on the all-terms kernels with
+ * cleared lo operands (same numerics, no speed-up).  Sets 3 / 4 replace 1 / 0 for hidden <= 256
+ * (hidden 512 / 768: with OP_FLAG_PANEL_F8) unless OP_FLAG_NO_F8 is set, set 3 needs every GEMM
+ * weight to be exactly an fp16 value, and neither is taken for a checkpoint with a weight TENSOR
+ * scaled into fp16's subnormal range (checked at load time).  Their fp16 operand plane has fp16's
+ * range: an MLP activation beyond it turns the outputs into NaN (on purpose: not clamped). */
 int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set);
 
 /* Replaces: OpenProvenceModel.forward (standalone.py:1666-1739) = HF
