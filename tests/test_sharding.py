@@ -307,3 +307,51 @@ def test_assign_jobs_is_deterministic_complete_and_balanced():
                 loads[r] += (sum(len(s) for s in entry) if isinstance(entry, list) else len(entry)) + 64
         assert max(loads) - min(loads) <= 4000 + 64
     assert assign_jobs([["a", "b"]], 1) == [[0, 0]]
+
+
+def _many_contexts_worker(rank, world, port, out_path):
+    """A 90-context request (several contexts per rank, reorder + top_k on the merged result): job-sharded process() on
+    every rank, rank 0 also computes the plain single-process result first; both are stored for comparison."""
+
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from helpers import CharTokenizer, golden_stub_forward, host_only_model, period_splitter
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        words = "the tower is tall boats carry fish and salt to north city harbour many years ago it was new".split()
+        contexts = [
+            " ".join(" ".join(words[(i * 5 + s * 3 + k) % len(words)] for k in range(4 + (i + s) % 5)).capitalize() + "." for s in range(1 + i % 6))
+            for i in range(90)
+        ]
+        kwargs = dict(question="which boats carry salt?", context=contexts, sentence_splitter=period_splitter, show_progress=False,
+                      return_sentence_metrics=True, return_sentence_texts=True, batch_size=8, threshold=0.4, reorder=True, top_k=25)
+        model = host_only_model(tokenizer=CharTokenizer(), max_length=96, forward=golden_stub_forward)
+        plain = model.process(**kwargs) if rank == 0 else None
+        model.attach_process_group(None, dst=0, shard="jobs")
+        got = model.process(**kwargs)
+        if rank == 0:
+            for res in (plain, got):
+                res.pop("timing")
+                res.pop("performance_trace")
+            torch.save({"plain": plain, "sharded": got}, out_path)
+        else:
+            assert got is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_job_sharded_process_of_many_contexts_equals_the_plain_call(tmp_path, world):
+    out_path = str(tmp_path / "many.pt")
+    mp.spawn(_many_contexts_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    both = torch.load(out_path, weights_only=False)
+    assert both["plain"].keys() == both["sharded"].keys()
+    for key in both["plain"]:
+        assert both["plain"][key] == both["sharded"][key], key
+    assert len(both["sharded"]["pruned_context"]) == 25  # top_k applied on the merged, re-ordered result
