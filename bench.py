@@ -8,8 +8,10 @@ One step = one pass of the hot path (``op_forward_packed``: ids -> per-token kee
 logits) over one batch of synthetic (query, context) pairs already resident in HBM.  Workload =
 BASELINE.json configs[1]: open-provence-reranker-xsmall-v1 dims, 256 pairs x 512 tokens per GPU, one query
 shared by all contexts, random-init weights (no network: no checkpoint, no dataset).  N > 1 is weak
-scaling: every rank processes its own 256 pairs (no data-path collective) and the per-pair outputs are
-gathered on rank 0 over RCCL inside the timed step.  Rank 0 prints ONE JSON line.
+scaling: every rank processes its own 256 pairs (no data-path collective) and, inside the timed step, does what
+``process()`` does with a process group attached: per-fragment means of the keep-probabilities on the device
+(``op_segment_means``, 32-token sentences) and ONE RCCL gather of 4 bytes per fragment + the ranking logits to rank 0.
+Rank 0 prints ONE JSON line.
 
 Checkpoint dtype.  The headline (`value`) is the FP32-valued checkpoint: the reference's training wrapper loads the
 backbone in fp32 (encoder.py:128-144), `bf16: true` of configs/open-provence-reranker-xsmall-v1.yaml:94 is HF-Trainer
@@ -48,6 +50,7 @@ from open_provence_amd.packing import pack_rows  # noqa: E402
 from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict, synth_varlen_lengths  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FRAGMENT_TOKENS = 32  # synthetic sentence length for the multi-GPU exchange (one fp32 per sentence is gathered)
 
 
 def algorithmic_flops_per_pair(dims: EncoderDims, seq_len: int) -> float:
@@ -80,6 +83,55 @@ def physical_cores() -> int:
     except OSError:
         pass
     return os.cpu_count() or 1
+
+
+ARITHMETIC_OF_KERNEL_SET = {
+    # what the dominant kernels multiply with (the line's `dtype`): every set accumulates in fp32
+    "f16-f8-w": "fp16 hi + e4m3 lo split operands (weights: fp16 + two e4m3 planes), fp32 accumulate",
+    "f16-f8": "fp16 hi + e4m3 lo split operands (weights: one fp16 plane), fp32 accumulate",
+    "bf16x3": "bf16 (hi, lo) split operands, three products per term, fp32 accumulate",
+    "bf16-weights": "bf16 (hi, lo) split activations x single-plane bf16 weights, fp32 accumulate",
+    "bf16": "bf16 single pass, fp32 accumulate",
+}
+
+
+def arithmetic_label(policy: dict) -> str:
+    return ARITHMETIC_OF_KERNEL_SET.get(policy["kernel_set"], policy["kernel_set"])
+
+
+def probed_pass(encoder, step_fn, steps: int, est_step_s: float, sync) -> dict:
+    """`steps` more steps of `step_fn` with the one-wave clock probe spinning beside them for about half of the loop
+    (s_memtime / s_memrealtime): the shader clock the chip holds under this load.  A SEPARATE pass -- the timed loops
+    never carry the probe -- whose own ms per step is reported next to the clock, so that what the probe costs is on
+    the record (it occupies one SIMD of one CU: the un-probed and the probed step agree to within run-to-run noise)."""
+
+    probe, probe_stream = encoder.clock_probe(max(200, int(est_step_s * steps * 0.5e6)))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync()
+    dt = (time.perf_counter() - t0) / steps
+    probe_stream.synchronize()
+    cycles, ticks = (int(v) for v in probe.cpu().tolist())
+    return {"value": cycles / max(ticks, 1) * 0.1, "ms_per_step_with_probe": dt * 1e3, "steps": steps}
+
+
+def require_finite(what: str, *tensors) -> None:
+    """A bench line must not carry a rate measured on garbage: refuse non-finite outputs loudly."""
+
+    for t in tensors:
+        if t is not None and not bool(torch.isfinite(t).all().item()):
+            raise SystemExit(f"bench.py: non-finite outputs in {what}: refusing to report a rate for it")
+
+
+def output_checksum(prune: torch.Tensor, rank_logits: torch.Tensor) -> dict:
+    """Order-independent fingerprint of a forward's outputs (float64 sums on the device), printed with every record so
+    that two runs of the same command -- or the same workload through another kernel set -- can be compared at a glance;
+    tests/test_gpu_timed_path.py checks the same workloads against the oracle at their full size."""
+
+    p64 = prune.double()
+    return {"prune_sum": float(p64.sum().item()), "prune_abs_sum": float(p64.abs().sum().item()),
+            "rank_sum": float(rank_logits.double().sum().item())}
 
 
 def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
@@ -213,7 +265,12 @@ def main() -> None:
         if grouped:
             from open_provence_amd.sharding import ShardPlan
 
-            plan = ShardPlan([len(r) for r in rows_all], world, width=1, num_labels=dims.num_labels)
+            # the product's exchange (modeling._collect_rows_sharded): rows assigned by TOKEN count, payload = one fp32
+            # per FRAGMENT (the mean keep-probability of a sentence, op_segment_means on the device) + ranking logits.
+            # Synthetic sentences: 32 tokens each.
+            token_plan = ShardPlan([len(r) for r in rows_all], world, width=1, num_labels=dims.num_labels)
+            frag_counts = [(len(r) + FRAGMENT_TOKENS - 1) // FRAGMENT_TOKENS for r in rows_all]
+            plan = ShardPlan(frag_counts, world, width=1, num_labels=dims.num_labels, shards=token_plan.shards)
             rows = [rows_all[i] for i in plan.local_rows(rank)]
         else:
             rows = rows_all
@@ -235,6 +292,17 @@ def main() -> None:
     want_pipes = args.pipelines or (2 if (dims.hidden_size <= 256 and not f8_set) else 1)
     n_pipes = want_pipes if (not args.varlen and len(rows) >= 2) else 1
     keep_dev = torch.empty(total_tokens, dtype=torch.float32, device=device)
+
+    def fragment_ranges(cu_host: np.ndarray) -> torch.Tensor:
+        """[S, 2] int32 token ranges of the 32-token sentences of every packed row (device)."""
+
+        segs = []
+        for i in range(len(cu_host) - 1):
+            a, b = int(cu_host[i]), int(cu_host[i + 1])
+            segs.extend((lo, min(lo + FRAGMENT_TOKENS, b)) for lo in range(a, b, FRAGMENT_TOKENS))
+        return torch.tensor(segs, dtype=torch.int32, device=device).reshape(-1, 2)
+
+    seg_dev = fragment_ranges(cu_np) if plan is not None else None
     pipes = []
     if n_pipes == 2:
         if plan is not None:
@@ -247,24 +315,25 @@ def main() -> None:
         for part, (part_rows, part_plan) in enumerate(halves):
             p_ids_np, p_cu_np, p_max = pack_rows(part_rows)
             pipes.append((part, torch.from_numpy(p_ids_np).to(device), torch.from_numpy(p_cu_np).to(device), p_cu_np, p_max,
-                          torch.empty(int(p_cu_np[-1]), dtype=torch.float32, device=device), part_plan))
+                          torch.empty(int(p_cu_np[-1]), dtype=torch.float32, device=device), part_plan,
+                          fragment_ranges(p_cu_np) if part_plan is not None else None))
         torch.cuda.synchronize(device)
 
     def step_one():
         prune, rank_logits = encoder.forward_packed(ids, cu, cu_np, max_len, keep_prob=keep_dev)
-        if plan is not None:  # the exchange step of the path: ShardPlan.gather (open_provence_amd/sharding.py)
-            plan.gather(keep_dev, rank_logits, dst=0)
+        if plan is not None:  # the exchange step of the path: per-fragment means, then ShardPlan.gather (sharding.py)
+            plan.gather(encoder.segment_means(keep_dev, seg_dev), rank_logits, dst=0)
         return prune, rank_logits
 
     def step():
         if not pipes:
             return step_one()
         out = None
-        for part, p_ids, p_cu, p_cu_np, p_max, p_keep, part_plan in pipes:
+        for part, p_ids, p_cu, p_cu_np, p_max, p_keep, part_plan, p_seg in pipes:
             out = encoder.forward_packed_on(part, p_ids, p_cu, p_cu_np, p_max, keep_prob=p_keep)
             if part_plan is not None:
                 with torch.cuda.stream(encoder.pipeline_stream(part)):
-                    part_plan.gather(p_keep, out[1], dst=0)
+                    part_plan.gather(encoder.segment_means(p_keep, p_seg), out[1], dst=0)
         return out
 
     def fence():
@@ -278,14 +347,6 @@ def main() -> None:
     # per-step device times from events on the launch stream (the library enqueues on torch's current stream)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     mark_stream = encoder.pipeline_stream(1) if pipes else torch.cuda.current_stream(device)
-    # the shader clock the chip holds while the timed steps run: a one-wave probe on its own stream spins for about
-    # half of the expected loop time (estimated from two more untimed steps)
-    te = time.perf_counter()
-    for _ in range(2):
-        step()
-    fence()
-    est_step = (time.perf_counter() - te) / 2
-    probe, probe_stream = encoder.clock_probe(max(200, int(est_step * args.steps * 0.5e6)))
     t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record(mark_stream)
@@ -293,15 +354,18 @@ def main() -> None:
     marks[args.steps].record(mark_stream)
     fence()
     elapsed = time.perf_counter() - t0
-    probe_stream.synchronize()
-    probe_cycles, probe_ticks = (int(v) for v in probe.cpu().tolist())
-    shader_clock_ghz = probe_cycles / max(probe_ticks, 1) * 0.1
+    # the shader clock the chip holds under this load: a SEPARATE pass of the same steps with the one-wave probe beside
+    # it (probed_pass) -- nothing but the steps runs inside the timed region above
+    clock = probed_pass(encoder, step, args.steps, elapsed / args.steps, fence)
+    shader_clock_ghz = clock["value"]
     step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    finite = bool(torch.isfinite(out[0]).all().item() and torch.isfinite(out[1]).all().item())
+    require_finite("the headline workload", out[0], out[1])
+    finite = True
+    checksum = output_checksum(out[0], out[1])
     # per-kernel HIP-event timing on the launch stream (separate, un-timed passes)
     encoder.profile_enable(True)
     encoder.profile_reset()
@@ -441,7 +505,7 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": arithmetic_label(policy),
         "data": "synthetic",
         "config": {
             "workload": f"open-provence-reranker-{args.model}-v1 dims (H={H}, I={I}, {n_layers} layers, {dims.num_heads} heads, "
@@ -456,18 +520,22 @@ def main() -> None:
             "precision": args.precision,
             "checkpoint_dtype": args.weights,
             "policy": policy,  # term masks evaluated per contraction family + the kernel set running them
-            "parallelism": f"dp{world} (pairs sharded, RCCL gather of per-pair outputs)" if world > 1
+            "parallelism": f"dp{world} (pairs sharded by token count, on-device fragment means, one RCCL gather of 4 B per fragment + ranking logits)" if world > 1
             else ("single GPU, two independent half-batch launch sequences on CU-partitioned streams" if pipes else "single GPU"),
             "algorithmic_gflop_per_pair": flops_pair / 1e9,
             "outputs_finite": finite,
+            "output_checksum": checksum,
         },
         "roofline": roofline,
         "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in profile.items()},
     }
     if one_pipeline is not None:
         line["one_pipeline"] = one_pipeline
-    line["shader_clock_ghz"] = {"value": shader_clock_ghz, "source": "one-wave probe (s_memtime / s_memrealtime) on its own stream "
-                                "during the first half of the timed loop; the 2.5 PFLOP/s peak assumes 2.4 GHz"}
+    line["shader_clock_ghz"] = {**clock, "source": "one-wave probe (s_memtime / s_memrealtime) on its own stream during a SEPARATE "
+                                "pass of the same steps (the timed loop carries no probe; ms_per_step_with_probe vs ms_per_step "
+                                "is the A/B of what the probe costs); the 2.5 PFLOP/s peak assumes 2.4 GHz"}
+    if roofline is not None:
+        roofline["shader_clock_ghz"] = shader_clock_ghz
     line["step_ms"] = {"median": float(np.median(step_ms)), "p10": float(np.percentile(step_ms, 10)),
                        "p90": float(np.percentile(step_ms, 90)), "source": "HIP events on the launch stream" + (" of the second half-batch" if pipes else "") + ", rank 0"}
     if world == 1 and not args.varlen and args.seq_len != 2048 and not args.no_long:
@@ -497,10 +565,15 @@ def main() -> None:
             long_step()
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t1) / long_steps
+        out_l = encoder.forward_packed(*long_in[0])
+        require_finite("the seq_len 2048 sub-record", out_l[0], out_l[1])
+        sync_dev = lambda: torch.cuda.synchronize(device)  # noqa: E731
         flops_l = algorithmic_flops_per_pair(dims, 2048)
         line["seq_len_2048"] = {"value": long_pairs / dt, "unit": "pairs/s", "pairs": long_pairs, "steps": long_steps,
                                 "ms_per_step": dt * 1e3, "algorithmic_gflop_per_pair": flops_l / 1e9,
-                                "whole_forward_frac": long_pairs / dt * flops_l / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+                                "whole_forward_frac": long_pairs / dt * flops_l / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                "shader_clock_ghz": probed_pass(encoder, long_step, long_steps, dt, sync_dev)["value"],
+                                "output_checksum": output_checksum(out_l[0], out_l[1])}
     if world == 1 and not args.varlen and not args.no_other_dtype:
         # the same workload with the OTHER checkpoint dtype, timed by the same command (sub-record, not the headline)
         other = "bf16" if args.weights == "fp32" else "fp32"
@@ -513,7 +586,7 @@ def main() -> None:
 
         def step_o(two: bool):
             if two and pipes:
-                for part, p_ids, p_cu, p_cu_np, p_max, p_keep, _plan in pipes:
+                for part, p_ids, p_cu, p_cu_np, p_max, p_keep, _plan, _seg in pipes:
                     enc_o.forward_packed_on(part, p_ids, p_cu, p_cu_np, p_max, keep_prob=p_keep)
             else:
                 enc_o.forward_packed(ids, cu, cu_np, max_len, keep_prob=keep_dev)
@@ -536,18 +609,24 @@ def main() -> None:
         prof_o = enc_o.profile_read()
         enc_o.profile_enable(False)
         dom_o = max(prof_o.items(), key=lambda kv: kv[1]["total_ms"])[0]
+        out_o = enc_o.forward_packed(ids, cu, cu_np, max_len)
+        require_finite(f"the {other}-checkpoint sub-record", out_o[0], out_o[1])
+        clock_o = probed_pass(enc_o, lambda: step_o(True), args.steps, dt_two, lambda: torch.cuda.synchronize(device))
         sub = {"value": n_pairs_rank / dt_two, "unit": "pairs/s", "ms_per_step": dt_two * 1e3, "steps": args.steps,
                "one_pipeline": n_pairs_rank / dt_one, "checkpoint_dtype": other, "policy": policy_o,
+               "dtype": arithmetic_label(policy_o), "shader_clock_ghz": clock_o["value"],
+               "output_checksum": output_checksum(out_o[0], out_o[1]),
                "whole_forward_frac": n_pairs_rank / dt_two * flops_pair / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in prof_o.items()}}
         if dom_o in flops_per_forward:
             lpf = prof_o[dom_o]["launches"] / prof_steps
             sub["roofline"] = {"kernel": dom_o, "avg_launch_ms": prof_o[dom_o]["avg_ms"], "avg_launch_ms_source": "event_bracketed",
+                               "shader_clock_ghz": clock_o["value"],
                                "frac": flops_per_forward[dom_o] / lpf / (prof_o[dom_o]["avg_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
         line[f"{other}_checkpoint"] = sub
         enc_o.close()
     if world == 1 and not args.varlen and args.model == "xsmall" and not args.no_base:
-        # the panel path (hidden 768: base dims, 22 layers) on the same batch, both checkpoint dtypes (sub-record; the
+        # the panel path (base dims: hidden 512, 19 layers) on the same batch, both checkpoint dtypes (sub-record; the
         # full record of that model is `bench.py --model base`)
         dims_b = named_dims("base")
         rows_b = synth_pair_batch(dims_b, args.pairs, args.seq_len, seed=1234)
@@ -575,6 +654,10 @@ def main() -> None:
             enc_b = HipEncoder(dims_b, device=device, precision=args.precision)
             enc_b.load_state_dict(state_b)
             dt_b = timed_base(enc_b)
+            out_b = enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
+            require_finite(f"the base-model sub-record ({wdt} checkpoint)", out_b[0], out_b[1])
+            clock_b = probed_pass(enc_b, lambda: enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b), base_steps, dt_b,
+                                  lambda: torch.cuda.synchronize(device))
             enc_b.profile_enable(True)
             enc_b.profile_reset()
             for _ in range(2):
@@ -582,6 +665,8 @@ def main() -> None:
             prof_b = enc_b.profile_read()
             enc_b.profile_enable(False)
             rec = {"value": args.pairs / dt_b, "ms_per_step": dt_b * 1e3, "kernel_set": enc_b.effective_policy()["kernel_set"],
+                   "dtype": arithmetic_label(enc_b.effective_policy()), "shader_clock_ghz": clock_b["value"],
+                   "output_checksum": output_checksum(out_b[0], out_b[1]),
                    "whole_forward_frac": args.pairs / dt_b * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                    "kernel_ms_per_forward": {k: v["total_ms"] / 2 for k, v in prof_b.items()}}
             enc_b.close()
@@ -590,6 +675,8 @@ def main() -> None:
             enc_f.load_state_dict(state_b)
             del state_b
             dt_f = timed_base(enc_f)
+            out_f = enc_f.forward_packed(ids_b, cu_b, cu_b_np, max_b)
+            require_finite(f"the base-model opt-in fp16 + e4m3 sub-record ({wdt} checkpoint)", out_f[0], out_f[1])
             rec["opt_in_panel_f8"] = {"value": args.pairs / dt_f, "ms_per_step": dt_f * 1e3, "kernel_set": enc_f.effective_policy()["kernel_set"]}
             enc_f.close()
             sub_b[f"{wdt}_checkpoint"] = rec

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 4 /* 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
+#define OP_ABI_VERSION 5 /* 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
@@ -157,6 +157,16 @@ size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int 
  * scaled into fp16's subnormal range (checked at load time).  Their fp16 operand plane has fp16's
  * range: an MLP activation beyond it turns the outputs into NaN (on purpose: not clamped). */
 int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set);
+
+/* Run-time switch between the fp16 + e4m3 kernel sets (3 / 4) and the (hi, lo) bf16 sets (1 / 0) they replace: both
+ * weight packs of a handle stay resident, so this only re-runs the selection of op_weights_ready (with enabled = 0 as if
+ * OP_FLAG_NO_F8 were set).  The Python layer calls it when a forward on sets 3 / 4 returns non-finite outputs -- an MLP
+ * activation beyond fp16's range -- and repeats that forward, so that process() returns what the reference returns
+ * instead of raising.  Replaces: nothing; precedent for a silent, correct retry: the reference's own fallback from an
+ * unsupported dtype / attention implementation at load time (standalone.py:1631-1642).  Returns OP_OK; *changed (may
+ * be NULL) = 1 when the evaluated kernel set is different afterwards.  The workspace size may change: query
+ * op_workspace_bytes again. */
+int op_set_compact_operands(op_handle* h, int enabled, int* changed);
 
 /* Replaces: OpenProvenceModel.forward (standalone.py:1666-1739) = HF
  * ModernBertForSequenceClassification.forward + OpenProvenceHead.forward (standalone.py:434-448),

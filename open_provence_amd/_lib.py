@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 
 OP_MAX_LAYERS = 128
-OP_ABI_VERSION = 4
+OP_ABI_VERSION = 5
 
 OP_OK = 0
 OP_DTYPE_F32, OP_DTYPE_BF16, OP_DTYPE_F16 = 0, 1, 2
@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "op_load_weight",
     "op_weights_ready",
     "op_effective_policy",
+    "op_set_compact_operands",
     "op_workspace_bytes",
     "op_forward_packed",
     "op_segment_means",
@@ -129,6 +130,9 @@ def load_library() -> ctypes.CDLL:
     lib.op_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, cs, vp]
     lib.op_effective_policy.restype = ci
     lib.op_effective_policy.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ci)]
+    if hasattr(lib, "op_set_compact_operands"):  # (absent only in an older library loaded for a same-box A/B, see below)
+        lib.op_set_compact_operands.restype = ci
+        lib.op_set_compact_operands.argtypes = [vp, ci, ctypes.POINTER(ci)]
     lib.op_segment_means.restype = ci
     lib.op_segment_means.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     lib.op_debug_capture_hidden.restype = ci
@@ -151,7 +155,10 @@ def load_library() -> ctypes.CDLL:
     lib.op_last_error.argtypes = [vp]
 
     version = lib.op_abi_version()
-    if version != OP_ABI_VERSION:
+    # measurement hook: scripts/ab_lib.sh times an OLDER build of the library against the tree's (same box, alternating
+    # runs); OPEN_PROVENCE_HIP_LIB_ANY_ABI=1 lets the explicitly named library through with its own version
+    any_abi = os.environ.get("OPEN_PROVENCE_HIP_LIB") and os.environ.get("OPEN_PROVENCE_HIP_LIB_ANY_ABI") == "1"
+    if version != OP_ABI_VERSION and not any_abi:
         raise HipLibraryError(f"{path} has ABI version {version}, the Python layer expects {OP_ABI_VERSION}; rebuild")
     _LIB = lib
     return lib

@@ -98,6 +98,7 @@ struct op_handle {
   int* any_lo_dev = nullptr;       // [OP_FAM_COUNT] device flags: some weight of the family has a non-zero lo element
                                    // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value (no "f16 + fp8" set)
   bool f8_packs = false;           // the "f16 + fp8" weight packs exist (row path, hidden a multiple of 128)
+  bool f8_off = false;             // op_set_compact_operands(h, 0): keep the (hi, lo) bf16 sets although the packs exist
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
   int n_cus = 256;          // compute units of the device (hipDeviceProp multiProcessorCount)
@@ -1256,7 +1257,7 @@ int resolve_policy(op_handle* h) {
       }
     // bf16-valued weights that are also exact fp16 values, on the whole-layer kernel's shapes: the "f16 + fp8" kernel
     // set evaluates the same terms at 1.5 instead of 2 MFMA units per product (op_internal.h)
-    const bool f8_ok = !h->emulate && h->f8_packs && !any_lo[OP_FAM_COUNT + 2] &&
+    const bool f8_ok = !h->emulate && h->f8_packs && !h->f8_off && !any_lo[OP_FAM_COUNT + 2] &&
                        !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32));
     if (f8_ok && h->pi == opl::PI_BF16_WEIGHTS && !any_lo[OP_FAM_COUNT]) h->pi = opl::PI_F16_F8;
     // every term requested and carried (fp32-valued weights): the same format with the weights' lo part as a third
@@ -1286,6 +1287,18 @@ int op_weights_ready(op_handle* h) {
   }
   msg += " (" + std::to_string(h->missing.size()) + " total)";
   return fail(h, OP_ERR_STATE, "%s", msg.c_str());
+}
+
+int op_set_compact_operands(op_handle* h, int enabled, int* changed) {
+  if (!h) return fail(nullptr, OP_ERR_INVALID, "op_set_compact_operands: NULL handle");
+  int rc = op_weights_ready(h);
+  if (rc != OP_OK) return rc;
+  const int before = h->pi;
+  h->f8_off = enabled == 0;
+  h->resolved = false;
+  rc = resolve_policy(h);
+  if (changed) *changed = (rc == OP_OK && h->pi != before) ? 1 : 0;
+  return rc;
 }
 
 int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set) {

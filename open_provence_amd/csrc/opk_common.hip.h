@@ -313,6 +313,12 @@ __device__ __forceinline__ bf16x8 lds_read_frag_after(uint32_t lds_addr, f32x4& 
     asm volatile("ds_read_b128 %0, %5 offset:%6" : "=v"(v), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(lds_addr), "n"(OFF));
   return v;
 }
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_frag_after1(uint32_t lds_addr, f32x4& p0) {  // one accumulator, in an AGPR
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %2 offset:%3" : "=v"(v), "+a"(p0) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
 template <int N>
 __device__ __forceinline__ void lds_wait2(bf16x8& a, bf16x8& b) {  // at most N fragment reads still in flight
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
@@ -401,36 +407,40 @@ __device__ __forceinline__ void frag_stream2(uint32_t lds_addr, Body&& body) {
   });
 }
 
-// The same stream over a two-stage ring WITHOUT a drain at the stage boundary: the SETS register sets stay in flight
-// across it -- the reads for the first SETS steps of the NEXT unit (other stage, offsets OffNext) are issued behind the
-// last SETS steps of this one, and the next unit starts on operands that are already there (PRIME = false).  What the
-// caller's body must do for that to be legal (the whole-layer kernel's MLP loop does): a barrier at its step 0 before
-// it requests the DMA into the other stage (every wave has then finished reading the unit that lived there), and
-// `s_waitcnt vmcnt(0)` + a second barrier at its step NSTEPS - SETS (the first read of the next unit follows that step:
-// every wave's share of it has landed).  NSTEPS % SETS == 0 keeps the set of step 0 the same in every unit.
-template <int NSTEPS, int SETS, class Off, class OffNext, bool PRIME, bool CONTINUE, class Body>
-__device__ __forceinline__ void frag_stream2_ring(uint32_t lds_cur, uint32_t lds_next, bf16x8 (&w)[SETS][2], Body&& body) {
-  static_assert(NSTEPS % SETS == 0 && NSTEPS >= SETS, "the register sets line up across units");
-  if constexpr (PRIME)
-    static_for<SETS>([&](auto t) {
-      constexpr int s = decltype(t)::value;
-      w[s][0] = lds_read_frag<Off::at(s, 0)>(lds_cur);
-      w[s][1] = lds_read_frag<Off::at(s, 1)>(lds_cur);
-    });
+// (a step body that may or may not be handed a read-placement callback: the callback, or the default)
+template <class D>
+__device__ __forceinline__ D&& rd_or(D&& d) { return static_cast<D&&>(d); }
+template <class D, class R>
+__device__ __forceinline__ R&& rd_or(D&&, R&& r) { return static_cast<R&&>(r); }
+
+// frag_stream2 with the reads of the group DEPTH + 1 steps ahead issued BETWEEN the step's MFMAs instead of behind them.
+// A wave that is alone on its SIMD issues one instruction per four cycles, in order: behind the last MFMA of a step only
+// that MFMA's shadow (12 cycles) is there for the two ds_read_b128, the counted wait and the hazard nop in front of the
+// next step's first MFMA -- measured on the bare stream of the whole-layer kernel's MLP loop (no riders, no DMA, no
+// barrier): 79.5 cycles per 64-cycle step.  Here the body calls rd(0, acc) / rd(1, acc) where the reads are to go:
+// each read "rewrites" the accumulator named (an AGPR), so it can neither rise above the MFMA that produces it nor sink
+// below its next use.  DEPTH + 2 register sets: the set being filled is not the one being multiplied.
+template <int NSTEPS, int DEPTH, class Off, class Body>
+__device__ __forceinline__ void frag_stream2i(uint32_t lds_addr, Body&& body) {
+  constexpr int SETS = DEPTH + 2;
+  bf16x8 w[SETS][2];
+  static_for<(DEPTH + 1 < NSTEPS ? DEPTH + 1 : NSTEPS)>([&](auto t) {
+    constexpr int s = decltype(t)::value;
+    w[s % SETS][0] = lds_read_frag<Off::at(s, 0)>(lds_addr);
+    w[s % SETS][1] = lds_read_frag<Off::at(s, 1)>(lds_addr);
+  });
   static_for<NSTEPS>([&](auto t) {
     constexpr int s = decltype(t)::value;
     constexpr int set = s % SETS;
-    constexpr int ahead = CONTINUE ? SETS - 1 : ((NSTEPS - 1 - s) < SETS - 1 ? (NSTEPS - 1 - s) : SETS - 1);
+    constexpr int nxt = s + DEPTH + 1;
+    constexpr int ahead = (NSTEPS - 1 - s) < DEPTH ? (NSTEPS - 1 - s) : DEPTH;
     lds_wait2<2 * ahead>(w[set][0], w[set][1]);
-    body(t, w[set][0], w[set][1]);
+    auto rd = [&](auto j_tag, f32x4& p0) {
+      constexpr int j = decltype(j_tag)::value;
+      if constexpr (nxt < NSTEPS) w[nxt % SETS][j] = lds_read_frag_after1<Off::at(nxt < NSTEPS ? nxt : 0, j)>(lds_addr, p0);
+    };
+    body(t, w[set][0], w[set][1], rd);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (s + SETS < NSTEPS) {
-      w[set][0] = lds_read_frag<Off::at(s + SETS, 0)>(lds_cur);
-      w[set][1] = lds_read_frag<Off::at(s + SETS, 1)>(lds_cur);
-    } else if constexpr (CONTINUE) {
-      w[set][0] = lds_read_frag<OffNext::at(s + SETS - NSTEPS, 0)>(lds_next);
-      w[set][1] = lds_read_frag<OffNext::at(s + SETS - NSTEPS, 1)>(lds_next);
-    }
   });
 }
 

@@ -6,17 +6,11 @@
 
 #include "opk_common.hip.h"
 
-// Measurement-only switches (microbench/rowgemm_ablate.hip compiles this header with one of them defined to price a
-// component of the chunk loop; results are wrong with any of them set, the library never defines them):
-//   OPK_ABL_NO_BARRIER   no block barrier per chunk        OPK_ABL_NO_STORE   epilogue stores dropped
-//   OPK_ABL_NO_GELU      GELU replaced by the identity     OPK_ABL_NO_DMA     no weight DMA inside the loop
-//   OPK_ABL_NO_EPILOGUE  the deferred epilogue is skipped  OPK_ABL_NO_PHASE1  phase 1 (x += A1 W1^T) skipped
-#ifndef OPK_PREFETCH
-#define OPK_PREFETCH 0  // whole-layer kernel: operands touched ahead (bit 0: o, bit 1: x), 0 = off; see macro()
-#endif
-#ifndef OPK_PF_STRIDE
-#define OPK_PF_STRIDE 256
-#endif
+// Measurement hooks (microbench/rowgemm_ablate.hip compiles this header with them; the library never defines them):
+//   OPK_TIMING / OPK_SEG_TIMING  cycle stamps of wave 0 at the phase boundaries (instrumentation only)
+//   OPK_ABL_NO_DMA, OPK_ABL_NO_BARRIER, OPK_ABL_NO_MLP_VALU  price one component of the loops (results are wrong)
+// Experiments that did not ship (ring stream without a drain at the stage boundary, operand prefetch, the first
+// LayerNorm form, store / epilogue ablations) are recorded with their numbers in DESIGN.md section 4 and profiles/r0*.
 namespace opk {
 
 // ----------------------------------------------------------------------------------------------
@@ -439,11 +433,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   // LDS.  Read from global memory inside the LayerNorm they were 32 L2 round trips per block issued just in time
   // (the compiler cannot hoist them over the asm fences), each behind an in-order vmcnt wait that also waited for the
   // write acknowledgements of the residual rows stored just before: 16 k of a block's 252 k cycles per LayerNorm.
-#ifdef OPK_LN_V1
-  constexpr bool LN_V2 = false;
-#else
   constexpr bool LN_V2 = PRO == RP_MLP;
-#endif
   static_assert(!F8 || LN_V2, "f16 + fp8 kernel set: LayerNorm phases of the whole-layer kernel");
   constexpr bool FIN_HEAD = LN_V2 && EPI == RE_NONE;  // (run-time switch: p.fin_ln)
   __shared__ __attribute__((aligned(16))) float sLn[LN_V2 ? (FIN_HEAD ? 4 : 2) * KS * 32 : 4];
@@ -772,11 +762,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         }
         __syncthreads();
       };
-  #ifdef OPK_ABL_NO_PHASE1
-      for (int k0 = 0; k0 < 0; k0 += 2) {
-  #else
       for (int k0 = 0; k0 < nks1; k0 += 2) {  // even number of k-steps (checked on the host)
-  #endif
         slab_step(k0, std::integral_constant<int, 0>{});
         slab_step(k0 + 1, std::integral_constant<int, 1>{});
       }
@@ -1151,6 +1137,15 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(a_lo[mf][ks]));
       }
+      // bf16-valued weights: the fp16 fragments of the normalised rows go to the accumulator file as well (an MFMA takes
+      // A / B from either): 64 more VGPRs for the riders of the loop (MLP loop 122.6 k -> 119.8 k cycles per tile).  The
+      // fp32-valued kernel has no room for them there (its e4m3 copies of the rows live in AGPRs already).
+      if constexpr (F8 == 1) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(a_hi[mf][ks]));
+      }
 
       f32x4 acc_b[2][MF];  // accumulators of the pair's second chunk: [input | gate] fragment x row fragment
       uint2 hold_hi[MF], hold_lo[MF];
@@ -1181,15 +1176,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         });
         return;
 #endif
-#if defined(OPK_ABL_NO_GELU) || defined(OPK_ABL_NO_EPILOGUE)
-        static_for<VPS>([&](auto j_tag) {
-          constexpr int i = sl * VPS + decltype(j_tag)::value;
-          if constexpr (i < NV) {
-            gv[i >> 2][i & 3] = av[0][i >> 2][i & 3] * av[1][i >> 2][i & 3];
-            if constexpr ((i & 3) == 3) pack(std::integral_constant<int, (i >> 2)>{});
-          }
-        });
-#else
         // Stage-major: slice sl advances ALL NV values of the chunk by 8 / KS stages of gelu(input) * gate (five
         // polynomial FMAs, exp2, the final FMA, the product with the gate + split / pack), so consecutive vector
         // instructions belong to different values: no instruction waits for the one issued just before it.
@@ -1215,7 +1201,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           });
           if constexpr (st == 7) static_for<MF>([&](auto mf_tag) { pack(mf_tag); });
         });
-#endif
       };
       // The same GeGLU as micro-operations [B, E) of its stage-major list (operation o = stage o / NV of value o % NV, 8 NV
       // in all; the pack follows the last one): the F8 stream spreads a chunk's GeGLU evenly over ALL steps of the next
@@ -1260,15 +1245,77 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         if constexpr (F8) split4_f16(g_cur[mf], hold_hi[mf], hold_lo[mf]);
         else split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
       };
-      auto chunk_step = [&](f32x4 (&acc)[2][MF], auto ks_tag, const bf16x8& w0, const bf16x8& w1) {
+      // The GeGLU of one chunk + the split / pack of its values as ONE list of RB_OPS = 9 NV micro-operations, so that it
+      // can be cut anywhere (OPK_X_REBAL spreads it over the steps that follow the chunk in proportion to their MFMA pipe
+      // time): operations [0, 7 NV) = stages 0..6 of value o % NV; then per row fragment mf: 4 x (stage 7 = the product
+      // with the gate) and 4 pack sub-operations (hi pair | lo parts 0, 1 | lo parts 2, 3 | lo pair + commit).
+      // IS_H: the chunk closes the pair (pack_h: h fragments from the held first half), else pack_hold.
+      constexpr int RB_OPS = 9 * MF * 4;
+      uint2 pk_hi[MF];
+      float pk_d[MF][4];
+      auto geglu_ops72 = [&](const f32x4 (&av)[2][MF], float (&gv)[MF][4], auto begin_tag, auto end_tag, auto is_h_tag) {
+        constexpr int B = decltype(begin_tag)::value, E = decltype(end_tag)::value;
+        constexpr bool IS_H = decltype(is_h_tag)::value;
+#ifdef OPK_ABL_NO_MLP_VALU
+        if constexpr (E > B && E == RB_OPS) {
+          asm volatile("" ::"v"(av[0][0]), "v"(av[1][0]), "v"(av[0][1]), "v"(av[1][1]));
+          if constexpr (IS_H) asm volatile("" : "+v"(h_hi[0]), "+v"(h_lo[0]), "+v"(h_hi[1]), "+v"(h_lo[1]));
+        }
+        return;
+#endif
+        static_for<(E > B ? E - B : 0)>([&](auto o_tag) {
+          constexpr int o = B + decltype(o_tag)::value;
+          if constexpr (o < 7 * NV) {
+            constexpr int st = o / NV, i = o % NV, mf = i >> 2, r = i & 3;
+            if constexpr (st == 0) {
+              gx[i] = av[0][mf][r];
+              gq[i] = gelu_erf_poly(0.f, fabsf(gx[i]), 0);
+            } else if constexpr (st < 5) {
+              gq[i] = gelu_erf_poly(gq[i], fabsf(gx[i]), st);
+            } else if constexpr (st == 5) {
+              gq[i] = __builtin_amdgcn_exp2f(gq[i]);
+            } else {
+              gq[i] = gelu_erf_finish(gq[i], gx[i]);
+            }
+          } else {
+            constexpr int q = o - 7 * NV, mf = q / 8, u = q % 8;
+            if constexpr (u < 4) {
+              gv[mf][u] = gq[4 * mf + u] * av[1][mf][u];
+            } else if constexpr (u == 4) {
+              pk_hi[mf].x = pack_f16x2(gv[mf][0], gv[mf][1]);
+              pk_hi[mf].y = pack_f16x2(gv[mf][2], gv[mf][3]);
+            } else if constexpr (u == 5) {
+              pk_d[mf][0] = sub_f16_half<0>(gv[mf][0], pk_hi[mf].x);
+              pk_d[mf][1] = sub_f16_half<1>(gv[mf][1], pk_hi[mf].x);
+            } else if constexpr (u == 6) {
+              pk_d[mf][2] = sub_f16_half<0>(gv[mf][2], pk_hi[mf].y);
+              pk_d[mf][3] = sub_f16_half<1>(gv[mf][3], pk_hi[mf].y);
+            } else {
+              const uint2 lo = make_uint2(pack_f16x2(pk_d[mf][0], pk_d[mf][1]), pack_f16x2(pk_d[mf][2], pk_d[mf][3]));
+              if constexpr (IS_H) {
+                h_hi[mf] = as_frag(make_uint4(hold_hi[mf].x, hold_hi[mf].y, pk_hi[mf].x, pk_hi[mf].y));
+                h_lo[mf] = as_frag(make_uint4(hold_lo[mf].x, hold_lo[mf].y, lo.x, lo.y));
+              } else {
+                hold_hi[mf] = pk_hi[mf];
+                hold_lo[mf] = lo;
+              }
+            }
+          }
+        });
+      };
+      auto no_rd = [](auto, f32x4&) {};
+      auto chunk_step = [&](f32x4 (&acc)[2][MF], auto ks_tag, const bf16x8& w0, const bf16x8& w1, auto&& rd) {
         constexpr int ks = decltype(ks_tag)::value;
         // the first MFMA of an accumulator takes the constant 0 as its C operand (no zero-fill of the registers)
         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (F8) {  // fp16 product only; the e4m3 lo product follows in chunk_step8
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) acc[0][mf] = mfma16h(w0, a_hi[mf][ks], ks == 0 ? zero : acc[0][mf]);
+          rd(std::integral_constant<int, 0>{}, acc[0][0]);
+          acc[1][0] = mfma16h(w1, a_hi[0][ks], ks == 0 ? zero : acc[1][0]);
+          rd(std::integral_constant<int, 1>{}, acc[0][MF - 1]);
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16h(w1, a_hi[mf][ks], ks == 0 ? zero : acc[1][mf]);
+          for (int mf = 1; mf < MF; ++mf) acc[1][mf] = mfma16h(w1, a_hi[mf][ks], ks == 0 ? zero : acc[1][mf]);
           return;
         }
         if (A_LOW) {
@@ -1283,19 +1330,24 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16(w1, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[1][mf]);
       };
       // F8: lo(LN(x)) x Wi as e4m3, fragment nf of the chunk, K-step s8: (w0, w1) are the fragment's two halves
-      auto chunk_step8 = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1) {
+      auto chunk_step8 = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1, auto&& rd) {
         constexpr int nf = decltype(nf_tag)::value, s8 = decltype(s8_tag)::value;
         const i32x8 w8 = f8_frag(w0, w1);
+        acc[nf][0] = mfma8<true>(w8, a_lo8[0][s8 < NS8 ? s8 : 0], acc[nf][0]);
+        rd(std::integral_constant<int, 0>{}, acc[nf][0]);
+        rd(std::integral_constant<int, 1>{}, acc[nf][0]);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = mfma8<true>(w8, a_lo8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
+        for (int mf = 1; mf < MF; ++mf) acc[nf][mf] = mfma8<true>(w8, a_lo8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
       };
-      auto slab_pair = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1) {
+      auto slab_pair = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1, auto&& rd) {
         constexpr int nf = decltype(nf_tag)::value;
         if constexpr (F8) {  // h: (hi, lo) fp16 pair, both on the fp16 shape (K = 32 per step is too short for the fp8 one)
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_lo[mf], acc1[nf][mf]);
+          rd(std::integral_constant<int, 0>{}, acc1[nf][0]);
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16h(w1, h_lo[mf], acc1[nf + 1][mf]);
+          rd(std::integral_constant<int, 1>{}, acc1[nf + 1][0]);
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_hi[mf], acc1[nf][mf]);
 #pragma unroll
@@ -1316,16 +1368,21 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       // WLO: e4m3(LN(x)) x lo(Wi), and one output fragment of the slab with all three terms:
       //   lo(h) x Wo, h x lo(Wo) (w1 = that plane's fragment: unscaled fp16, see pack_kstream_f8_kernel) and h x Wo, all
       //   on the fp16 shape
-      auto chunk_step8w = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1) {
+      auto chunk_step8w = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1, auto&& rd) {
         constexpr int nf = decltype(nf_tag)::value, s8 = decltype(s8_tag)::value;
         const i32x8 w8 = f8_frag(w0, w1);
+        acc[nf][0] = mfma8w<false>(w8, a_h8[0][s8 < NS8 ? s8 : 0], acc[nf][0]);
+        rd(std::integral_constant<int, 0>{}, acc[nf][0]);
+        rd(std::integral_constant<int, 1>{}, acc[nf][0]);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = mfma8w<false>(w8, a_h8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
+        for (int mf = 1; mf < MF; ++mf) acc[nf][mf] = mfma8w<false>(w8, a_h8[mf][s8 < NS8 ? s8 : 0], acc[nf][mf]);
       };
-      auto slab_one = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1) {
+      auto slab_one = [&](auto nf_tag, const bf16x8& w0, const bf16x8& w1, auto&& rd) {
         constexpr int nf = decltype(nf_tag)::value;
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w0, h_lo[mf], acc1[nf][mf]);
+        rd(std::integral_constant<int, 0>{}, acc1[nf][0]);
+        rd(std::integral_constant<int, 1>{}, acc1[nf][MF - 1]);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16h(w1, h_hi[mf], acc1[nf][mf]);
 #pragma unroll
@@ -1350,23 +1407,28 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         }
       };
       constexpr int DEPTH = 2;  // fragment groups in flight ahead of the one being consumed (a step = 8 MFMAs)
-#ifndef OPK_F8_DEPTH
-#define OPK_F8_DEPTH 4
-#endif
-      constexpr int DEPTH8 = OPK_F8_DEPTH;  // F8: a chunk step is 4 fp16 / 2 e4m3 MFMAs = half the pipe time, twice the steps ahead
+      constexpr int DEPTH8 = 4;  // F8: a chunk step is 4 fp16 / 2 e4m3 MFMAs = half the pipe time, twice the steps ahead
       // The stage index is a RUNTIME value here (one copy of the loop body): the fragment reads are inline asm with
       // the stage's base address in a register, so the compiler has no DMA-vs-read aliasing to resolve, and a body
       // unrolled by two would permute the 128 accumulator registers between its copies on every back edge.
-      // F8 (bf16-valued weights): the fragment-read pipeline is NOT drained at the stage boundary (frag_stream2_ring):
-      // `last_tag` = the unit after this one is the tail slab, not another macro-iteration
-      struct TailOff8 {
-        static constexpr int at(int s, int j) { return 2 * F8Chunk<KS>::BYTES + (s * 2 + j) * 1024; }
-      };
-      constexpr int RING_SETS = 4;
-      bf16x8 wq[RING_SETS][2];
-      auto macro = [&](int t, int cur, auto slab_tag, auto last_tag) {
+      // Riders (round 4).  A wave that is alone on its SIMD issues ONE instruction per four cycles, in order: a 16-cycle
+      // MFMA leaves three slots behind it for everything else of the step (vector instructions, fragment reads, the DMA,
+      // waits), a 32-cycle e4m3 MFMA seven.  So the GeGLU of a chunk is cut into RB_OPS micro-operations (geglu_ops72) and
+      // spread in proportion to MFMA pipe time over the units of 64 cycles that FOLLOW the chunk.  bf16-valued weights
+      // (20 units) -- chunk 2t: the 12 steps of chunk 2t+1 and the first half of the slab steps; chunk 2t+1: the second half and the 12
+      // steps of the NEXT iteration's chunk 2t+2 (its accumulators cross the back edge as VGPR values, nbv): 3.6 operations
+      // per unit where the stream had 0 on chunk 2t, 5.3 + the accumulator reads on chunk 2t+1 and 4 + the pack on the
+      // slab; MLP loop 125.5 k -> 118.0 k cycles per tile.  fp32-valued weights (28 units): see half_iter.
+      // (hidden 256: 12 chunk steps + 8 slab steps of two units = 20 units, fp32-valued weights 16 + 8 x 1.5 = 28; hidden
+      // 128: half of each)
+      constexpr int RB_CS = F8 ? F8Chunk<KS, WLO>::STEPS : KS;  // chunk steps = units per chunk
+      constexpr int RB_NSL = NF1 / 2;                            // slab steps (per half-iteration with fp32-valued weights)
+      constexpr int RB_UNITS = WLO ? RB_CS + 3 * RB_NSL / 2 : RB_CS + RB_NSL;
+      f32x4 nbv[2][MF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) nbv[0][mf] = nbv[1][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto macro = [&](int t, int cur, auto slab_tag) {
         constexpr bool SLAB = decltype(slab_tag)::value;  // false only for t = 0
-        constexpr bool LAST = decltype(last_tag)::value;
         using Off = MlpStreamOff<KS, NF1, SLAB>;
         constexpr int NS = Off::NS;
         // The next stage's DMA instructions are spread over the first steps of the stream, one per step: issued in
@@ -1374,49 +1436,19 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         // na: chunk 2t, written by its first k-step (C operand = 0).  Chunk 2t+1 accumulates straight into acc_b: the
         // GeGLU of chunk 2t-1 (the last reader of acc_b's old contents) is over after the first KS steps.
         f32x4 na[2][MF];
-#if OPK_PREFETCH
-        // Experiment kept behind OPK_PREFETCH (default 0).  Every CU of the chip starts a tile at the same time and the
-        // operand fetch that opens it is a 64 MB burst (29 k of a tile's 245 k cycles, 8 k of them MFMAs) while HBM
-        // idles during the MLP; so each macro-iteration can touch one dword per 64 B of a slice of the attention
-        // output `o` (bit 0) / the residual rows (bit 1) of the tile OPK_PF_STRIDE blocks ahead (the block the
-        // dispatcher hands to this XCD a round later, as observed).  Measured: the isolated launch gains 1.3 % (fetch
-        // phase 29.0 k -> 23.8 k cycles), the whole forward LOSES 0.9 % (same-box A/B, three alternations): an XCD's
-        // 4 MB of L2 cannot hold the 8 MB its CUs touch per round, FETCH_SIZE of the launch doubles (352 -> 714 MB),
-        // and in the sustained run that traffic costs more of the power budget than the shorter phase returns.
-        unsigned pf_dummy;
-        {
-          const int blk = (int)blockIdx.x + OPK_PF_STRIDE < (int)gridDim.x ? (int)blockIdx.x + OPK_PF_STRIDE : (int)blockIdx.x;
-          const size_t tile = (size_t)blk * (WAVES * 16 * MF);
-          const char* o_base = reinterpret_cast<const char*>(p.a1_fp + (tile >> 4) * (size_t)p.k1_steps * 2 * 512);
-          const char* x_base = reinterpret_cast<const char*>(p.x_io + tile * K);
-          constexpr int PER_WAVE = 16 * MF * K * 4;  // bytes of either operand per wave
-          constexpr int NI = PER_WAVE / 4096;        // instructions to touch it
-          const int t_eff = t;
-          const int j = OPK_PREFETCH == 3 ? (t_eff % (2 * NI)) : (t_eff % NI);
-          const bool use_x = OPK_PREFETCH == 2 || (OPK_PREFETCH == 3 && j >= NI);
-          const char* src = (use_x ? x_base : o_base) + (size_t)wave * PER_WAVE + (size_t)(j % NI) * 4096 + lane * 64;
-          asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(src));
-        }
-#endif
         if constexpr (F8) {
-          // F8 stream order: chunk 2t -> na | chunk 2t+1 -> nb, GeGLU(2t) riding on its steps | slab t-1 (h of pair
-          // t-1 from the previous iteration), GeGLU(2t+1) riding on its steps and closing h of pair t.  No chunk
-          // accumulator crosses the back edge (only the 16 registers of h do): with one that did, the register
-          // allocator moved accumulators through VGPRs on every iteration (40 of 72 v_accvgpr moves, ~8 cycles each).
+          // F8 stream order: chunk 2t -> na | chunk 2t+1 -> nb | slab t-1 (h of pair t-1), riders as above.  A finished
+          // chunk leaves the accumulator file ONCE ("+v"): left to the register allocator, the MFMA destinations of
+          // the next chunk landed on tiles of acc1 and those were saved and restored through VGPRs on every iteration
+          // (64 v_accvgpr moves per iteration, 32 of them shuffles; 32 now).
           using Off8 = MlpStreamOff8<KS, NF1, SLAB>;
           using C8 = F8Chunk<KS>;
           constexpr int CS = C8::STEPS;
           f32x4 nb[2][MF];
           constexpr int NSTEPS8 = 2 * CS + NS;
-          auto unit_body = [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+          auto unit_body = [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&&... rd_opt) {
             constexpr int s = decltype(step_tag)::value;
-#ifdef OPK_RING_STREAM
-            // step 0: every wave is past the unit that lived in the other stage -> its DMA may start;
-            // step NSTEPS8 - RING_SETS: this wave's share of the next unit has landed, then all waves meet -- the reads of
-            // the next unit's first steps follow this step
-            if constexpr (s == 0) asm volatile("s_barrier" ::: "memory");
-            if constexpr (s == NSTEPS8 - RING_SETS) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
+            auto&& rd = rd_or(no_rd, rd_opt...);
 #ifdef OPK_SEG_TIMING  // cycles of the three segments of an iteration (chunk 2t | chunk 2t+1 + GeGLU | slab + GeGLU)
             if constexpr (s == 0 || s == CS || s == 2 * CS) {
               const unsigned long long now = __builtin_readcyclecounter();
@@ -1431,34 +1463,53 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
               constexpr bool FIRST_CHUNK = s < CS;
               constexpr int cs = FIRST_CHUNK ? s : s - CS;
               auto& acc = *(FIRST_CHUNK ? &na : &nb);
-              if constexpr (!C8::is_f8(cs)) chunk_step(acc, std::integral_constant<int, C8::ks(cs)>{}, w0, w1);
-              else chunk_step8(acc, std::integral_constant<int, C8::nf(cs)>{}, std::integral_constant<int, C8::s8(cs)>{}, w0, w1);
-              if constexpr (!FIRST_CHUNK) {  // GeGLU(2t), evenly over the steps of chunk 2t+1
-                constexpr int OB = cs * 8 * NV / CS, OE = (cs + 1) * 8 * NV / CS;
-                geglu_ops(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_hold);
+              if constexpr (!C8::is_f8(cs)) chunk_step(acc, std::integral_constant<int, C8::ks(cs)>{}, w0, w1, rd);
+              else chunk_step8(acc, std::integral_constant<int, C8::nf(cs)>{}, std::integral_constant<int, C8::s8(cs)>{}, w0, w1, rd);
+              if constexpr (!FIRST_CHUNK && cs == CS - 1) {  // chunk 2t+1 is complete: it crosses the back edge in VGPRs
+#pragma unroll
+                for (int nf_ = 0; nf_ < 2; ++nf_)
+#pragma unroll
+                  for (int mf_ = 0; mf_ < MF; ++mf_) {
+                    nbv[nf_][mf_] = nb[nf_][mf_];
+                    asm volatile("" : "+v"(nbv[nf_][mf_]));
+                  }
+              }
+              if constexpr (FIRST_CHUNK && cs == CS - 1) {
+#pragma unroll
+                for (int nf_ = 0; nf_ < 2; ++nf_)
+#pragma unroll
+                  for (int mf_ = 0; mf_ < MF; ++mf_) asm volatile("" : "+v"(na[nf_][mf_]));
+              }
+              if constexpr (!FIRST_CHUNK) {  // GeGLU(2t): units 0..11 of its 20 (t = 0: all of it, there is no slab to ride on)
+                constexpr int OB = SLAB ? cs * RB_OPS / RB_UNITS : cs * RB_OPS / CS, OE = SLAB ? (cs + 1) * RB_OPS / RB_UNITS : (cs + 1) * RB_OPS / CS;
+                geglu_ops72(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, no_);
+              } else if constexpr (SLAB) {  // GeGLU(2t-1) of the previous iteration: units 8..19 of its 20
+                constexpr int OB = (RB_NSL + cs) * RB_OPS / RB_UNITS, OE = (RB_NSL + cs + 1) * RB_OPS / RB_UNITS;
+                geglu_ops72(nbv, g_prev, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, yes_);
               }
               if constexpr (!C8::is_f8(cs)) interleave_n(std::integral_constant<int, 2 * MF>{}, std::integral_constant<int, 2>{});
-              else interleave_n(std::integral_constant<int, MF>{}, std::integral_constant<int, 5>{});
-            } else {  // slab t-1, with the GeGLU of chunk 2t+1
-              slab_pair(std::integral_constant<int, 2 * (s - 2 * CS)>{}, w0, w1);
-              geglu_slice(nb, g_prev, std::integral_constant<int, s - 2 * CS>{}, pack_h);
-              interleave_n(std::integral_constant<int, 4 * MF>{}, std::integral_constant<int, 3>{});
+              else interleave_n(std::integral_constant<int, MF>{}, std::integral_constant<int, 4>{});
+            } else {  // slab t-1: steps 0..3 carry units 12..19 of GeGLU(2t), steps 4..7 units 0..7 of GeGLU(2t+1)
+              constexpr int i = s - 2 * CS;
+              slab_pair(std::integral_constant<int, 2 * i>{}, w0, w1, rd);
+              if constexpr (i < RB_NSL / 2) {
+                constexpr int OB = (RB_CS + 2 * i) * RB_OPS / RB_UNITS, OE = (RB_CS + 2 * i + 2) * RB_OPS / RB_UNITS;
+                geglu_ops72(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, no_);
+              } else {
+                constexpr int OB = (2 * (i - RB_NSL / 2)) * RB_OPS / RB_UNITS, OE = (2 * (i - RB_NSL / 2) + 2) * RB_OPS / RB_UNITS;
+                geglu_ops72(nbv, g_prev, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, yes_);
+              }
+              interleave_n(std::integral_constant<int, 4 * MF>{}, std::integral_constant<int, 2>{});
             }
           };
-#ifdef OPK_RING_STREAM
-          {
-            const uint32_t base_cur = cur ? lds_stage[1] : lds_stage[0], base_next = cur ? lds_stage[0] : lds_stage[1];
-            using OffNextSlab = MlpStreamOff8<KS, NF1, true>;
-            if constexpr (LAST) frag_stream2_ring<NSTEPS8, RING_SETS, Off8, TailOff8, !SLAB, true>(base_cur, base_next, wq, unit_body);
-            else frag_stream2_ring<NSTEPS8, RING_SETS, Off8, OffNextSlab, !SLAB, true>(base_cur, base_next, wq, unit_body);
-          }
-#else
+          // (reads between the MFMAs, frag_stream2i, are 5 % faster on the bare stream here too, but with the riders placed
+          // by sched_group_barrier they measure +5 % SLOWER, and equal without the barriers: this form stays)
           frag_stream2<NSTEPS8, DEPTH8, Off8>(cur ? lds_stage[1] : lds_stage[0], unit_body);
-#endif
 #ifdef OPK_SEG_TIMING
           opk_seg[2] += __builtin_readcyclecounter() - opk_seg_t;
 #endif
-          if constexpr (!SLAB) static_for<KS>([&](auto sl) { geglu_slice(nb, g_prev, sl, pack_h); });  // first pair: no slab to ride on
+          if constexpr (!SLAB)  // first pair: the slab-borne units 0..7 of GeGLU(1) have no slab to ride on
+            geglu_ops72(nbv, g_prev, std::integral_constant<int, 0>{}, std::integral_constant<int, RB_NSL * RB_OPS / RB_UNITS>{}, yes_);
         } else
         frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int s = decltype(step_tag)::value;
@@ -1466,27 +1517,21 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
 #endif
           if constexpr (s < KS) {  // chunk 2t, with the GeGLU of chunk 2t-1 (-> h of pair t-1 ready for the slab)
-            chunk_step(na, std::integral_constant<int, s>{}, w0, w1);
+            chunk_step(na, std::integral_constant<int, s>{}, w0, w1, no_rd);
             if constexpr (SLAB) geglu_slice(acc_b, g_prev, std::integral_constant<int, s>{}, pack_h);
           } else if constexpr (s < KS + NS) {  // slab t-1, with the GeGLU of chunk 2t
-            slab_pair(std::integral_constant<int, 2 * (s - KS)>{}, w0, w1);
+            slab_pair(std::integral_constant<int, 2 * (s - KS)>{}, w0, w1, no_rd);
             geglu_slice(na, g_cur, std::integral_constant<int, s - KS>{}, pack_hold);
           } else {  // chunk 2t+1 (t = 0: with the GeGLU of chunk 0)
-            chunk_step(acc_b, std::integral_constant<int, s - KS - NS>{}, w0, w1);
+            chunk_step(acc_b, std::integral_constant<int, s - KS - NS>{}, w0, w1, no_rd);
             if constexpr (!SLAB) geglu_slice(na, g_cur, std::integral_constant<int, s - KS>{}, pack_hold);
           }
           interleave_step();
         });
-#ifdef OPK_RING_STREAM
-        if constexpr (F8) return;  // (its two barriers sit inside the unit: no drain here)
-#endif
 #ifdef OPK_TIMING
         const unsigned long long opk_w0 = __builtin_readcyclecounter();
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (no other VMEM in this loop)
-#if OPK_PREFETCH
-        asm volatile("" ::"v"(pf_dummy));
-#endif
 #ifndef OPK_ABL_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
@@ -1516,30 +1561,55 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           // tail: the stream is shorter than the DMA list -- the first tail half requests the last slab half up front,
           // the second one has nothing left to request
           if constexpr (!CHUNK && hb == 0) static_for<UNIT_DMA>([&](auto u) { stage_piece_w(u, c + 1, hb ^ 1); });
-          frag_stream2<CS + NSH - S0, DEPTH8, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
+#ifndef OPK_WLO_ILV
+#define OPK_WLO_ILV 2  // fragment groups in flight with the reads between the MFMAs (0: reads behind the step, DEPTH8 ahead)
+#endif
+#if OPK_WLO_ILV == 0
+          frag_stream2<CS + NSH - S0, DEPTH8, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&&... rd_opt) {
+#else
+          frag_stream2i<CS + NSH - S0, OPK_WLO_ILV, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&&... rd_opt) {
+#endif
+            auto&& rd = rd_or(no_rd, rd_opt...);
             constexpr int sr = decltype(step_tag)::value, st = sr + S0;
 #ifndef OPK_ABL_NO_DMA
             if constexpr (CHUNK && sr < UNIT_DMA) stage_piece_w(step_tag, c + 1, hb ^ 1);
 #endif
             if constexpr (st < CS) {
               auto& acc = *(hb == 0 ? &na : &nb);
-              if constexpr (!C8::is_f8(st)) chunk_step(acc, std::integral_constant<int, C8::ks(st)>{}, w0, w1);
-              else if constexpr (!C8::is_wlo(st)) chunk_step8(acc, std::integral_constant<int, C8::nf(st)>{}, std::integral_constant<int, C8::s8(st)>{}, w0, w1);
-              else chunk_step8w(acc, std::integral_constant<int, C8::nf(st)>{}, std::integral_constant<int, C8::s8(st)>{}, w0, w1);
-              if constexpr (hb == 1) {  // second half of GeGLU(2t), evenly over the chunk's steps
-                constexpr int OB = 4 * NV + st * 4 * NV / CS, OE = 4 * NV + (st + 1) * 4 * NV / CS;
-                geglu_ops(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_hold);
+              if constexpr (!C8::is_f8(st)) chunk_step(acc, std::integral_constant<int, C8::ks(st)>{}, w0, w1, rd);
+              else if constexpr (!C8::is_wlo(st)) chunk_step8(acc, std::integral_constant<int, C8::nf(st)>{}, std::integral_constant<int, C8::s8(st)>{}, w0, w1, rd);
+              else chunk_step8w(acc, std::integral_constant<int, C8::nf(st)>{}, std::integral_constant<int, C8::s8(st)>{}, w0, w1, rd);
+              // Riders in proportion to pipe time: a chunk step is one unit of 64 cycles, a slab step (6 MFMAs) 1.5.  The
+              // GeGLU of chunk 2t rides on the 12 + 16 units that follow it (slab half 0, chunk 2t+1): 2.6 operations per
+              // unit where it had 4 per slab step and 3 per chunk step.  A finished chunk leaves the accumulator file once.
+              if constexpr (st == CS - 1) {
+#pragma unroll
+                for (int nf_ = 0; nf_ < 2; ++nf_)
+#pragma unroll
+                  for (int mf_ = 0; mf_ < MF; ++mf_) {
+                    if constexpr (hb == 1) nbv[nf_][mf_] = nb[nf_][mf_];
+                    asm volatile("" : "+v"((hb == 0 ? na : nbv)[nf_][mf_]));
+                  }
+              }
+              // Chunk 2t+1's GeGLU stays inside the iteration, all of it on slab half 1 (nothing crosses the back edge):
+              // carried into the next iteration's chunk 2t+2, as the bf16-valued kernel does, it costs this kernel -- 256
+              // VGPRs + 208 AGPRs in use -- 48 more accumulator shuffles per iteration than the emptier steps return
+              // (MLP loop 166.2 k cycles per tile before, 161.6 k this way, 173.5 k carried).  With the fragment reads
+              // between the MFMAs (frag_stream2i, two groups ahead): 154.8 k.
+              if constexpr (hb == 1) {
+                constexpr int OB = (3 * RB_NSL / 2 + st) * RB_OPS / RB_UNITS, OE = (3 * RB_NSL / 2 + st + 1) * RB_OPS / RB_UNITS;
+                geglu_ops72(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, no_);
               }
             } else {
               constexpr int i = st - CS;
-              slab_one(std::integral_constant<int, hb * NSH + i>{}, w0, w1);
-              if constexpr (CHUNK && hb == 0) {  // first half of GeGLU(2t)
-                constexpr int OB = i * 4 * NV / NSH, OE = (i + 1) * 4 * NV / NSH;
-                geglu_ops(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_hold);
+              slab_one(std::integral_constant<int, hb * NSH + i>{}, w0, w1, rd);
+              if constexpr (CHUNK && hb == 0) {
+                constexpr int OB = (3 * i / 2) * RB_OPS / RB_UNITS, OE = (3 * (i + 1) / 2) * RB_OPS / RB_UNITS;
+                geglu_ops72(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, no_);
               }
-              if constexpr (CHUNK && hb == 1) {  // GeGLU(2t+1): NSH steps carry the 8 NV operations
-                constexpr int OB = i * 8 * NV / NSH, OE = (i + 1) * 8 * NV / NSH;
-                geglu_ops(nb, g_prev, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, pack_h);
+              if constexpr (CHUNK && hb == 1) {
+                constexpr int OB = i * RB_OPS / NSH, OE = (i + 1) * RB_OPS / NSH;
+                geglu_ops72(nbv, g_prev, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, yes_);
               }
             }
           });
@@ -1560,40 +1630,24 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           half_iter(2 * n_pairs + 1, h1, no_, na, nb);
         }
       } else {
-      macro(0, 0, no_, no_);
-#ifdef OPK_RING_STREAM
-      if constexpr (F8) {  // the last iteration hands its read pipeline to the tail slab: peeled
-        if (n_pairs > 2) {
-          int t = 1;
-          do {
-            macro(t, t & 1, yes_, no_);
-          } while (++t < n_pairs - 1);
-        }
-        macro(n_pairs - 1, 1, yes_, yes_);  // (n_pairs is even)
-      } else
-#endif
+      macro(0, 0, no_);
       {  // n_pairs is even (checked on the host): at least one more iteration, and the tail reads stage 0.  Written as
         // do-while: around a loop that may run zero times the compiler parks accumulator values in scratch.
         int t = 1;
         do {
-          macro(t, t & 1, yes_, no_);
+          macro(t, t & 1, yes_);
         } while (++t < n_pairs);
       }
       }
       if constexpr (!WLO) {  // tail: the last pair's h fragments and their slab (stage 0 of the ring)
         if constexpr (!F8) static_for<KS>([&](auto sl) { geglu_slice(acc_b, g_prev, sl, pack_h); });
+        if constexpr (F8 == 1)  // units 8..19 of the last chunk's GeGLU: no next iteration to ride on
+          geglu_ops72(nbv, g_prev, std::integral_constant<int, RB_NSL * RB_OPS / RB_UNITS>{}, std::integral_constant<int, RB_OPS>{}, yes_);
         struct TailOff {
           static constexpr int at(int s, int j) { return (F8 ? 2 * F8Chunk<KS>::BYTES : 2 * KS * 2048) + (s * 2 + j) * 1024; }
         };
-#ifdef OPK_RING_STREAM
-        if constexpr (F8)
-          frag_stream2_ring<NF1 / 2, RING_SETS, TailOff8, TailOff8, false, false>(lds_stage[0], lds_stage[0], wq, [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
-            slab_pair(std::integral_constant<int, 2 * decltype(step_tag)::value>{}, w0, w1);
-          });
-        else
-#endif
         frag_stream2<NF1 / 2, DEPTH, TailOff>(lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
-          slab_pair(std::integral_constant<int, 2 * decltype(step_tag)::value>{}, w0, w1);
+          slab_pair(std::integral_constant<int, 2 * decltype(step_tag)::value>{}, w0, w1, no_rd);
         });
       }
       __builtin_amdgcn_s_barrier();  // every wave is done with the ring: the chunk loop may reuse stage 0
@@ -1762,11 +1816,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       for (int mf = 0; mf < MF; ++mf) {
         float v[4];
 #pragma unroll
-#ifdef OPK_ABL_NO_GELU
-        for (int r = 0; r < 4; ++r) v[r] = av[0][mf][r] * av[1][mf][r];
-#else
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(av[0][mf][r]) * av[1][mf][r];
-#endif
         uint2 h2, l2;
         split4<O0_LO>(v, h2, l2);
         if (PP == 0) {
@@ -1854,13 +1904,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       if (PP == 1) {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-#ifdef OPK_ABL_NO_STORE
-          asm volatile("" ::"v"(st_v[mf][0]), "v"(st_p[mf]));
-          if (O0_LO) asm volatile("" ::"v"(st_v[mf][1]));
-#else
           st16(st_p[mf], st_v[mf][0]);
           if (O0_LO) st16(st_p[mf] + 512, st_v[mf][1]);
-#endif
         }
       }
     } else if (EPI == RE_QKV) {
@@ -1929,11 +1974,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     // Nothing crosses this point: the RoPE loads stay ahead of the DMA, and the epilogue's stores stay BEHIND it --
     // the counted wait in front of the barrier below relies on that order.
     __builtin_amdgcn_sched_barrier(0);
-#ifdef OPK_ABL_NO_EPILOGUE
-    if (!FIRST) asm volatile("" ::"v"(acc_prev[0][0]), "v"(acc_prev[1][0]), "v"(acc_prev[0][MF - 1]), "v"(acc_prev[1][MF - 1]));
-#else
     if (!FIRST) epilogue(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag, acc_prev);
-#endif
 
     f32x4 acc[2][MF];
 #pragma unroll
@@ -1942,9 +1983,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (F8) rowgemm_chunk_mfma_f8<KS, MF, SW, true, WLO>(lds_stage[cur], a_hi, a_lo8, a_h8, acc);
     else rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP)>(lds_stage[cur], a_hi, a_lo, acc);
-#if !defined(OPK_ABL_NO_EPILOGUE)
     if (!FIRST) epilogue_store(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag);
-#endif
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -1978,11 +2017,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #ifdef OPK_TIMING
     const unsigned long long opk_w0 = __builtin_readcyclecounter();
 #endif
-#if defined(OPK_ABL_NO_STORE) || defined(OPK_ABL_NO_EPILOGUE) || defined(OPK_STRICT_VMCNT)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
-#endif
 #ifdef OPK_TIMING
     const unsigned long long opk_w1 = __builtin_readcyclecounter();
     opk_wait1 += opk_w1 - opk_w0;

@@ -195,6 +195,53 @@ class HipEncoder:
             "kernel_set": names.get(int(kernel_set.value), str(kernel_set.value)),
         }
 
+    # -- the range guard of the fp16 + e4m3 kernel sets ---------------------------------------------
+    def f8_active(self) -> bool:
+        """True while the forward runs on kernel sets 3 / 4 (fp16 hi + e4m3 lo operands): their fp16 plane has fp16's
+        range, and an MLP activation beyond it comes out as NaN by design (never clamped)."""
+
+        cached = self.__dict__.get("_f8_active")
+        if cached is None:
+            cached = self.__dict__["_f8_active"] = self.effective_policy()["kernel_set"] in ("f16-f8", "f16-f8-w")
+        return cached
+
+    def fall_back_from_f8(self, reason: str = "") -> bool:
+        """Switch this model to the (hi, lo) bf16 kernel sets for good (``op_set_compact_operands``: both weight packs are resident,
+        nothing is re-loaded) and warn once.  Returns True when the kernel set changed, i.e. when repeating the forward
+        can give a different answer.  The reference's own precedent for a silent, correct retry: its fallback from an
+        unsupported dtype / attention implementation at load time (standalone.py:1631-1642)."""
+
+        if not self.f8_active() or not hasattr(self.lib, "op_set_compact_operands"):
+            return False
+        changed = ctypes.c_int(0)
+        code = self.lib.op_set_compact_operands(self._handle, 0, ctypes.byref(changed))
+        _lib.check(self.lib, self._handle, code, "op_set_compact_operands")
+        self.__dict__["_f8_active"] = None
+        if changed.value:
+            import warnings
+
+            warnings.warn(
+                "open_provence_amd: a forward on the fp16 + e4m3 kernel set returned non-finite values"
+                + (f" ({reason})" if reason else "")
+                + ": an activation left fp16's range.  The batch is repeated on the (hi, lo) bf16 kernels (fp32 range) and "
+                "this model stays on them (slower: 2-3 instead of 1.5-2 MFMA products per term); set OPEN_PROVENCE_NO_F8=1 "
+                "to start there.",
+                RuntimeWarning, stacklevel=3,
+            )
+        return bool(changed.value)
+
+    def forward_packed_checked(self, ids, cu_seqlens, cu_seqlens_host, max_seqlen, keep_prob=None):
+        """``forward_packed`` + the range guard: on kernel sets 3 / 4 the outputs are tested for NaN / Inf (one device
+        reduction, one synchronisation) and a non-finite batch is repeated on the (hi, lo) bf16 sets.  On those sets
+        nothing is tested: whatever comes out is what the reference's arithmetic gives."""
+
+        prune, rank = self.forward_packed(ids, cu_seqlens, cu_seqlens_host, max_seqlen, keep_prob=keep_prob)
+        if self.f8_active():
+            ok = torch.isfinite(rank).all() & torch.isfinite(prune).all()
+            if not bool(ok.item()) and self.fall_back_from_f8("forward"):
+                prune, rank = self.forward_packed(ids, cu_seqlens, cu_seqlens_host, max_seqlen, keep_prob=keep_prob)
+        return prune, rank
+
     # -- forward ---------------------------------------------------------------------------------
     def _ensure_workspace(self, n_seqs: int, total_tokens: int, max_seqlen: int) -> torch.Tensor:
         need = int(self.lib.op_workspace_bytes(self._handle, n_seqs, total_tokens, max_seqlen))

@@ -36,7 +36,7 @@ from .config import DEFAULT_PROCESS_THRESHOLD, EncoderDims, OpenProvenceConfig
 from .engine import HipEncoder, require_gpu
 from .packing import pack_padded, pack_rows, unpack_to_padded
 from .pipeline import ContextState, FragmentRecord, RawPrediction
-from .splitters import SentenceSplitter, resolve_sentence_splitter
+from .splitters import SentenceSplitter, is_builtin_splitter, resolve_sentence_splitter
 
 LOGGER = logging.getLogger(__name__)
 # As the reference (standalone.py:160), the Rust tokenizer's own thread pool is off unless the environment says otherwise.
@@ -491,7 +491,8 @@ class OpenProvenceModel:
         dev = self._runtime_device
         ids = torch.from_numpy(ids_np).to(dev)
         cu = torch.from_numpy(cu_np).to(dev)
-        prune, rank = self.encoder.forward_packed(ids, cu, cu_np, max_len)
+        # (the fp16 + e4m3 kernel sets are range-guarded: a non-finite result is repeated on the (hi, lo) bf16 sets)
+        prune, rank = self.encoder.forward_packed_checked(ids, cu, cu_np, max_len)
         pruning_logits = unpack_to_padded(prune, cu_np, width)
         if return_dict is not None and not return_dict:
             return (rank, pruning_logits)
@@ -648,12 +649,22 @@ class OpenProvenceModel:
             rows = [rows[i] for i in mine]
             if segments is not None:
                 segments = [segments[i] for i in mine]
+        handle = self._enqueue_local(rows, segments)
+        handle["shard"] = shard
+        return handle
+
+    def _enqueue_local(self, rows: list[list[int]], segments: list[list[tuple[int, int]]] | None) -> dict[str, Any]:
+        """The launch of :meth:`_launch_rows` for THIS process's rows (also what the range guard of the fp16 + e4m3 kernel
+        sets repeats, see :meth:`_guard_launch`)."""
+
+        shard = None
+        retry = (rows, segments)
         ids_np, cu_np, max_len = pack_rows(rows)
         self.encoder.check_ids(ids_np)
         total, n_rows, nl = int(cu_np[-1]), len(rows), int(self.dims.num_labels)
         if n_rows == 0:  # (more ranks than rows) nothing to enqueue here; the gather still runs on every rank
             return {"event": None, "pool": None, "total": 0, "rows": 0, "cu": cu_np, "seg_counts": [] if segments is not None else None,
-                    "alive": None, "shard": shard}
+                    "alive": None, "shard": shard, "retry": None}
         slot = self.__dict__["_staging_slot"] = (self.__dict__.get("_staging_slot", -1) + 1) % 2
         pool = self._staging(slot, total, n_rows)
         dev = self._runtime_device
@@ -690,7 +701,31 @@ class OpenProvenceModel:
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev))
         return {"event": event, "pool": pool, "total": total, "rows": n_rows, "cu": cu_np, "seg_counts": seg_counts,
-                "alive": (ids_dev, cu_dev, keep_dev, rank_dev, seg_dev, means_dev), "shard": shard}
+                "alive": (ids_dev, cu_dev, keep_dev, rank_dev, seg_dev, means_dev), "shard": shard, "retry": retry,
+                "f8": self.encoder.f8_active()}
+
+    def _guard_launch(self, handle: dict[str, Any]) -> dict[str, Any]:
+        """Range guard of the fp16 + e4m3 kernel sets for a pipelined launch (the launch has completed): when its
+        results -- fragment means or keep-probabilities, ranking logits -- are not finite and it ran on those sets, the
+        model falls back to the (hi, lo) bf16 sets (``HipEncoder.fall_back_from_f8``: warn once, stay there) and THIS
+        launch is repeated synchronously; the handle of the repeat is returned.  Launches already in flight are guarded
+        the same way when they are collected.  On the bf16 sets nothing is tested (reference arithmetic, fp32 range)."""
+
+        if not handle.get("f8") or handle.get("retry") is None or handle["rows"] == 0:
+            return handle
+        pool, nl = handle["pool"], int(self.dims.num_labels)
+        n_val = sum(handle["seg_counts"]) if handle["seg_counts"] is not None else handle["total"]
+        if np.isfinite(pool["keep_np"][:n_val]).all() and np.isfinite(pool["rank_np"][: handle["rows"] * nl]).all():
+            return handle
+        self.encoder.fall_back_from_f8("process")
+        if self.encoder.f8_active():
+            return handle  # (nothing to fall back to: the caller reports the NaN)
+        rows, segments = handle["retry"]
+        handle["alive"] = None
+        again = self._enqueue_local(rows, segments)
+        again["shard"] = handle.get("shard")
+        again["event"].synchronize()
+        return again
 
     def _collect_rows(self, handle: dict[str, Any]) -> tuple[torch.Tensor, list[Any]]:
         """-> (ranking logits, per row: its keep-probabilities, or -- launched with ``segments`` -- the list of its
@@ -699,6 +734,7 @@ class OpenProvenceModel:
         if handle.get("shard") is not None:
             return self._collect_rows_sharded(handle)
         handle["event"].synchronize()
+        handle = self._guard_launch(handle)
         total, n_rows, nl, cu = handle["total"], handle["rows"], int(self.dims.num_labels), handle["cu"]
         rank = torch.from_numpy(handle["pool"]["rank_np"][: n_rows * nl].copy()).reshape(n_rows, nl)
         counts = handle.get("seg_counts")
@@ -730,6 +766,7 @@ class OpenProvenceModel:
         per_row = counts_all if counts_all is not None else lengths  # values per row in the payload
         if handle["event"] is not None:
             handle["event"].synchronize()
+            handle = self._guard_launch(handle)  # a rank repeats ITS rows before the gather: the payload is finite
         n_rows, n_val = handle["rows"], (sum(handle["seg_counts"]) if counts_all is not None else handle["total"])
         if n_rows:
             values = torch.from_numpy(handle["pool"]["keep_np"][:n_val].copy())
@@ -765,11 +802,15 @@ class OpenProvenceModel:
             # keep-probability = softmax(pruning_logits)[:, 1], evaluated by the head kernel itself (no ATen
             # arithmetic on the product path; the D2H payload is 4 B per token)
             keep_dev = torch.empty(int(cu_np[-1]), dtype=torch.float32, device=dev)
-            _, rank = self.encoder.forward_packed(
-                torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev), cu_np, max_len, keep_prob=keep_dev
-            )
+            ids_dev, cu_dev = torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev)
+            _, rank = self.encoder.forward_packed(ids_dev, cu_dev, cu_np, max_len, keep_prob=keep_dev)
             keep = keep_dev.cpu().numpy()
             rank_cpu = rank.cpu()
+            if self.encoder.f8_active() and not (np.isfinite(keep).all() and bool(torch.isfinite(rank_cpu).all())):
+                # range guard of the fp16 + e4m3 kernel sets: repeat on the (hi, lo) bf16 sets, stay there
+                if self.encoder.fall_back_from_f8("get_raw_predictions"):
+                    _, rank = self.encoder.forward_packed(ids_dev, cu_dev, cu_np, max_len, keep_prob=keep_dev)
+                    keep, rank_cpu = keep_dev.cpu().numpy(), rank.cpu()
             return rank_cpu, [keep[cu_np[i] : cu_np[i + 1]] for i in range(len(rows))]
 
         pad_raw = getattr(self.tokenizer, "pad_token_id", None)
@@ -1141,11 +1182,16 @@ class OpenProvenceModel:
                 t_frag = perf_counter() - t4
             return jobs, (t_collect, t_norm, t3 - t2, t_frag)
 
+        # With worker threads the per-stage seconds are summed over threads that run side by side: they are scaled by
+        # 1 / workers so that the trace's stage timers add up to wall-clock seconds of the stage (what the reference's
+        # single-thread timers mean), never to more than the call took.
+        share = 1.0 / max(1, int(workers))
+
         def account(times):
-            timing["sentence_collect_seconds"] += times[0]
-            timing["sentence_normalize_seconds"] += times[1]
-            timing["tokenize_seconds"] += times[2]
-            timing["fragment_decode_seconds"] += times[3]
+            timing["sentence_collect_seconds"] += times[0] * share
+            timing["sentence_normalize_seconds"] += times[1] * share
+            timing["tokenize_seconds"] += times[2] * share
+            timing["fragment_decode_seconds"] += times[3] * share
 
         def groups():
             it = specs()
@@ -1253,12 +1299,13 @@ class OpenProvenceModel:
         for i, job in enumerate(chunk):
             reduced = isinstance(keeps[i], list)  # per-fragment means from the device (see _launch_rows)
             if scores[i] != scores[i] or (reduced and any(m != m for m in keeps[i])):
-                # The fp16 + e4m3 kernel sets turn an MLP activation beyond fp16's range into Inf on purpose
-                # (csrc/opk_common.hip.h: set_overflowing_conversions) so that it ends up here and not in a pruned text.
+                # (The fp16 + e4m3 kernel sets turn an MLP activation beyond fp16's range into Inf on purpose --
+                # csrc/opk_common.hip.h: set_overflowing_conversions -- and _guard_launch / _predict_rows_local have
+                # already repeated such a batch on the (hi, lo) bf16 sets: what arrives here is NaN in fp32 arithmetic.)
                 raise RuntimeError(
-                    "the forward returned NaN for a (query, context) block: either the checkpoint holds non-finite weights or an "
-                    "activation left the fp16 range of the default kernel set -- rerun with OPEN_PROVENCE_NO_F8=1 "
-                    "(the (hi, lo) bf16 kernels have fp32's range)"
+                    "the forward returned NaN for a (query, context) block on the (hi, lo) bf16 kernels (fp32 range; a batch that "
+                    "overflows the fp16 + e4m3 kernel set is repeated on them automatically): the checkpoint holds non-finite "
+                    "weights or the inputs overflow fp32"
                 )
             states[(job["query_idx"], job["context_idx"])].raw_blocks.append(
                 (
@@ -1496,19 +1543,23 @@ class OpenProvenceModel:
                 batch_explicit=batch_explicit,
                 prefetch_explicit=prefetch_explicit,
             )
+            # Worker threads for the split / tokenize stage: as many as explicitly requested (preprocess_workers=, the
+            # OPEN_PROVENCE_PREPROCESS_WORKERS variable or torch_dataloader_kwargs["num_workers"]); WITHOUT a request, four
+            # of them from 128 jobs on when BOTH hold: the tokenizer is a Hugging Face fast one (its Rust batch calls run
+            # outside the GIL) and the sentence splitter is one of this package's own (thread-safe: stateless regex /
+            # lazily initialised under a lock).  A caller-supplied splitter is never called from several threads unless
+            # workers were asked for -- the reference only ever ran splitters in separate processes (standalone.py:3589).
+            # Pure-Python tokenizers are served best by the lazy single-thread pipeline below (the reference's own default
+            # is 0 workers under 2000 jobs, standalone.py:2591-2592).
+            thread_workers = min(int(workers), 32) if (workers_explicit and workers > 0) else 0
+            if (not workers_explicit and total_jobs >= 128 and is_builtin_splitter(splitter)
+                    and hasattr(getattr(self.tokenizer, "_tokenizer", None), "encode_batch")):
+                thread_workers = 4
             if debug_callback is not None:
                 debug_callback(
-                    f"[OpenProvenceModel] preprocess_workers={workers} preprocess_batch={preprocess_batch} "
-                    f"default_workers={pl.default_preprocess_workers()}"
+                    f"[OpenProvenceModel] preprocess_workers={workers} preprocess_threads={thread_workers} "
+                    f"preprocess_batch={preprocess_batch} default_workers={pl.default_preprocess_workers()}"
                 )
-
-            # Worker threads for the split / tokenize stage only on an explicit request (preprocess_workers=, the
-            # OPEN_PROVENCE_PREPROCESS_WORKERS variable or torch_dataloader_kwargs["num_workers"]): they pay off with
-            # GIL-releasing tokenizers / splitters, while pure-Python ones are served best by the lazy single-thread
-            # pipeline below (the reference's own default is 0 workers under 2000 jobs, standalone.py:2591-2592).
-            thread_workers = min(int(workers), 32) if (workers_explicit and workers > 0) else 0
-            if not workers_explicit and total_jobs >= 128 and hasattr(getattr(self.tokenizer, "_tokenizer", None), "encode_batch"):
-                thread_workers = 4  # a Hugging Face fast tokenizer: its Rust batch calls run outside the GIL
             job_stream = self._iter_jobs(
                 queries, contexts, titles, splitter, query_token_ids, strip_sentences=strip_sentences, timing=timing,
                 workers=thread_workers, group_size=min(64, max(1, preprocess_batch)), owned=owned,

@@ -9,8 +9,10 @@ when missing -- callers can always pass ``sentence_splitter=<callable>`` or pre-
 
 from __future__ import annotations
 
+import itertools
 import math
 import re
+import threading
 from typing import Any, Callable, Iterable, Mapping
 
 SentenceSplitter = Callable[[str], list[str]]
@@ -51,6 +53,21 @@ def is_japanese_fast(text: str, window: int = 500, min_kana_per_window: int = 1)
     return False
 
 
+def _builtin(fn: SentenceSplitter) -> SentenceSplitter:
+    """Marks one of this module's splitters: stateless apart from lazily created, lock-protected singletons, hence safe
+    to call from the worker threads ``process()`` starts on its own (``is_builtin_splitter``)."""
+
+    fn._open_provence_builtin = True  # type: ignore[attr-defined]
+    return fn
+
+
+def is_builtin_splitter(fn: Any) -> bool:
+    """True for the splitters this module builds (``resolve_sentence_splitter`` with ``None``, ``simple_sentence_splitter``,
+    ...).  A caller-supplied callable is not: ``process()`` never calls it from several threads unless asked to."""
+
+    return bool(getattr(fn, "_open_provence_builtin", False))
+
+
 def simple_sentence_splitter(text: str) -> list[str]:
     """Regex splitter: a sentence ends at 。！？!? or a newline; nothing is stripped."""
 
@@ -69,86 +86,77 @@ def fast_bunkai_sentence_splitter(text: str) -> list[str]:
             "(e.g. `simple_sentence_splitter`)."
         ) from exc
     global _BUNKAI
-    if _BUNKAI is None:
-        _BUNKAI = FastBunkai()
+    with _LAZY_INIT_LOCK:
+        if _BUNKAI is None:
+            _BUNKAI = FastBunkai()
     sentences = [s for s in _BUNKAI(text) if s]
     return sentences or ([text] if text else [])
 
 
+_builtin(simple_sentence_splitter)
+_builtin(fast_bunkai_sentence_splitter)
+
+
 def _iter_english_blocks(text: str) -> Iterable[tuple[str, int, int]]:
-    """Group lines into blocks, starting a new block at every bullet-looking line; yields spans."""
+    """Spans ``(block, start, end)`` of the bullet-delimited blocks of ``text``: a block begins at the start of the text
+    and at every later LINE that opens with a bullet / enumeration marker (``standalone.py:485-530`` groups the lines the
+    same way).  Formulated over offsets: the line lengths give every line's start, the bullet test picks the cut points,
+    consecutive cut points delimit the blocks."""
 
     if not text:
         return
     lines = text.splitlines(keepends=True)
-    if not lines:
-        yield text, 0, len(text)
-        return
-    pos = 0
-    start = 0
-    parts: list[str] = []
-    for line in lines:
-        line_start = pos
-        pos += len(line)
-        if _BULLET_PREFIX_RE.match(line.rstrip("\r\n")) and parts:
-            block = "".join(parts)
-            if block:
-                yield block, start, start + len(block)
-            parts = [line]
-            start = line_start
-        else:
-            if not parts:
-                start = line_start
-            parts.append(line)
-    if parts:
-        block = "".join(parts)
-        if block:
-            yield block, start, start + len(block)
-    if pos < len(text):
-        yield text[pos:], pos, len(text)
+    offsets = [0, *itertools.accumulate(len(line) for line in lines)]  # offsets[i] = start of line i; [-1] = len(text)
+    cuts = [0]
+    cuts.extend(offsets[i] for i in range(1, len(lines)) if _BULLET_PREFIX_RE.match(lines[i].rstrip("\r\n")))
+    cuts.append(offsets[-1])
+    for begin, end in zip(cuts, cuts[1:]):
+        if end > begin:
+            yield text[begin:end], begin, end
+
+
+_CUT_MARKS = ".?!;:\n"
+
+
+def _cut_length(window: str) -> int:
+    """How much of ``window`` (the next ``max_chars`` characters of an overlong sentence) the next piece takes: up to and
+    including the last newline if there is one past the first character, else up to and including the last of ``.?!;:``
+    (or a newline in first position), else all of it (``standalone.py:532-577`` searches backwards for the same places)."""
+
+    newline = window.rfind("\n", 1)
+    if newline >= 1:
+        return newline + 1
+    mark = max(window.rfind(ch) for ch in _CUT_MARKS)
+    return mark + 1 if mark >= 0 else len(window)
 
 
 def split_overlong_sentence(sentence: str, max_chars: int = DEFAULT_ENGLISH_SENTENCE_MAX_CHARS, *, preserve_whitespace: bool = False) -> list[str]:
-    """Cut a sentence longer than ``max_chars`` at the last newline, else the last of ``.?!;:``, else hard."""
+    """Pieces of at most ``max_chars`` characters, cut behind the last newline of each window, else behind the last of
+    ``.?!;:``, else hard at the limit; pieces are stripped (and empty ones dropped) unless ``preserve_whitespace``."""
 
-    working = sentence if preserve_whitespace else sentence.strip()
-    if not working:
+    rest = sentence if preserve_whitespace else sentence.strip()
+    if not rest:
         return []
-    if len(working) <= max_chars:
-        return [working]
-    chunks: list[str] = []
-    start, length = 0, len(working)
-    while start < length:
-        target = min(start + max_chars, length)
-        boundary = None
-        newline = working.rfind("\n", start + 1, target)
-        if newline >= start + 1:
-            boundary = newline + 1
-        if boundary is None or boundary <= start:
-            for idx in range(target, start, -1):
-                if working[idx - 1] in ".?!;:\n":
-                    boundary = idx
-                    break
-        if boundary is None or boundary <= start:
-            boundary = target
-        chunk = working[start:boundary]
+    if len(rest) <= max_chars:
+        return [rest]
+    whole, pieces = rest, []
+    while rest:
+        take = _cut_length(rest[:max_chars])
+        piece, rest = rest[:take], rest[take:]
         if not preserve_whitespace:
-            chunk = chunk.strip()
-        if chunk:
-            chunks.append(chunk)
-        start = boundary
-    return chunks or [working]
+            piece = piece.strip()
+        if piece:
+            pieces.append(piece)
+    return pieces or [whole]
 
 
-def create_english_sentence_splitter(max_chars: int = DEFAULT_ENGLISH_SENTENCE_MAX_CHARS) -> SentenceSplitter:
-    """Punkt spans per bullet-delimited block, each span stretched over trailing whitespace, each piece
-    clipped to ``max_chars``; whitespace and newlines of the source are preserved."""
+_SPACE_RUN = re.compile(r"\s*")
+_LAZY_INIT_LOCK = threading.Lock()  # the Punkt model / FastBunkai instance are created once, whichever thread comes first
 
-    if max_chars <= 0:
-        raise ValueError("max_chars must be positive")
 
-    def _punkt():
-        global _ENGLISH_SENTENCE_TOKENIZER
+def _load_punkt():
+    global _ENGLISH_SENTENCE_TOKENIZER
+    with _LAZY_INIT_LOCK:
         if _ENGLISH_SENTENCE_TOKENIZER is not None:  # loaded once per process, as the reference does (:466-478)
             return _ENGLISH_SENTENCE_TOKENIZER
         try:
@@ -165,37 +173,43 @@ def create_english_sentence_splitter(max_chars: int = DEFAULT_ENGLISH_SENTENCE_M
         except LookupError as exc:
             raise LookupError("Missing NLTK punkt tokenizer data. Run `python -m nltk.downloader punkt`.") from exc
 
+
+def _english_segments(text: str, tokenizer: Any) -> Iterable[str]:
+    """The raw sentence segments of ``text``: Punkt's spans inside every bullet-delimited block, each stretched over the
+    whitespace that follows it (never past its block), or the whole block where Punkt finds nothing; whitespace-only
+    segments are dropped (``standalone.py:1057-1126``)."""
+
+    for block, begin, end in _iter_english_blocks(text):
+        spans = list(tokenizer.span_tokenize(block))
+        candidates = [text[begin + s : _SPACE_RUN.match(text, begin + e, end).end()] for s, e in spans] if spans else [block]
+        yield from (segment for segment in candidates if segment.strip())
+
+
+def create_english_sentence_splitter(max_chars: int = DEFAULT_ENGLISH_SENTENCE_MAX_CHARS) -> SentenceSplitter:
+    """Punkt spans per bullet-delimited block, each span stretched over trailing whitespace, each piece
+    clipped to ``max_chars``; whitespace and newlines of the source are preserved."""
+
+    if max_chars <= 0:
+        raise ValueError("max_chars must be positive")
+
     def split(text: str) -> list[str]:
         if not text:
             return []
-        tokenizer = _punkt()
-        out: list[str] = []
-        for block, b_start, b_end in _iter_english_blocks(text):
-            if not block:
-                continue
-            spans = list(tokenizer.span_tokenize(block))
-            if not spans:
-                segment = text[b_start:b_end]
-                if segment.strip():
-                    out.extend(split_overlong_sentence(segment, max_chars, preserve_whitespace=True))
-                continue
-            for s, e in spans:
-                end = b_start + e
-                while end < b_end and text[end].isspace():
-                    end += 1
-                segment = text[b_start + s : end]
-                if segment and segment.strip():
-                    out.extend(split_overlong_sentence(segment, max_chars, preserve_whitespace=True))
+        out = [piece for segment in _english_segments(text, _load_punkt())
+               for piece in split_overlong_sentence(segment, max_chars, preserve_whitespace=True)]
         if out:
             return out
         stripped = text.strip()
         return [stripped] if stripped else []
 
-    return split
+    return _builtin(split)
 
 
 def english_sentence_splitter(text: str) -> list[str]:
     return create_english_sentence_splitter()(text)
+
+
+_builtin(english_sentence_splitter)
 
 
 def create_auto_sentence_splitter(
@@ -210,7 +224,7 @@ def create_auto_sentence_splitter(
             return japanese_splitter(text)
         return english_splitter(text)
 
-    return split
+    return _builtin(split) if (is_builtin_splitter(japanese_splitter) and is_builtin_splitter(english_splitter)) else split
 
 
 def resolve_sentence_splitter(

@@ -1,7 +1,7 @@
 # same-box A/B of two builds of the library: scripts/ab_lib.sh <other .so> [bench args...]  (three alternations)
 LIB=$1; shift
 for i in 1 2 3; do
-  OPEN_PROVENCE_HIP_LIB=$LIB python bench.py --steps 60 --no-cpu-baseline --no-long --no-base "$@" > gpurun_out/ablib_other_$i.json 2>/dev/null
+  OPEN_PROVENCE_HIP_LIB=$LIB OPEN_PROVENCE_HIP_LIB_ANY_ABI=1 python bench.py --steps 60 --no-cpu-baseline --no-long --no-base "$@" > gpurun_out/ablib_other_$i.json 2>/dev/null
   python bench.py --steps 60 --no-cpu-baseline --no-long --no-base "$@" > gpurun_out/ablib_tree_$i.json 2>/dev/null
 done
 python - <<'PY'

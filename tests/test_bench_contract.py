@@ -39,12 +39,20 @@ def test_bench_json_line_contract():
     assert line["config"]["parallelism"] == "single GPU" and "one_pipeline" not in line
     other = line["bf16_checkpoint"]
     assert other["value"] > 0 and other["policy"]["kernel_set"] == "f16-f8" and other["checkpoint_dtype"] == "bf16"
-    assert 0.5 < line["shader_clock_ghz"]["value"] < 3.0
+    # the label says what ran (fp16 + e4m3 split operands), not "bf16"; every frac has the clock it was measured at beside
+    # it, taken in a SEPARATE probed pass whose own step time is on the record
+    assert "fp16" in line["dtype"] and "e4m3" in line["dtype"] and "fp16" in other["dtype"]
+    assert 0.5 < line["shader_clock_ghz"]["value"] < 3.0 and line["shader_clock_ghz"]["ms_per_step_with_probe"] > 0
+    assert 0.5 < roof["shader_clock_ghz"] < 3.0 and 0.5 < other["shader_clock_ghz"] < 3.0
+    assert 0.5 < line["seq_len_2048"]["shader_clock_ghz"] < 3.0
+    for rec in (line["config"], other, line["seq_len_2048"]):
+        assert set(rec["output_checksum"]) == {"prune_sum", "prune_abs_sum", "rank_sum"}
     assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
     # the panel path (base dims) as a sub-record, both checkpoint dtypes: default flags = the (hi, lo) bf16 kernel sets
     base = line["base_model"]
     assert base["model"] == "base" and base["fp32_checkpoint"]["kernel_set"] == "bf16x3" and base["bf16_checkpoint"]["kernel_set"] == "bf16-weights"
     assert base["fp32_checkpoint"]["value"] > 0 and base["bf16_checkpoint"]["value"] > 0
+    assert "bf16" in base["fp32_checkpoint"]["dtype"] and 0.5 < base["fp32_checkpoint"]["shader_clock_ghz"] < 3.0
 
 
 @pytest.mark.gpu

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import dims_from_meta, load_golden, rows_from_fixture, state_from_fixture
+from helpers import CharTokenizer, dims_from_meta, load_golden, period_splitter, rows_from_fixture, state_from_fixture
 from parity_utils import run_fixture_on_gpu
 
 pytestmark = pytest.mark.gpu
@@ -266,16 +266,9 @@ def test_tiny_scaled_weight_tensor_keeps_the_bf16_kernel_sets(weights):
         assert np.abs(rank.cpu().numpy() - ref.ranking_logits.numpy()).max() < 1e-3, scale
 
 
-def test_activation_beyond_fp16_range_is_loud_on_the_f8_sets_and_fine_on_the_bf16_sets():
-    """MLP activations h = GeGLU(...) of 1e5 .. 1e6 (Wi x 512 in two layers; their Wo x 2^-18, rounded to multiples of
-    2^-24 so that fp16's subnormal grid holds them exactly and the load-time guard of the previous test stays quiet).
-    The fp16 operand plane cannot hold such an h: the whole-layer kernel converts it with IEEE overflow (Inf), so the
-    outputs come back non-finite -- process() raises on that -- instead of being computed from a quietly clamped operand;
-    the (hi, lo) bf16 sets (OP_FLAG_NO_F8) have fp32's range and match the oracle."""
-
-    from open_provence_amd.engine import HipEncoder
-    from open_provence_amd.synthetic import pad_rows
-    from oracle.modernbert_oracle import oracle_forward
+def _overflowing_state():
+    """g1_xsmall with MLP activations h = GeGLU(...) of 1e5 .. 1e6 (Wi x 512 in two layers; their Wo x 2^-18, rounded to
+    multiples of 2^-24 so that fp16's subnormal grid holds them exactly and the load-time guard stays quiet)."""
 
     arrays, meta = load_golden("g1_xsmall")
     dims = dims_from_meta(meta)
@@ -287,6 +280,19 @@ def test_activation_beyond_fp16_range_is_loud_on_the_f8_sets_and_fine_on_the_bf1
         state[wi] = state[wi] * scale
         # x 2^-18, on fp16's subnormal grid exactly (multiples of 2^-24): representable, so the format is selected
         state[wo] = torch.round(state[wo] / (scale * scale) * 2.0**24) / 2.0**24
+    return meta, dims, rows, state
+
+
+def test_activation_beyond_fp16_range_is_loud_on_the_f8_sets_and_fine_on_the_bf16_sets():
+    """The fp16 operand plane cannot hold an h of 1e5 .. 1e6: the whole-layer kernel converts it with IEEE overflow
+    (Inf), so the raw outputs come back non-finite instead of being computed from a quietly clamped operand; the
+    (hi, lo) bf16 sets (OP_FLAG_NO_F8) have fp32's range and match the oracle."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import pad_rows
+    from oracle.modernbert_oracle import oracle_forward
+
+    _meta, dims, rows, state = _overflowing_state()
     ids, mask = pad_rows(rows)
     ref = oracle_forward(state, dims, ids, mask)
     m = mask.bool().numpy()
@@ -305,3 +311,92 @@ def test_activation_beyond_fp16_range_is_loud_on_the_f8_sets_and_fine_on_the_bf1
         else:
             assert np.abs(p - ref.pruning_logits.numpy()[m]).max() < 1e-3 and np.abs(r - ref.ranking_logits.numpy()).max() < 1e-3
     assert outs[NO_F8] == "bf16x3"
+
+
+def test_overflow_of_the_f8_sets_falls_back_to_the_bf16_sets_instead_of_failing():
+    """What a caller sees (reference precedent for a silent, correct retry: standalone.py:1631-1642): the range guard
+    repeats a non-finite batch on the (hi, lo) bf16 kernel sets -- ``op_set_compact_operands`` through the C ABI, both weight packs
+    are resident -- warns once, and the model stays there.  The result is BIT-identical to a model created with
+    OP_FLAG_NO_F8, through every entry point: the guarded forward, ``forward()``, the single-block API, ``process()``."""
+
+    import warnings
+
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.modeling import OpenProvenceModel
+    from open_provence_amd.packing import pack_rows
+    from open_provence_amd.synthetic import pad_rows
+
+    meta, dims, rows, state = _overflowing_state()
+    ids_np, cu_np, max_len = pack_rows(rows)
+
+    def run(enc, checked):
+        ids, cu = torch.from_numpy(ids_np).to(enc.device), torch.from_numpy(cu_np).to(enc.device)
+        fn = enc.forward_packed_checked if checked else enc.forward_packed
+        prune, rank = fn(ids, cu, cu_np, max_len)
+        torch.cuda.synchronize()
+        return prune.cpu().numpy(), rank.cpu().numpy()
+
+    ref_enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=NO_F8)
+    ref_enc.load_state_dict(state)
+    ref_p, ref_r = run(ref_enc, False)
+    ref_enc.close()
+    assert np.isfinite(ref_p).all() and np.isfinite(ref_r).all()
+
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(state)
+    assert enc.effective_policy()["kernel_set"] == "f16-f8-w" and enc.f8_active()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        p, r = run(enc, True)
+        assert any("fp16 + e4m3" in str(w.message) for w in caught)
+    assert enc.effective_policy()["kernel_set"] == "bf16x3" and not enc.f8_active()  # it stays on the bf16 sets
+    assert np.array_equal(p, ref_p) and np.array_equal(r, ref_r)
+    with warnings.catch_warnings(record=True) as caught:  # nothing to fall back from any more, nothing to warn about
+        warnings.simplefilter("always")
+        p2, r2 = run(enc, True)
+        assert not caught
+    assert np.array_equal(p2, ref_p)
+    enc.close()
+
+    # the model-level entry points
+    cfg = OpenProvenceConfig(base_model_config=meta["base_model_config"], tokenizer_name_or_path="x",
+                             pruning_config={"hidden_size": meta["base_model_config"]["hidden_size"]}, max_length=512)
+    ids, mask = pad_rows(rows)
+
+    def model_with(env_no_f8):
+        import os
+
+        old = os.environ.pop("OPEN_PROVENCE_NO_F8", None)
+        if env_no_f8:
+            os.environ["OPEN_PROVENCE_NO_F8"] = "1"
+        try:
+            return OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
+        finally:
+            os.environ.pop("OPEN_PROVENCE_NO_F8", None)
+            if old is not None:
+                os.environ["OPEN_PROVENCE_NO_F8"] = old
+
+    plain = model_with(True)
+    want = plain(input_ids=ids, attention_mask=mask)
+    text = "alpha beta gamma. delta epsilon zeta eta. theta iota kappa lambda mu. " * 6
+    want_proc = plain.process("what is gamma", [text, text[:120]], sentence_splitter=period_splitter, show_progress=False,
+                              return_sentence_metrics=True)
+    want_raw = plain.get_raw_predictions("what is gamma", [text[:200]])
+    for entry in ("forward", "process", "raw"):
+        model = model_with(False)
+        assert model.encoder.f8_active()
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            if entry == "forward":
+                got = model(input_ids=ids, attention_mask=mask)
+                assert torch.equal(got.ranking_logits, want.ranking_logits) and torch.equal(got.pruning_logits, want.pruning_logits)
+            elif entry == "process":
+                got = model.process("what is gamma", [text, text[:120]], sentence_splitter=period_splitter, show_progress=False,
+                                    return_sentence_metrics=True)
+                for key in ("pruned_context", "kept_sentences", "removed_sentences", "reranking_score", "sentence_probabilities"):
+                    assert got[key] == want_proc[key], key
+            else:
+                got = model.get_raw_predictions("what is gamma", [text[:200]])
+                assert got.ranking_score == want_raw.ranking_score and np.array_equal(got.pruning_probs, want_raw.pruning_probs)
+        assert not model.encoder.f8_active()

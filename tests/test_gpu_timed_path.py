@@ -67,7 +67,7 @@ def test_bench_configuration_matches_the_oracle(weights, kernel_set):
     assert "fused_layer_attnout_mlp_qkv" in kinds and "final_ln_prune" not in kinds, kinds  # one launch per layer, either dtype
     prune1, rank1 = prune1.cpu().numpy().reshape(PAIRS, SEQ_LEN, 2), rank1.cpu().numpy()
 
-    # two half-batch launch sequences on CU-partitioned streams (bench.py: the headline `value`)
+    # two half-batch launch sequences on CU-partitioned streams (bench.py --pipelines 2; the default with OPEN_PROVENCE_NO_F8=1)
     half = PAIRS // 2
     outs = []
     for part, part_rows in enumerate((rows[:half], rows[half:])):
@@ -93,3 +93,92 @@ def test_bench_configuration_matches_the_oracle(weights, kernel_set):
     keep = 1.0 / (1.0 + np.exp(-(got_prune[..., 1] - got_prune[..., 0]).astype(np.float64)))
     keep_ref = 1.0 / (1.0 + np.exp(-(ref_prune[..., 1] - ref_prune[..., 0]).astype(np.float64)))
     assert np.abs(keep - keep_ref).max() < 1e-3
+
+
+# ---- the panel path (hidden 512 / 768: BASELINE configs 3-5) at the sizes bench.py times it ------------------------------
+# Full depth, default flags, both checkpoint dtypes.  At >= 256 row blocks the XCD-aware block maps of the panel GEMMs
+# (op_api.hip: per_xcd / groups / row_group all follow r_pad / 128), the XCD-grouped attention map and the 256-query
+# attention blocks take the values they have in the bench -- none of which the 1..7-row-block fixtures reach.  Checked
+# pairs: first / last of the batch and pairs whose 4 row blocks sit at the boundaries of the 8-row-block XCD groups.
+
+def _panel_setup(model: str, weights: str):
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, synth_state_dict
+
+    dims = named_dims(model)
+    state = synth_state_dict(dims, seed=7)
+    if weights == "bf16":
+        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(state)
+    return dims, state, enc
+
+
+def _run_and_check(enc, dims, state, rows, checked, expect_kinds):
+    from open_provence_amd.packing import pack_rows
+
+    ids_np, cu_np, max_len = pack_rows(rows)
+    ids, cu = torch.from_numpy(ids_np).to(enc.device), torch.from_numpy(cu_np).to(enc.device)
+    enc.profile_enable(True)
+    prune, rank = enc.forward_packed(ids, cu, cu_np, max_len)
+    torch.cuda.synchronize()
+    kinds = set(enc.profile_read())
+    enc.profile_enable(False)
+    assert expect_kinds <= kinds, kinds
+    prune, rank = prune.cpu().numpy(), rank.cpu().numpy()
+    assert np.isfinite(prune).all() and np.isfinite(rank).all()
+    ref_prune, ref_rank = _oracle(state, dims, [rows[i] for i in checked])
+    worst = 0.0
+    for j, i in enumerate(checked):
+        n = len(rows[i])
+        got = prune[cu_np[i] : cu_np[i + 1]]
+        worst = max(worst, float(np.abs(got - ref_prune[j, :n]).max()), float(np.abs(rank[i] - ref_rank[j]).max()))
+    return worst
+
+
+PANEL_KINDS = {"gemm_qkv_rope", "gemm_attn_out", "gemm_wi_geglu", "gemm_mlp_out", "layer_norm", "attn_global", "attn_local"}
+
+
+@pytest.mark.parametrize("weights,kernel_set", [("fp32", "bf16x3"), ("bf16", "bf16-weights")])
+def test_base_model_at_bench_size_matches_the_oracle(weights, kernel_set):
+    """bench.py's `base_model` sub-record and `--model base`: base dims (H = 512, 19 layers), 256 x 512 = 1024 row blocks."""
+
+    from open_provence_amd.synthetic import synth_pair_batch
+
+    dims, state, enc = _panel_setup("base", weights)
+    assert enc.effective_policy()["kernel_set"] == kernel_set
+    rows = synth_pair_batch(dims, PAIRS, SEQ_LEN, seed=1234)
+    # pairs 1 / 2 and 15 / 16 straddle XCD-group boundaries (8 row blocks = 2 pairs per group, 8 groups per round)
+    worst = _run_and_check(enc, dims, state, rows, [0, 1, 2, 15, 16, 127, 128, 200, 254, 255], PANEL_KINDS)
+    enc.close()
+    assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("weights", ["fp32", "bf16"])
+def test_en_gte_varlen_at_bench_size_matches_the_oracle(weights):
+    """`bench.py --model en-gte --varlen` (BASELINE config 5): mixed lengths 128..2048, ~131 072 tokens, 22 layers."""
+
+    from open_provence_amd.synthetic import synth_pair_batch, synth_varlen_lengths
+
+    dims, state, enc = _panel_setup("en-gte", weights)
+    lengths = synth_varlen_lengths(PAIRS * SEQ_LEN, seed=1234)
+    rows = [synth_pair_batch(dims, 1, n, seed=1234 + 7 * i)[0] for i, n in enumerate(lengths)]
+    assert sum(lengths) >= PAIRS * SEQ_LEN
+    # first, last, the longest and the shortest row, and two in the middle
+    order = sorted(range(len(rows)), key=lambda i: len(rows[i]))
+    checked = sorted({0, len(rows) - 1, order[0], order[-1], len(rows) // 3, 2 * len(rows) // 3})
+    worst = _run_and_check(enc, dims, state, rows, checked, PANEL_KINDS)
+    enc.close()
+    assert worst < 1e-3, worst
+
+
+def test_large_model_at_2048_matches_the_oracle():
+    """`bench.py --model large --seq-len 2048 --pairs 64` (BASELINE config 4): 25 layers, 64 x 2048 = 1024 row blocks."""
+
+    from open_provence_amd.synthetic import synth_pair_batch
+
+    dims, state, enc = _panel_setup("large", "fp32")
+    rows = synth_pair_batch(dims, 64, 2048, seed=1234)
+    worst = _run_and_check(enc, dims, state, rows, [0, 63], PANEL_KINDS)
+    enc.close()
+    assert worst < 1e-3, worst

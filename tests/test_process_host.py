@@ -122,35 +122,61 @@ def test_preprocess_workers_give_identical_results_in_order():
     assert any(name.startswith("open-provence-prep") for name in seen_threads), seen_threads
 
 
-def test_fast_tokenizer_requests_take_worker_threads_by_default_and_change_nothing():
-    """From 128 jobs on, a request with a Hugging Face fast tokenizer prepares its groups of contexts (split, one
-    ``encode_batch``, one ``decode_batch`` per group) on four worker threads without being asked to -- same result as
-    ``preprocess_workers=0``, field for field."""
+def test_fast_tokenizer_requests_take_worker_threads_by_default_and_change_nothing(monkeypatch):
+    """From 128 jobs on, a request with a Hugging Face fast tokenizer AND one of the package's own sentence splitters
+    prepares its groups of contexts (split, one ``encode_batch``, one ``decode_batch`` per group) on four worker threads
+    without being asked to -- same result as ``preprocess_workers=0``, field for field.  A caller-supplied splitter is
+    never called from several threads unless workers were requested (the reference only ever ran splitters in separate
+    processes, standalone.py:3589): it may not be thread-safe."""
 
     import threading
 
     from helpers import build_wordpiece_tokenizer
+    from open_provence_amd import pipeline as pl
+    from open_provence_amd.splitters import is_builtin_splitter, simple_sentence_splitter
 
     words = "the tower is tall boats carry fish and salt to north city harbour many years ago it was new".split()
-    contexts = [
-        " ".join(f"{words[(i * 7 + j * 3 + k) % len(words)]}" for k in range(5 + (i + j) % 6)).capitalize() + "."
-        for i in range(140) for j in range(1)
+    sentences = [
+        " ".join(f"{words[(i * 7 + k) % len(words)]}" for k in range(5 + i % 6)).capitalize() + "!"
+        for i in range(140)
     ]
-    contexts = [" ".join(contexts[(i + d) % len(contexts)] for d in range(1 + i % 4)) for i in range(140)]
+    contexts = ["\n".join(sentences[(i + d) % len(sentences)] for d in range(1 + i % 4)) for i in range(140)]
+    tokenizing_threads = set()
+    real_tokenize = pl.tokenize_sentence_groups
+
+    def recording_tokenize(tokenizer, groups):
+        tokenizing_threads.add(threading.current_thread().name)
+        return real_tokenize(tokenizer, groups)
+
+    monkeypatch.setattr(pl, "tokenize_sentence_groups", recording_tokenize)
+    model = host_only_model(tokenizer=build_wordpiece_tokenizer(True), max_length=64, forward=golden_stub_forward)
+    kwargs = dict(question="which boats carry salt?", context=contexts, show_progress=False,
+                  return_sentence_metrics=True, return_sentence_texts=True, batch_size=16, threshold=0.4)
+    assert is_builtin_splitter(simple_sentence_splitter)
+    default = model.process(sentence_splitter=simple_sentence_splitter, **kwargs)
+    assert any(name.startswith("open-provence-prep") for name in tokenizing_threads), tokenizing_threads
+    tokenizing_threads.clear()
+    single = model.process(sentence_splitter=simple_sentence_splitter, preprocess_workers=0, **kwargs)
+    assert not any(name.startswith("open-provence-prep") for name in tokenizing_threads), tokenizing_threads
+    for key in ("pruned_context", "reranking_score", "compression_rate", "kept_sentences", "removed_sentences", "sentence_probabilities", "title"):
+        assert default[key] == single[key], key
+    assert sum(len(k) for k in default["kept_sentences"]) > 0 and sum(len(r) for r in default["removed_sentences"]) > 0
+    # the stage timers are wall-clock seconds of the stage (thread seconds scaled by 1 / workers): never more than the call
+    timing = default["timing"]
+    assert timing["preprocess_seconds"] <= timing["total_seconds"] + 1e-6
+
+    # a caller's own splitter: one thread unless workers are requested
     seen = set()
 
     def splitter(text):
         seen.add(threading.current_thread().name)
-        return period_splitter(text)
+        return simple_sentence_splitter(text)
 
-    model = host_only_model(tokenizer=build_wordpiece_tokenizer(True), max_length=64, forward=golden_stub_forward)
-    kwargs = dict(question="which boats carry salt?", context=contexts, sentence_splitter=splitter, show_progress=False,
-                  return_sentence_metrics=True, return_sentence_texts=True, batch_size=16, threshold=0.4)
-    default = model.process(**kwargs)
-    assert any(name.startswith("open-provence-prep") for name in seen), seen
+    assert not is_builtin_splitter(splitter)
+    own = model.process(sentence_splitter=splitter, **kwargs)
+    assert seen and not any(name.startswith("open-provence-prep") for name in seen), seen
     seen.clear()
-    single = model.process(preprocess_workers=0, **kwargs)
-    assert not any(name.startswith("open-provence-prep") for name in seen), seen
-    for key in ("pruned_context", "reranking_score", "compression_rate", "kept_sentences", "removed_sentences", "sentence_probabilities", "title"):
-        assert default[key] == single[key], key
-    assert sum(len(k) for k in default["kept_sentences"]) > 0 and sum(len(r) for r in default["removed_sentences"]) > 0
+    asked = model.process(sentence_splitter=splitter, preprocess_workers=3, **kwargs)
+    assert any(name.startswith("open-provence-prep") for name in seen), seen
+    for key in ("pruned_context", "reranking_score", "kept_sentences", "removed_sentences", "sentence_probabilities"):
+        assert own[key] == single[key] and asked[key] == single[key], key
