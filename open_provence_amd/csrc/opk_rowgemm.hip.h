@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           // the second one has nothing left to request
           if constexpr (!CHUNK && hb == 0) static_for<UNIT_DMA>([&](auto u) { stage_piece_w(u, c + 1, hb ^ 1); });
 #ifndef OPK_WLO_ILV
-#define OPK_WLO_ILV 2  // fragment groups in flight with the reads between the MFMAs (0: reads behind the step, DEPTH8 ahead)
+#define OPK_WLO_ILV 4  // fragment groups in flight with the reads between the MFMAs (0: reads behind the step, DEPTH8 ahead)
 #endif
 #if OPK_WLO_ILV == 0
           frag_stream2<CS + NSH - S0, DEPTH8, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&&... rd_opt) {
@@ -1595,7 +1595,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
               // carried into the next iteration's chunk 2t+2, as the bf16-valued kernel does, it costs this kernel -- 256
               // VGPRs + 208 AGPRs in use -- 48 more accumulator shuffles per iteration than the emptier steps return
               // (MLP loop 166.2 k cycles per tile before, 161.6 k this way, 173.5 k carried).  With the fragment reads
-              // between the MFMAs (frag_stream2i, two groups ahead): 154.8 k.
+              // between the MFMAs (frag_stream2i): 154.8 k two groups ahead, 157.2 k four ahead in the isolated launch --
+              // and in the whole forward (same box, alternating runs, ten layers with their own weights) four ahead is the
+              // faster one: 36.5 k pairs/s against 35.7 k two ahead and 36.1 k for the round-3 kernel.
               if constexpr (hb == 1) {
                 constexpr int OB = (3 * RB_NSL / 2 + st) * RB_OPS / RB_UNITS, OE = (3 * RB_NSL / 2 + st + 1) * RB_OPS / RB_UNITS;
                 geglu_ops72(na, g_cur, std::integral_constant<int, OB>{}, std::integral_constant<int, OE>{}, no_);
