@@ -407,15 +407,16 @@ class HipEncoder:
             raise ValueError("cu_seqlens_host length mismatch")
         st = self._split_streams()
         side = st["streams"][part]
-        # The outputs are allocated on the CALLER's stream (its caching-allocator pool) and handed to the side stream
-        # with record_stream: a consumer that reads them on its own stream after waiting for pipeline_stream(part) can
-        # never see the block recycled by a later call while that read is still in flight.
-        with torch.cuda.device(self.device):
+        # The outputs come from the SIDE stream's pool of the caching allocator (allocated under that stream): a block of
+        # that pool is only ever recycled in side-stream order, so the kernels that write them can never land on memory a
+        # still-queued reader of the caller's stream owns (allocated from the caller's pool, a block freed there and
+        # whose last reader is still queued could be handed out here and overwritten early: nothing orders the side
+        # stream behind the caller's).  Consumers wait on pipeline_stream(part) before reading; a consumer that reads
+        # them on ANOTHER stream and drops them right away should record_stream() them there, as with any tensor that
+        # crosses streams.
+        with torch.cuda.device(self.device), torch.cuda.stream(side):
             prune = torch.empty((total, 2), dtype=torch.float32, device=self.device)
             rank = torch.empty((n_seqs, self.dims.num_labels), dtype=torch.float32, device=self.device)
-            prune.record_stream(side)
-            rank.record_stream(side)
-        with torch.cuda.device(self.device), torch.cuda.stream(side):
             if n_seqs == 0:
                 return prune, rank
             need = int(self.lib.op_workspace_bytes(self._handle, n_seqs, total, int(max_seqlen)))

@@ -1298,15 +1298,16 @@ class OpenProvenceModel:
         scores = torch.sigmoid(rank_scores.to(torch.float32)).tolist()  # = _ranking_score row by row (ref :2913-2916)
         for i, job in enumerate(chunk):
             reduced = isinstance(keeps[i], list)  # per-fragment means from the device (see _launch_rows)
-            if scores[i] != scores[i] or (reduced and any(m != m for m in keeps[i])):
-                # (The fp16 + e4m3 kernel sets turn an MLP activation beyond fp16's range into Inf on purpose --
-                # csrc/opk_common.hip.h: set_overflowing_conversions -- and _guard_launch / _predict_rows_local have
-                # already repeated such a batch on the (hi, lo) bf16 sets: what arrives here is NaN in fp32 arithmetic.)
-                raise RuntimeError(
-                    "the forward returned NaN for a (query, context) block on the (hi, lo) bf16 kernels (fp32 range; a batch that "
-                    "overflows the fp16 + e4m3 kernel set is repeated on them automatically): the checkpoint holds non-finite "
-                    "weights or the inputs overflow fp32"
-                )
+            if (scores[i] != scores[i] or (reduced and any(m != m for m in keeps[i]))) and not self.__dict__.get("_nan_warned"):
+                # The fp16 + e4m3 kernel sets turn an MLP activation beyond fp16's range into Inf on purpose
+                # (csrc/opk_common.hip.h: set_overflowing_conversions) and _guard_launch / _predict_rows_local have already
+                # repeated such a batch on the (hi, lo) bf16 sets: what arrives here is NaN in fp32-range arithmetic, i.e.
+                # what the reference computes for this checkpoint / input too.  It goes on as the reference's does (a NaN
+                # probability fails `> threshold`, standalone.py:3130) -- said once, not raised: a drop-in must not fail
+                # where the reference returns, and a raise on one rank of a process group would strand the others.
+                self.__dict__["_nan_warned"] = True
+                LOGGER.warning("the forward returned NaN for a (query, context) block on fp32-range kernels: the checkpoint "
+                               "holds non-finite weights or the inputs overflow fp32; results follow the reference (NaN scores)")
             states[(job["query_idx"], job["context_idx"])].raw_blocks.append(
                 (
                     job["block_idx"],
@@ -1333,28 +1334,44 @@ class OpenProvenceModel:
             self._store_raw_predictions(chunk, ranges_per_job, queries, states, rank, keeps)
         return waited
 
-    def _gather_job_results(self, result, owned, info):
+    def _gather_job_results(self, result, owned, info, error: BaseException | None = None):
         """Job-sharded ``process()``: every rank sends the post-processed fields of the contexts it owns to rank
         ``dst`` (one ``gather_object``; the payload is the texts and a few floats per context), which writes them into
-        its own full-size result lists -- the entries of contexts a rank does not own are placeholders until then."""
+        its own full-size result lists -- the entries of contexts a rank does not own are placeholders until then.
+
+        A rank whose share FAILED (a splitter / tokenizer error on one of its contexts, an out-of-range id, ...) still
+        enters the collective -- with an error marker instead of results (``error``: called from process()'s exit
+        handler) -- and ``dst`` then tells every rank who failed (one ``broadcast_object_list``), so that all ranks raise
+        instead of the healthy ones waiting forever for a peer that has left."""
 
         import torch.distributed as dist
 
-        fields = [f for f in (result.pruned_contexts, result.reranking_scores, result.compression_rates, result.kept_sentences,
-                              result.removed_sentences, result.titles, result.sentence_probabilities)]
-        mine = {
-            (q, c): tuple(None if f is None else f[q][c] for f in fields)
-            for q, per_query in enumerate(owned) for c, own in enumerate(per_query) if own
-        }
         group, dst, rank, world = info["group"], info["dst"], info["rank"], info["world"]
         if world <= 1 and not info.get("force"):
             return result
+        fields = []
+        if error is None:
+            fields = [f for f in (result.pruned_contexts, result.reranking_scores, result.compression_rates, result.kept_sentences,
+                                  result.removed_sentences, result.titles, result.sentence_probabilities)]
+            mine = {
+                (q, c): tuple(None if f is None else f[q][c] for f in fields)
+                for q, per_query in enumerate(owned) for c, own in enumerate(per_query) if own
+            }
+        else:
+            mine = {"__error__": f"{type(error).__name__}: {error}"}
         dst_global = dist.get_global_rank(group, dst) if group is not None and group is not dist.group.WORLD else dst
         gathered = [None] * world if rank == dst else None
         device = getattr(self, "device", None)
         ctx = torch.cuda.device(device) if (device is not None and torch.device(device).type == "cuda") else contextlib.nullcontext()
         with ctx:  # (the NCCL backend moves pickled objects through tensors on the CURRENT device)
             dist.gather_object(mine, gathered, dst=dst_global, group=group)
+            failed = [{r: part["__error__"] for r, part in enumerate(gathered) if isinstance(part, dict) and "__error__" in part}] if rank == dst else [None]
+            dist.broadcast_object_list(failed, src=dst_global, group=group)
+        if failed[0]:
+            if error is not None:
+                return result  # this rank's own exception is already propagating
+            raise RuntimeError("process() over the process group failed on rank(s) "
+                               + "; ".join(f"{r}: {msg}" for r, msg in sorted(failed[0].items())))
         if rank != dst:
             return result
         for part_rank, part in enumerate(gathered):
@@ -1505,6 +1522,20 @@ class OpenProvenceModel:
                 total_jobs = sum(sum(per_query) for per_query in owned)
                 job_shard["local_only"] = True
                 stack.callback(job_shard.__setitem__, "local_only", False)
+                gather_state = {"entered": False}
+
+                def _leave_with_error(_exc_type, exc, _tb, _info=job_shard, _state=gather_state):
+                    # an exception on this rank before its gather: enter the collective with an error marker, so that
+                    # the peers are told instead of blocking in gather_object forever; then let the exception go on
+                    if exc is not None and not _state["entered"]:
+                        _state["entered"] = True
+                        try:
+                            self._gather_job_results(None, None, _info, error=exc)
+                        except Exception:  # (a broken group must not mask the original error)
+                            pass
+                    return False
+
+                stack.push(_leave_with_error)
 
             # effective preprocess batch (= cap of blocks per inference pass), as the reference computes it
             workers = self._resolve_preprocess_workers(preprocess_workers)
@@ -1650,6 +1681,7 @@ class OpenProvenceModel:
             result = pl.PostprocessResult(pruned_l, scores_l, rates_l, kept_l, removed_l, titles_l, probs_l)
             if job_shard is not None:
                 t_gather = perf_counter()
+                gather_state["entered"] = True
                 result = self._gather_job_results(result, owned, job_shard)
                 post_time += perf_counter() - t_gather
 

@@ -114,22 +114,28 @@ class ShardPlan:
             out.append((plan_j, rows_j))
         return out
 
-    def pack(self, rank: int, values: torch.Tensor, rank_logits: torch.Tensor) -> torch.Tensor:
-        """This rank's payload (on the tensors' device)."""
+    def pack(self, rank: int, values: torch.Tensor, rank_logits: torch.Tensor, *, out: torch.Tensor | None = None) -> torch.Tensor:
+        """This rank's payload (on the tensors' device): a NEW tensor on every call (``out`` given: written there --
+        :meth:`gather` passes its private, zero-filled-once buffer)."""
 
         if values.numel() != self.tokens[rank] * self.width or rank_logits.numel() != self.rows[rank] * self.num_labels:
             raise ValueError("local outputs do not match this rank's shard")
-        # one payload buffer per (plan, device), zero-filled ONCE: the padding behind the values / logits is never
-        # written again, and a step of a long run only copies its two tensors in (no allocation, no fill)
-        cache = self.__dict__.setdefault("_payload_cache", {})
-        key = (str(values.device), int(rank))
-        payload = cache.get(key)
-        if payload is None:
-            payload = cache[key] = torch.zeros(self.payload_size, dtype=torch.float32, device=values.device)
+        payload = out if out is not None else torch.zeros(self.payload_size, dtype=torch.float32, device=values.device)
         payload[: values.numel()].copy_(values.reshape(-1))
         base = self.max_tokens * self.width
         payload[base : base + rank_logits.numel()].copy_(rank_logits.reshape(-1))
         return payload
+
+    def _send_buffer(self, device: torch.device, rank: int) -> torch.Tensor:
+        """:meth:`gather`'s own send buffer, one per (device, rank), zero-filled ONCE: the padding behind the values /
+        logits is never written again, so a step of a long run only copies its two tensors in (no allocation, no fill).
+        Private to ``gather``: nothing a caller holds aliases it."""
+
+        cache = self.__dict__.setdefault("_payload_cache", {})
+        key = (str(device), int(rank))
+        if key not in cache:
+            cache[key] = torch.zeros(self.payload_size, dtype=torch.float32, device=device)
+        return cache[key]
 
     def unpack(self, bucket: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """``bucket[world * payload_size]`` (the gathered payloads, rank-major) -> per-token values ``[T, width]`` and
@@ -164,7 +170,7 @@ class ShardPlan:
         the sizes from the plan).  Returns ``unpack`` of the bucket on ``dst``, ``None`` elsewhere."""
 
         me = dist.get_rank(group)  # rank INSIDE the group: what shards / tokens are indexed by, and what `dst` names
-        payload = self.pack(me, values, rank_logits)
+        payload = self.pack(me, values, rank_logits, out=self._send_buffer(values.device, me))
         # torch.distributed.gather takes the GLOBAL rank of the destination: translate for a real sub-group
         dst_global = dist.get_global_rank(group, dst) if group is not None and group is not dist.group.WORLD else dst
         if me == dst:

@@ -355,3 +355,63 @@ def test_job_sharded_process_of_many_contexts_equals_the_plain_call(tmp_path, wo
     for key in both["plain"]:
         assert both["plain"][key] == both["sharded"][key], key
     assert len(both["sharded"]["pruned_context"]) == 25  # top_k applied on the merged, re-ordered result
+
+
+def _failing_rank_worker(rank, world, port, out_path):
+    """Job-sharded process() where ONE rank's share fails (its splitter raises on a marked context): every rank must
+    come back with an exception -- the failing one with its own, the others with a report of who failed -- instead of
+    the healthy ranks blocking in the final gather forever."""
+
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from helpers import CharTokenizer, golden_stub_forward, host_only_model, period_splitter
+    from open_provence_amd.pipeline import assign_jobs
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        contexts = [f"Sentence one of context {i}. Sentence two of it is here. And a third one." for i in range(12)]
+        owner = assign_jobs([contexts], world)[0]
+        victim = next(i for i, r in enumerate(owner) if r == world - 1)  # a context the LAST rank owns
+        contexts[victim] = "POISON " + contexts[victim]
+        owner = assign_jobs([contexts], world)[0]
+        bad_rank = owner[victim]
+
+        def splitter(text):
+            if text.startswith("POISON"):
+                raise ValueError("splitter failed on purpose")
+            return period_splitter(text)
+
+        model = host_only_model(tokenizer=CharTokenizer(), max_length=96, forward=golden_stub_forward)
+        model.attach_process_group(None, dst=0, shard="jobs")
+        outcome = "returned"
+        try:
+            model.process("which sentence?", contexts, sentence_splitter=splitter, show_progress=False)
+        except ValueError as exc:
+            outcome = f"own:{exc}"
+        except RuntimeError as exc:
+            outcome = f"peer:{exc}"
+        torch.save({"outcome": outcome, "bad_rank": bad_rank}, f"{out_path}.{rank}")
+        # the group is still usable afterwards: a clean call goes through
+        clean = model.process("which sentence?", [c for c in contexts if not c.startswith("POISON")], sentence_splitter=splitter, show_progress=False)
+        assert (clean is not None) == (rank == 0)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_failing_rank_does_not_strand_the_others_in_the_gather(tmp_path, world):
+    out_path = str(tmp_path / "fail.pt")
+    mp.spawn(_failing_rank_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    reports = [torch.load(f"{out_path}.{r}", weights_only=False) for r in range(world)]
+    bad = reports[0]["bad_rank"]
+    for r, rep in enumerate(reports):
+        if r == bad:
+            assert rep["outcome"].startswith("own:") and "on purpose" in rep["outcome"], rep
+        else:
+            assert rep["outcome"].startswith("peer:") and f"{bad}: ValueError" in rep["outcome"], rep
