@@ -1,0 +1,139 @@
+"""The decision metric near the threshold (GPU).
+
+``north_star`` asks for identical pruned sentence indices; the reference decides with a strict ``>`` on the MEAN
+keep-probability of a sentence (standalone.py:3075-3082, 3116-3130).  A sentence's decision can only differ between two
+forwards when the threshold lies BETWEEN their two means, i.e. within |p_hip - p_ref| of the reference's value.  The
+golden process() fixtures keep every sentence >= 0.013 away from their threshold, so they never stress this.  Here a
+synthetic corpus of > 10 000 sentences goes through ``process()`` twice -- on the HIP path and with the forward replaced
+by the CPU oracle (same host pipeline, same weights) -- and thresholds are swept through the quantiles of the reference
+means so that hundreds of sentences sit within 2e-3 of one: flips are counted per kernel set, and
+
+* no sentence whose reference mean is more than 1e-3 away from a threshold may flip (for any threshold: max |dp| <= 1e-3);
+* the table (sentences near a threshold, flips among them, max / mean |dp|) is printed and kept in
+  profiles/r04_decision_flips.txt (scripts/decision_flips.py runs the same code).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CharTokenizer
+
+pytestmark = pytest.mark.gpu
+
+N_CONTEXTS, SENTENCES_PER_CONTEXT = 704, 16
+NEAR = 2e-3
+
+
+def corpus():
+    words = ("the tower is tall boats carry fish and salt to north city harbour many years ago it was new stone walls keep "
+             "wind out of narrow streets where traders sell cloth spice iron tools every morning before the tide turns").split()
+    rng = np.random.default_rng(11)
+    contexts = []
+    for _ in range(N_CONTEXTS):
+        sents = []
+        for _ in range(SENTENCES_PER_CONTEXT):
+            n = int(rng.integers(3, 7))
+            sents.append(" ".join(words[int(k)] for k in rng.integers(0, len(words), size=n)).capitalize() + ".")
+        contexts.append(" ".join(sents))
+    return "which boats carry salt to the north city?", contexts
+
+
+def dot_splitter(text):
+    out, start = [], 0
+    for i, ch in enumerate(text):
+        if ch == ".":
+            end = i + 1
+            while end < len(text) and text[end] == " ":
+                end += 1
+            out.append(text[start:end])
+            start = end
+    if start < len(text):
+        out.append(text[start:])
+    return out
+
+
+def sentence_means(model, question, contexts):
+    res = model.process(question, contexts, sentence_splitter=dot_splitter, show_progress=False, return_sentence_metrics=True,
+                        threshold=0.5, batch_size=64)
+    probs = [p for per_context in res["sentence_probabilities"] for p in per_context]
+    return np.asarray(probs, dtype=np.float64)
+
+
+def build_models(weights: str, no_f8: bool):
+    import os
+
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.modeling import OpenProvenceModel
+    from open_provence_amd.synthetic import named_dims, synth_state_dict
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = named_dims("xsmall", vocab_size=512)  # the character tokenizer's ids are code points < 256
+    state = synth_state_dict(dims, seed=7)
+    if weights == "bf16":
+        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    cfg = OpenProvenceConfig(base_model_config=dims.to_base_model_config(), tokenizer_name_or_path="x",
+                             pruning_config={"hidden_size": dims.hidden_size}, max_length=512)
+    old = os.environ.pop("OPEN_PROVENCE_NO_F8", None)
+    if no_f8:
+        os.environ["OPEN_PROVENCE_NO_F8"] = "1"
+    try:
+        hip = OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
+    finally:
+        os.environ.pop("OPEN_PROVENCE_NO_F8", None)
+        if old is not None:
+            os.environ["OPEN_PROVENCE_NO_F8"] = old
+
+    def oracle_fwd(input_ids=None, attention_mask=None, **_kw):
+        with torch.no_grad():
+            out = oracle_forward(state, dims, input_ids.cpu(), attention_mask.cpu(), attn="sdpa")
+        return {"ranking_logits": out.ranking_logits, "pruning_logits": out.pruning_logits}
+
+    ref = OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
+    ref.forward = oracle_fwd  # the reference's own monkeypatch idiom: process() then runs its padded protocol on it
+    return hip, ref
+
+
+def flip_table(p_hip: np.ndarray, p_ref: np.ndarray) -> dict:
+    """Thresholds = 41 quantiles of the reference means (so every threshold has neighbours): sentences within NEAR of
+    one, flips among them, flips of sentences further than 1e-3 from it (must be 0)."""
+
+    thresholds = np.quantile(p_ref, np.linspace(0.02, 0.98, 41))
+    near = flips_near = flips_far = 0
+    for th in thresholds:
+        d_ref, d_hip = p_ref > th, p_hip > th
+        close = np.abs(p_ref - th) <= NEAR
+        near += int(close.sum())
+        flips_near += int((d_ref != d_hip)[close].sum())
+        flips_far += int((d_ref != d_hip)[np.abs(p_ref - th) > 1e-3].sum())
+    dp = np.abs(p_hip - p_ref)
+    return {"sentences": int(p_ref.size), "thresholds": int(thresholds.size), "near_a_threshold": near, "flips_near": flips_near,
+            "flips_beyond_1e-3": flips_far, "max_dp": float(dp.max()), "mean_dp": float(dp.mean()),
+            "p99_dp": float(np.quantile(dp, 0.99))}
+
+
+CASES = [("fp32", False, "f16-f8-w"), ("bf16", False, "f16-f8"), ("fp32", True, "bf16x3")]
+
+
+_REFERENCE_MEANS: dict = {}  # weights -> the oracle's sentence means (the fp32 case serves two kernel sets)
+
+
+def run_case(weights, no_f8, kernel_set):
+    question, contexts = corpus()
+    hip, ref = build_models(weights, no_f8)
+    assert hip.encoder.effective_policy()["kernel_set"] == kernel_set
+    p_hip = sentence_means(hip, question, contexts)
+    if weights not in _REFERENCE_MEANS:
+        _REFERENCE_MEANS[weights] = sentence_means(ref, question, contexts)
+    p_ref = _REFERENCE_MEANS[weights]
+    assert p_hip.shape == p_ref.shape and p_ref.size >= 10_000
+    return flip_table(p_hip, p_ref)
+
+
+@pytest.mark.parametrize("weights,no_f8,kernel_set", CASES)
+def test_no_decision_flips_beyond_1e3_of_a_threshold(weights, no_f8, kernel_set):
+    table = run_case(weights, no_f8, kernel_set)
+    print(kernel_set, table)
+    assert table["near_a_threshold"] >= 500, table   # the sweep does stress the decision
+    assert table["flips_beyond_1e-3"] == 0, table
+    assert table["max_dp"] <= 1e-3, table            # hence: for ANY threshold, only sentences within 1e-3 of it can flip

@@ -87,8 +87,9 @@ def test_bench_configuration_matches_the_oracle(weights, kernel_set):
 
     ref_prune, ref_rank = _oracle(state, dims, [rows[i] for i in CHECKED])
     got_prune, got_rank = prune1[CHECKED], rank1[CHECKED]
-    assert np.abs(got_prune - ref_prune).max() < 1e-3, float(np.abs(got_prune - ref_prune).max())
-    assert np.abs(got_rank - ref_rank).max() < 1e-3, float(np.abs(got_rank - ref_rank).max())
+    # bar of the path: 1e-3; regression bound of THIS configuration: 8e-4 (measured <= 6.0e-4 on either checkpoint dtype)
+    assert np.abs(got_prune - ref_prune).max() < 8e-4, float(np.abs(got_prune - ref_prune).max())
+    assert np.abs(got_rank - ref_rank).max() < 8e-4, float(np.abs(got_rank - ref_rank).max())
     # the decision quantity of process(): keep-probabilities (standalone.py:2918-2924)
     keep = 1.0 / (1.0 + np.exp(-(got_prune[..., 1] - got_prune[..., 0]).astype(np.float64)))
     keep_ref = 1.0 / (1.0 + np.exp(-(ref_prune[..., 1] - ref_prune[..., 0]).astype(np.float64)))
@@ -151,7 +152,7 @@ def test_base_model_at_bench_size_matches_the_oracle(weights, kernel_set):
     # pairs 1 / 2 and 15 / 16 straddle XCD-group boundaries (8 row blocks = 2 pairs per group, 8 groups per round)
     worst = _run_and_check(enc, dims, state, rows, [0, 1, 2, 15, 16, 127, 128, 200, 254, 255], PANEL_KINDS)
     enc.close()
-    assert worst < 1e-3, worst
+    assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
 
 
 @pytest.mark.parametrize("weights", ["fp32", "bf16"])
@@ -169,7 +170,7 @@ def test_en_gte_varlen_at_bench_size_matches_the_oracle(weights):
     checked = sorted({0, len(rows) - 1, order[0], order[-1], len(rows) // 3, 2 * len(rows) // 3})
     worst = _run_and_check(enc, dims, state, rows, checked, PANEL_KINDS)
     enc.close()
-    assert worst < 1e-3, worst
+    assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
 
 
 def test_large_model_at_2048_matches_the_oracle():
@@ -181,4 +182,4 @@ def test_large_model_at_2048_matches_the_oracle():
     rows = synth_pair_batch(dims, 64, 2048, seed=1234)
     worst = _run_and_check(enc, dims, state, rows, [0, 63], PANEL_KINDS)
     enc.close()
-    assert worst < 1e-3, worst
+    assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
