@@ -90,6 +90,8 @@ ARITHMETIC_OF_KERNEL_SET = {
     "f16-f8-w": "fp16 hi + e4m3 lo split operands (weights: fp16 + two e4m3 planes), fp32 accumulate",
     "f16-f8": "fp16 hi + e4m3 lo split operands (weights: one fp16 plane), fp32 accumulate",
     "bf16x3": "bf16 (hi, lo) split operands, three products per term, fp32 accumulate",
+    "bf16x3+wi-f16-f8-w": "bf16 (hi, lo) split operands (three products per term); Wi GEMM: fp16 hi + e4m3 lo split operands; fp32 accumulate",
+    "bf16-weights+wi-f16-f8": "bf16 (hi, lo) split activations x single-plane bf16 weights; Wi GEMM: fp16 hi + e4m3 lo; fp32 accumulate",
     "bf16-weights": "bf16 (hi, lo) split activations x single-plane bf16 weights, fp32 accumulate",
     "bf16": "bf16 single pass, fp32 accumulate",
 }

@@ -86,6 +86,7 @@ enum op_flags {
   OP_FLAG_LAYER_M32 = 128,        /* whole-layer kernel on 32x32x16 MFMAs (hidden = 256): fewer cycles, more power per flop -- slower under the power limit (A/B hook) */
   OP_FLAG_ATTN_XCD_GROUP = 1024,  /* row path too: the XCD-grouped attention block map (the query blocks of a sequence-head follow each other on one XCD; default on the panel path only) (A/B hook) */
   OP_FLAG_PANEL_F8 = 2048,        /* hidden 512 / 768 (panel GEMMs): select the fp16 + e4m3 kernel sets there too.  OFF by default: through 19-25 layers their error against the fp32 reference reaches 0.45-1.0e-3 on logits (the (hi, lo) bf16 sets: 0.2-0.5e-3), too close to the 1e-3 bar of the path for +2.5 % (bf16 checkpoint) / +14 % (fp32) pairs/s */
+  OP_FLAG_PANEL_F8_WI = 4096,     /* hidden 512 / 768: the fp16 + e4m3 format in the Wi GEMM alone (52 % of the GEMM FLOPs; LayerNorm(mlp_norm) written in that format, h still as (hi, lo) bf16 pieces for the MLP output projection): the cheapest place for the format's error.  DEFAULT for fp32-valued weights (+5.6 % pairs/s on base, <= 5.4e-4 at 19-25 layers); this flag requests it for bf16-valued weights too (+0.7 %).  OP_FLAG_NO_F8 switches it off */
   OP_FLAG_NO_F8 = 512             /* never select kernel set 3 (fp16 hi + e4m3 lo operands in the whole-layer kernel): keep the (hi, lo) bf16 kernel sets (A/B and bit-identity test hook) */
 };
 
@@ -151,7 +152,8 @@ size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int 
  * operands carried as fp16 hi + e4m3 lo -- 1.5 instead of 2 MFMA units per product, 4 = the terms
  * of 0 in that format with the weights' lo part as a second e4m3 plane -- 2 units instead of 3 and
  * one kernel per layer instead of two), or -1 when the policy runs on the all-terms kernels with
- * cleared lo operands (same numerics, no speed-up).  Sets 3 / 4 replace 1 / 0 for hidden <= 256
+ * cleared lo operands (same numerics, no speed-up); 5 / 6 = sets 0 / 1 on the panel path with the Wi GEMM alone in the
+ * format of sets 4 / 3 (OP_FLAG_PANEL_F8_WI).  Sets 3 / 4 replace 1 / 0 for hidden <= 256
  * (hidden 512 / 768: with OP_FLAG_PANEL_F8) unless OP_FLAG_NO_F8 is set, set 3 needs every GEMM
  * weight to be exactly an fp16 value, and neither is taken for a checkpoint with a weight TENSOR
  * scaled into fp16's subnormal range (checked at load time).  Their fp16 operand plane has fp16's

@@ -28,6 +28,7 @@ OP_FLAG_NO_HEAD_FUSION = 256
 OP_FLAG_NO_F8 = 512
 OP_FLAG_ATTN_XCD_GROUP = 1024
 OP_FLAG_PANEL_F8 = 2048
+OP_FLAG_PANEL_F8_WI = 4096
 OP_POOL_CLS, OP_POOL_MEAN = 0, 1
 
 LIB_NAME = "libopenprovence_hip.so"

@@ -99,6 +99,7 @@ struct op_handle {
                                    // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value (no "f16 + fp8" set)
   bool f8_packs = false;           // the "f16 + fp8" weight packs exist (row path, hidden a multiple of 128)
   bool f8_off = false;             // op_set_compact_operands(h, 0): keep the (hi, lo) bf16 sets although the packs exist
+  bool wi_f8 = false;              // panel path, OP_FLAG_PANEL_F8_WI: the Wi GEMM (and its LayerNorm) in the fp16 + e4m3 format
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
   int n_cus = 256;          // compute units of the device (hipDeviceProp multiProcessorCount)
@@ -629,10 +630,12 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       // ---- panel path (hidden % 256 == 0): LayerNorm -> fragment-packed planes, k-streamed panel GEMMs ----
       const dim3 ln_grid((unsigned)(r_pad / 16));
       const bool pf8 = o_f8;  // kernel sets 3 / 4: activations as fp16 pieces + e4m3 pieces (x 2^12) of their lo part
-      const bool wlo8 = h->pi == opl::PI_F16_F8_W;
-      auto layer_norm_fp = [&](const float* w, bool with_lo, bool clear) -> int {
+      const bool wlo8 = h->pi == opl::PI_F16_F8_W || (h->wi_f8 && h->pi == opl::PI_ALL_TERMS);
+      // OP_FLAG_PANEL_F8_WI: the format in the Wi GEMM alone -- its LayerNorm writes fp16 + e4m3 pieces, its epilogue
+      // writes h as the (hi, lo) bf16 pieces the MLP output projection's kernel reads
+      auto layer_norm_fp = [&](const float* w, bool with_lo, bool clear, bool f8_here = false) -> int {
         OP_TRY(L.begin(PK_LN));
-        if (pf8) {
+        if (pf8 || f8_here) {
           hipLaunchKernelGGL(ln_fp8_kernel, ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad, w ? 1 : 0, ws.ln_hi,
                              ws.ln_lo);
           return L.end();
@@ -647,7 +650,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         if (clear) OP_TRY(clear_lo(L, ws.ln_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
         return OP_OK;
       };
-      auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles) -> int {
+      auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles, bool f8_here = false) -> int {
         OP_TRY(L.begin(kind));
         PanelParams q = pp;
         q.n_tiles = n_tiles;
@@ -655,8 +658,9 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         const unsigned per_xcd = ((unsigned)(r_pad / ROW_BM) + 7) / 8;  // row blocks each XCD owns
         const unsigned groups = (per_xcd + q.row_group - 1) / q.row_group;
         const dim3 grid(8u * groups * (unsigned)q.row_group * (unsigned)n_tiles);  // XCD-aware block map: see panel_gemm_kernel
-        const bool ok = pf8 ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
-                            : (epi == 102 ? opl::launch_panel_qkv(st, q, h->pi, grid) : opl::launch_panel(st, q, epi, h->pi, grid));
+        const bool ok = f8_here ? opl::launch_panel_f8(st, q, 103, wlo8, grid)
+                        : pf8   ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
+                                : (epi == 102 ? opl::launch_panel_qkv(st, q, h->pi, grid) : opl::launch_panel(st, q, epi, h->pi, grid));
         if (!ok) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
         return L.end();
       };
@@ -698,16 +702,17 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       pp.x = ws.x;
       pp.ld_out = H;
       OP_TRY(panel(PK_GEMM_ATTN_OUT, 100, pp, H / 256));
-      OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp));
+      const bool wi8 = h->wi_f8 && !pf8;
+      OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp && !wi8, wi8));
       pp.a_fp = ws.ln_hi;
       pp.a_lo8 = ws.ln_lo;
-      pp.wp = pf8 ? lw.wi_p16 : lw.wi_pk;
+      pp.wp = (pf8 || wi8) ? lw.wi_p16 : lw.wi_pk;
       pp.wp8 = lw.wi_p8;
       pp.w8_lo_off = (size_t)2 * I * H / 2;
       pp.o0 = ws.h_hi;
       pp.o0_lo8 = ws.h_lo;
       pp.ld_out = I;
-      OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128));
+      OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128, wi8));
       OP_TRY(clear_h());
       pp.a_fp = ws.h_hi;
       pp.a_lo8 = ws.h_lo;
@@ -939,7 +944,9 @@ int op_create(const op_config* cfg, op_handle** out) {
   OP_CREATE_HIP(hipMemset(h->f16_fit_dev, 0, 2 * sizeof(float)));
   // panel path: opt-in (OP_FLAG_PANEL_F8) -- at the depth of the published models (19-25 layers) the format's error
   // reaches 0.45-1.0e-3 on logits, the (hi, lo) bf16 sets stay at 0.2-0.5e-3 (scripts/f8_depth_check.py)
-  h->f8_packs = ((h->row_path && (H / 32) % 4 == 0) || (h->panel_path && (cfg->flags & OP_FLAG_PANEL_F8))) && !(cfg->flags & OP_FLAG_NO_F8);
+  // (panel path: the packs are always built -- the Wi GEMM takes the format by default for fp32-valued weights, see
+  // resolve_policy; OP_FLAG_PANEL_F8 extends it to every GEMM of the layer)
+  h->f8_packs = ((h->row_path && (H / 32) % 4 == 0) || h->panel_path) && !(cfg->flags & OP_FLAG_NO_F8);
   OP_CREATE_TRY(dev_alloc(h, &h->emb, (size_t)h->V * H));
   OP_CREATE_TRY(dev_alloc(h, &h->emb_norm, H));
   OP_CREATE_TRY(dev_alloc(h, &h->final_norm, H));
@@ -1248,6 +1255,7 @@ int resolve_policy(op_handle* h) {
   h->eff = e;
   h->pi = 0;
   h->emulate = true;
+  h->wi_f8 = false;
   if (!(h->cfg.flags & OP_FLAG_NO_POLICY_KERNELS)) {
     for (int i = 0; i < opl::N_POLICIES; ++i)
       if (opl::kPolicies[i] == e) {
@@ -1259,10 +1267,22 @@ int resolve_policy(op_handle* h) {
     // set evaluates the same terms at 1.5 instead of 2 MFMA units per product (op_internal.h)
     const bool f8_ok = !h->emulate && h->f8_packs && !h->f8_off && !any_lo[OP_FAM_COUNT + 2] &&
                        !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32));
-    if (f8_ok && h->pi == opl::PI_BF16_WEIGHTS && !any_lo[OP_FAM_COUNT]) h->pi = opl::PI_F16_F8;
-    // every term requested and carried (fp32-valued weights): the same format with the weights' lo part as a third
-    // plane -- one kernel per layer at 2 MFMA units per product instead of two kernels at 3
-    if (f8_ok && h->pi == opl::PI_ALL_TERMS) h->pi = opl::PI_F16_F8_W;
+    // Panel path (hidden 512 / 768).  The whole layer in the format (OP_FLAG_PANEL_F8) costs 0.45-1.0e-3 on logits at the
+    // published depths: opt-in.  The Wi GEMM ALONE -- 52 % of the GEMM FLOPs -- costs 1-1.5e-4 (base / large / en-gte at
+    // 19-25 layers: <= 5.4e-4 against the oracle where the (hi, lo) bf16 sets give <= 4.7e-4; scripts/f8_depth_check.py,
+    // profiles/r04_f8_depth_check.txt) and takes the fp32-valued Wi GEMM from 3 to 2 MFMA units per product: +5.6 %
+    // pairs/s on base -- the DEFAULT for fp32-valued weights.  For bf16-valued weights (2 -> 1.5 units in a GEMM that
+    // is not pipe-bound there) it measures +0.7 %: only on request (OP_FLAG_PANEL_F8_WI).
+    const bool full_f8 = h->row_path || (h->cfg.flags & OP_FLAG_PANEL_F8);
+    const bool wi_only = h->panel_path && !full_f8;
+    h->wi_f8 = wi_only && f8_ok &&
+               (h->pi == opl::PI_ALL_TERMS || ((h->cfg.flags & OP_FLAG_PANEL_F8_WI) && h->pi == opl::PI_BF16_WEIGHTS && !any_lo[OP_FAM_COUNT]));
+    if (!wi_only) {
+      if (f8_ok && h->pi == opl::PI_BF16_WEIGHTS && !any_lo[OP_FAM_COUNT]) h->pi = opl::PI_F16_F8;
+      // every term requested and carried (fp32-valued weights): the same format with the weights' lo part as a third
+      // plane -- one kernel per layer at 2 MFMA units per product instead of two kernels at 3
+      if (f8_ok && h->pi == opl::PI_ALL_TERMS) h->pi = opl::PI_F16_F8_W;
+    }
   } else if (opl::kPolicies[0] == e) {
     h->emulate = false;
   }
@@ -1311,7 +1331,7 @@ int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set) {
   terms_out[OP_FAM_ATTN_OUT] = (uint8_t)h->eff.attn_out;
   terms_out[OP_FAM_WI] = (uint8_t)h->eff.wi;
   terms_out[OP_FAM_MLP_OUT] = (uint8_t)h->eff.mlp_out;
-  *kernel_set = h->emulate ? -1 : h->pi;
+  *kernel_set = h->emulate ? -1 : (h->wi_f8 ? 5 + h->pi : h->pi);  // 5 / 6: sets 0 / 1 with the Wi GEMM in the fp16 + e4m3 format
   return OP_OK;
 }
 

@@ -63,7 +63,8 @@ namespace {
 template <bool WLO>
 bool launch_f8_t(hipStream_t st, const PanelParams& p, int epi, dim3 grid) {
   const dim3 block(256);
-  if (epi == PE_GEGLU) hipLaunchKernelGGL((panel_f8_gemm_kernel<PE_GEGLU, WLO, 1>), grid, block, 0, st, p);
+  if (epi == 103) hipLaunchKernelGGL((panel_f8_gemm_kernel<PE_GEGLU, WLO, 2>), grid, block, 0, st, p);  // h as (hi, lo) bf16 pieces
+  else if (epi == PE_GEGLU) hipLaunchKernelGGL((panel_f8_gemm_kernel<PE_GEGLU, WLO, 1>), grid, block, 0, st, p);
   else if (epi == 100 || epi == 101) hipLaunchKernelGGL((panel_f8_gemm_kernel<PE_RESIDUAL, WLO, 0>), grid, block, 0, st, p);
   else return false;
   return true;

@@ -590,6 +590,29 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
     // h in the format the MLP output projection reads: fp16 pieces [rb][I/32][512] + one e4m3 half-fragment piece per
     // two k-steps; this panel's four k-steps are two of those
     const int kb_out = p.ld_out >> 5;
+    if constexpr (OLO == 2) {
+      // h as (hi, lo) bf16 pieces (panel_gemm_kernel's layout): the Wi GEMM alone runs in the fp16 + e4m3 format and the
+      // MLP output projection that reads h stays on the (hi, lo) bf16 kernels (OP_FLAG_PANEL_F8_WI)
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        const size_t rb = (size_t)((m0 >> 4) + mf);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = gelu_erf(acc[2 * s][mf][r]) * acc[8 + 2 * s][mf][r];
+            v[4 + r] = gelu_erf(acc[2 * s + 1][mf][r]) * acc[8 + 2 * s + 1][mf][r];
+          }
+          bf16x8 hi, lo;
+          pack8<true>(v, hi, lo);
+          u16* dst = o0 + ((rb * kb_out + (size_t)(tile * 4 + s)) * 2) * 512 + lane * 8;
+          store_stream16(dst, as_u4(hi));
+          store_stream16(dst + 512, as_u4(lo));
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
       const size_t rb = (size_t)((m0 >> 4) + mf);

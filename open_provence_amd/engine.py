@@ -32,6 +32,7 @@ _ENV_FLAGS = {
     "OPEN_PROVENCE_NO_F8": _lib.OP_FLAG_NO_F8,
     "OPEN_PROVENCE_ATTN_XCD_GROUP": _lib.OP_FLAG_ATTN_XCD_GROUP,
     "OPEN_PROVENCE_PANEL_F8": _lib.OP_FLAG_PANEL_F8,
+    "OPEN_PROVENCE_PANEL_F8_WI": _lib.OP_FLAG_PANEL_F8_WI,
 }
 
 
@@ -189,7 +190,8 @@ class HipEncoder:
         kernel_set = ctypes.c_int(0)
         code = self.lib.op_effective_policy(self._handle, terms, ctypes.byref(kernel_set))
         _lib.check(self.lib, self._handle, code, "op_effective_policy")
-        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", 4: "f16-f8-w", -1: "all-terms kernels, cleared lo operands"}
+        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", 4: "f16-f8-w", 5: "bf16x3+wi-f16-f8-w", 6: "bf16-weights+wi-f16-f8",
+                 -1: "all-terms kernels, cleared lo operands"}
         return {
             "terms": {name: int(terms[i]) for i, name in enumerate(_lib.OP_FAMILIES)},
             "kernel_set": names.get(int(kernel_set.value), str(kernel_set.value)),

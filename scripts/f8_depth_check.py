@@ -24,7 +24,7 @@ for model_name, lengths in CASES:
         for row in rows:
             ids = torch.tensor([row], dtype=torch.long)
             refs.append(oracle_forward(state, dims, ids, torch.ones_like(ids)))
-        for flags in (2048, 512):  # OP_FLAG_PANEL_F8 / OP_FLAG_NO_F8
+        for flags in (2048, 4096, 512):  # OP_FLAG_PANEL_F8 / OP_FLAG_PANEL_F8_WI / OP_FLAG_NO_F8
             enc = HipEncoder(dims, device="cuda", flags=flags)
             enc.load_state_dict(state)
             ks = enc.effective_policy()["kernel_set"]
@@ -35,5 +35,5 @@ for model_name, lengths in CASES:
                 er = (rank[i].cpu() - ref.ranking_logits[0]).abs().max().item()
                 errs.append(f"{lengths[i]}: {ep:.2e}/{er:.2e}")
             scale = max(float(r.pruning_logits.abs().max()) for r in refs)
-            print(f"{model_name:7s} {weights} [{ks:12s}] max|logit| {scale:6.1f}  " + "  ".join(errs), flush=True)
+            print(f"{model_name:7s} {weights} [{ks:22s}] max|logit| {scale:6.1f}  " + "  ".join(errs), flush=True)
             enc.close()

@@ -37,8 +37,31 @@ def make_request(n_contexts: int, chars: int, seed: int = 5):
     return "which greek letters appear here", contexts
 
 
+def build_e2e_model():
+    """Model factory (module level: ProcessFrontEnd's worker processes rebuild it by name); tokenizer from the environment."""
+
+    from open_provence_amd.config import OpenProvenceConfig
+    from open_provence_amd.modeling import OpenProvenceModel
+    from open_provence_amd.synthetic import named_dims, synth_state_dict
+
+    dims = named_dims("xsmall")
+    cfg = OpenProvenceConfig(base_model_config=dims.to_base_model_config(), tokenizer_name_or_path="x",
+                             pruning_config={"hidden_size": dims.hidden_size}, max_length=512)
+    if os.environ.get("E2E_TOKENIZER", "char") == "wordpiece":
+        from helpers import build_wordpiece_tokenizer
+
+        tok = build_wordpiece_tokenizer(True)
+    else:
+        tok = CharTokenizer()
+    model = OpenProvenceModel(cfg, device="cuda", tokenizer=tok, state_dict=synth_state_dict(dims, 7))
+    model.tokenizer.model_max_length = 512
+    return model
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--front-end", type=int, default=0,
+                    help="N > 0: open_provence_amd.frontend.ProcessFrontEnd with N worker processes (all on cuda:0) beside the caller")
     ap.add_argument("--contexts", type=int, default=256)
     ap.add_argument("--chars", type=int, default=470)
     ap.add_argument("--reps", type=int, default=3)
@@ -51,26 +74,20 @@ def main():
     ap.add_argument("--chars-are-words", action="store_true", help="wordpiece: size the contexts in words (~tokens) instead of characters")
     args = ap.parse_args()
 
-    from open_provence_amd.config import OpenProvenceConfig
-    from open_provence_amd.modeling import OpenProvenceModel
-    from open_provence_amd.synthetic import named_dims, synth_state_dict
-
-    dims = named_dims("xsmall")
-    cfg = OpenProvenceConfig(base_model_config=dims.to_base_model_config(), tokenizer_name_or_path="x",
-                             pruning_config={"hidden_size": dims.hidden_size}, max_length=512)
-    if args.tokenizer == "wordpiece":
-        from helpers import build_wordpiece_tokenizer
-
-        tok = build_wordpiece_tokenizer(True)
-    else:
-        tok = CharTokenizer()
-    model = OpenProvenceModel(cfg, device="cuda", tokenizer=tok, state_dict=synth_state_dict(dims, 7))
-    model.tokenizer.model_max_length = 512
+    os.environ["E2E_TOKENIZER"] = args.tokenizer
     question, contexts = make_request(args.contexts, args.chars)
+    front = None
+    if args.front_end > 0:
+        from open_provence_amd.frontend import ProcessFrontEnd
+
+        front = ProcessFrontEnd(build_e2e_model, workers=args.front_end)
+        target = front
+    else:
+        target = build_e2e_model()
 
     def call():
-        return model.process(question, contexts, threshold=0.1, batch_size=args.batch_size, sentence_splitter=period_splitter,
-                             show_progress=False, preprocess_batch_size=args.preprocess_batch, preprocess_workers=args.workers)
+        return target.process(question, contexts, threshold=0.1, batch_size=args.batch_size, sentence_splitter=period_splitter,
+                              show_progress=False, preprocess_batch_size=args.preprocess_batch, preprocess_workers=args.workers)
 
     call()
     torch.cuda.synchronize()
@@ -88,7 +105,7 @@ def main():
         if best is None or dt < best[0]:
             best = (dt, out["timing"], usage)
     dt, timing, usage = best
-    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "tokenizer": args.tokenizer, "workers": args.workers, "wall_s": dt, "contexts_per_s": args.contexts / dt, "rusage": usage,
+    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "tokenizer": args.tokenizer, "workers": args.workers, "front_end_processes": args.front_end, "wall_s": dt, "contexts_per_s": args.contexts / dt, "rusage": usage,
                       "timing": {k: round(float(v), 5) for k, v in timing.items()}}))
     if args.profile:
         pr = cProfile.Profile()
@@ -98,6 +115,8 @@ def main():
         buf = io.StringIO()
         pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(35)
         print(buf.getvalue()[:6000])
+    if front is not None:
+        front.close()
 
 
 if __name__ == "__main__":

@@ -292,3 +292,9 @@ WORDPIECE_CASES = [
          context=" ".join(f"In year {i} the boats carry fish and salt to the harbour of the north city." for i in range(30)),
          kwargs=dict(threshold=0.5)),
 ]
+
+
+def frontend_stub_model():
+    """Model factory of tests/test_frontend.py (module-level: the front-end's worker processes unpickle it by name)."""
+
+    return host_only_model(tokenizer=CharTokenizer(), max_length=96, forward=golden_stub_forward)

@@ -50,7 +50,8 @@ def test_bench_json_line_contract():
     assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
     # the panel path (base dims) as a sub-record, both checkpoint dtypes: default flags = the (hi, lo) bf16 kernel sets
     base = line["base_model"]
-    assert base["model"] == "base" and base["fp32_checkpoint"]["kernel_set"] == "bf16x3" and base["bf16_checkpoint"]["kernel_set"] == "bf16-weights"
+    # (the Wi GEMM of an fp32-valued checkpoint takes the fp16 + e4m3 format by default: kernel set "bf16x3+wi-f16-f8-w")
+    assert base["model"] == "base" and base["fp32_checkpoint"]["kernel_set"] == "bf16x3+wi-f16-f8-w" and base["bf16_checkpoint"]["kernel_set"] == "bf16-weights"
     assert base["fp32_checkpoint"]["value"] > 0 and base["bf16_checkpoint"]["value"] > 0
     assert "bf16" in base["fp32_checkpoint"]["dtype"] and 0.5 < base["fp32_checkpoint"]["shader_clock_ghz"] < 3.0
 

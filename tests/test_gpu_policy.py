@@ -20,6 +20,7 @@ NO_LAYER_FUSION = 32    # OP_FLAG_NO_LAYER_FUSION: two fused kernels per layer (
 LAYER_M32 = 128         # OP_FLAG_LAYER_M32: the whole-layer kernel on 32x32x16 MFMAs (hidden = 256)
 NO_F8 = 512             # OP_FLAG_NO_F8: keep the (hi, lo) bf16 whole-layer kernel (kernel set "bf16-weights")
 PANEL_F8 = 2048         # OP_FLAG_PANEL_F8: the fp16 + e4m3 kernel sets on the panel path (hidden 512 / 768) too -- opt-in
+PANEL_F8_WI = 4096      # OP_FLAG_PANEL_F8_WI: that format in the Wi GEMM alone (default for fp32-valued weights)
 
 
 @pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
@@ -208,9 +209,13 @@ def test_panel_path_f16_f8_kernel_sets(fixture, weights):
         state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v for k, v in state.items()}
     rows = rows_from_fixture(arrays)
     pre = bool(meta.get("prune_pre_final_norm", False))
-    expected = {("bf16", PANEL_F8): "f16-f8", ("bf16", 0): "bf16-weights", ("fp32", PANEL_F8): "f16-f8-w", ("fp32", 0): "bf16x3"}
+    # default flags: fp32-valued weights take the format in the Wi GEMM alone (set "bf16x3+wi-f16-f8-w"), bf16-valued ones
+    # only with OP_FLAG_PANEL_F8_WI; NO_F8: the (hi, lo) bf16 sets everywhere
+    expected = {("bf16", PANEL_F8): "f16-f8", ("bf16", 0): "bf16-weights", ("fp32", PANEL_F8): "f16-f8-w", ("fp32", 0): "bf16x3+wi-f16-f8-w",
+                ("bf16", PANEL_F8_WI): "bf16-weights+wi-f16-f8", ("fp32", PANEL_F8_WI): "bf16x3+wi-f16-f8-w",
+                ("bf16", NO_F8): "bf16-weights", ("fp32", NO_F8): "bf16x3"}
     outs = {}
-    for flags in (PANEL_F8, 0):
+    for flags in (PANEL_F8, 0, PANEL_F8_WI, NO_F8):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags, prune_pre_final_norm=pre)
         enc.load_state_dict(state)
         assert enc.effective_policy()["kernel_set"] == expected[(weights, flags)]
@@ -224,12 +229,17 @@ def test_panel_path_f16_f8_kernel_sets(fixture, weights):
     ids, mask = pad_rows(rows)
     ref = oracle_forward(state, dims, ids, mask, prune_pre_final_norm=pre)
     m = mask.bool().numpy()
-    for flags in (PANEL_F8, 0):  # tolerance of the path: 1e-3 on logits against the CPU reference arithmetic
+    for flags in (PANEL_F8, 0, PANEL_F8_WI, NO_F8):  # tolerance of the path: 1e-3 on logits against the CPU reference arithmetic
         assert np.isfinite(outs[flags][0]).all() and np.isfinite(outs[flags][1]).all()
         assert np.abs(outs[flags][0] - ref.pruning_logits.numpy()[m]).max() < 1e-3, flags
         assert np.abs(outs[flags][1] - ref.ranking_logits.numpy()).max() < 1e-3, flags
-    assert np.abs(outs[0][0] - outs[PANEL_F8][0]).max() < 5e-4
-    assert np.abs(outs[0][1] - outs[PANEL_F8][1]).max() < 5e-4
+    assert np.abs(outs[NO_F8][0] - outs[PANEL_F8][0]).max() < 5e-4
+    assert np.abs(outs[NO_F8][1] - outs[PANEL_F8][1]).max() < 5e-4
+    assert np.abs(outs[NO_F8][0] - outs[PANEL_F8_WI][0]).max() < 3e-4  # the Wi GEMM alone: closer to the bf16 sets
+    if weights == "bf16":  # bf16-valued weights: the default IS the (hi, lo) bf16 set
+        assert np.array_equal(outs[0][0], outs[NO_F8][0])
+    else:
+        assert np.array_equal(outs[0][0], outs[PANEL_F8_WI][0])
 
 
 @pytest.mark.parametrize("weights", ["bf16", "fp32"])

@@ -140,7 +140,7 @@ def _run_and_check(enc, dims, state, rows, checked, expect_kinds):
 PANEL_KINDS = {"gemm_qkv_rope", "gemm_attn_out", "gemm_wi_geglu", "gemm_mlp_out", "layer_norm", "attn_global", "attn_local"}
 
 
-@pytest.mark.parametrize("weights,kernel_set", [("fp32", "bf16x3"), ("bf16", "bf16-weights")])
+@pytest.mark.parametrize("weights,kernel_set", [("fp32", "bf16x3+wi-f16-f8-w"), ("bf16", "bf16-weights")])
 def test_base_model_at_bench_size_matches_the_oracle(weights, kernel_set):
     """bench.py's `base_model` sub-record and `--model base`: base dims (H = 512, 19 layers), 256 x 512 = 1024 row blocks."""
 
