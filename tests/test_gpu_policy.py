@@ -391,7 +391,7 @@ def test_overflow_of_the_f8_sets_falls_back_to_the_bf16_sets_instead_of_failing(
     want = plain(input_ids=ids, attention_mask=mask)
     text = "alpha beta gamma. delta epsilon zeta eta. theta iota kappa lambda mu. " * 6
     want_proc = plain.process("what is gamma", [text, text[:120]], sentence_splitter=period_splitter, show_progress=False,
-                              return_sentence_metrics=True)
+                              return_sentence_metrics=True, return_sentence_texts=True)
     want_raw = plain.get_raw_predictions("what is gamma", [text[:200]])
     for entry in ("forward", "process", "raw"):
         model = model_with(False)
@@ -403,7 +403,7 @@ def test_overflow_of_the_f8_sets_falls_back_to_the_bf16_sets_instead_of_failing(
                 assert torch.equal(got.ranking_logits, want.ranking_logits) and torch.equal(got.pruning_logits, want.pruning_logits)
             elif entry == "process":
                 got = model.process("what is gamma", [text, text[:120]], sentence_splitter=period_splitter, show_progress=False,
-                                    return_sentence_metrics=True)
+                                    return_sentence_metrics=True, return_sentence_texts=True)
                 for key in ("pruned_context", "kept_sentences", "removed_sentences", "reranking_score", "sentence_probabilities"):
                     assert got[key] == want_proc[key], key
             else:
