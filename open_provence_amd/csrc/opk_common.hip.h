@@ -434,10 +434,14 @@ __device__ __forceinline__ void frag_stream2i(uint32_t lds_addr, Body&& body) {
     constexpr int set = s % SETS;
     constexpr int nxt = s + DEPTH + 1;
     constexpr int ahead = (NSTEPS - 1 - s) < DEPTH ? (NSTEPS - 1 - s) : DEPTH;
+#ifndef OPK_ABL_NO_FRAG_WAIT
     lds_wait2<2 * ahead>(w[set][0], w[set][1]);
+#endif
     auto rd = [&](auto j_tag, f32x4& p0) {
       constexpr int j = decltype(j_tag)::value;
+#ifndef OPK_ABL_NO_FRAG_READS
       if constexpr (nxt < NSTEPS) w[nxt % SETS][j] = lds_read_frag_after1<Off::at(nxt < NSTEPS ? nxt : 0, j)>(lds_addr, p0);
+#endif
     };
     body(t, w[set][0], w[set][1], rd);
     __builtin_amdgcn_sched_barrier(0);

@@ -163,6 +163,8 @@ def main() -> None:
     ap.add_argument("--schemes", default="bf16,f16,bf16x2,bf16x3,f16+f8,f16+2f8,bf16+f8")
     ap.add_argument("--families", default="", help="comma list: apply the scheme to these families only (others exact)")
     ap.add_argument("--gemm-only", action="store_true", help="attention (qk, pv) stays bf16x3 whatever the scheme")
+    ap.add_argument("--override", default="", help="per-family scheme on top of --schemes, e.g. 'wqkv=f16+f8;wi=f16+f8' "
+                    "(several alternatives separated by '|': each is run against every scheme)")
     args = ap.parse_args()
     torch.set_num_threads(8)
     for name in args.fixtures.split(","):
@@ -176,9 +178,13 @@ def main() -> None:
         mask = torch.from_numpy(arrays["attention_mask"]).long()
         m = mask.bool()
         ref_rank, ref_prune = forward(state, dims, ids, mask, make_mm("exact"), resid_dtype=torch.float64)
-        for sch in args.schemes.split(","):
+        for sch, ovr in ((a, b) for a in args.schemes.split(",") for b in args.override.split("|")):
             fams = set(args.families.split(",")) if args.families else None
             mm = make_mm(sch, fams)
+            if ovr:
+                table = {k: make_mm(v) for k, v in (item.split("=") for item in ovr.split(";"))}
+                mm = lambda a, b, f, base=mm, table=table: table.get(f, base)(a, b, f)  # noqa: E731
+                sch = f"{sch} [{ovr}]"
             if args.gemm_only:
                 inner, att = mm, make_mm("bf16x3")
                 mm = lambda a, b, f, inner=inner, att=att: (att if f in ("qk", "pv") else inner)(a, b, f)  # noqa: E731
