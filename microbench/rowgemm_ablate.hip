@@ -1,9 +1,10 @@
 // Measurement aid (not product code): times the REAL fused kernel x += o Wo^T ; h = GeGLU(LN(x) Wi^T)
 // (rowgemm_kernel<8, RE_GEGLU, RP_KSTREAM, T1, T2, 1, 4, 2> of open_provence_amd/csrc/opk_rowgemm.hip.h) at the bench
-// size (131072 rows, H = 256, I = 1024) on random finite data.  Built once per ablation switch of that header
-// (scripts/ablate_rowgemm.sh), each binary prints the kernel's average time: the differences price the components
-// of the chunk loop.  Results of ablated builds are numerically meaningless by design.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize [-DOPK_ABL_...] -DABL_T=1 -o x rowgemm_ablate.hip
+// size (131072 rows, H = 256, I = 1024) on random finite data.  Built once per variant (scripts/ablate_x.sh), each
+// binary prints the kernel's average time and, with -DOPK_TIMING, wave 0's cycle stamps.  The ablation switches
+// (-DOPK_ABL_..., results numerically meaningless by design) exist only in the instrumented copy of csrc/ that
+// scripts/instrumented_csrc.sh makes from microbench/experiments/rowgemm_ablation_hooks.patch:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I <csrc dir> [-DOPK_TIMING] [-DOPK_ABL_...] -DABL_T=1 -o x rowgemm_ablate.hip
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -11,8 +12,8 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../open_provence_amd/csrc/opk_rowgemm.hip.h"
-#include "../open_provence_amd/csrc/opk_layer32.hip.h"
+#include "opk_rowgemm.hip.h"
+#include "opk_layer32.hip.h"
 
 #ifndef ABL_T
 #define ABL_T 1

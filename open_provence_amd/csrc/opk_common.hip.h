@@ -434,14 +434,10 @@ __device__ __forceinline__ void frag_stream2i(uint32_t lds_addr, Body&& body) {
     constexpr int set = s % SETS;
     constexpr int nxt = s + DEPTH + 1;
     constexpr int ahead = (NSTEPS - 1 - s) < DEPTH ? (NSTEPS - 1 - s) : DEPTH;
-#ifndef OPK_ABL_NO_FRAG_WAIT
     lds_wait2<2 * ahead>(w[set][0], w[set][1]);
-#endif
     auto rd = [&](auto j_tag, f32x4& p0) {
       constexpr int j = decltype(j_tag)::value;
-#ifndef OPK_ABL_NO_FRAG_READS
       if constexpr (nxt < NSTEPS) w[nxt % SETS][j] = lds_read_frag_after1<Off::at(nxt < NSTEPS ? nxt : 0, j)>(lds_addr, p0);
-#endif
     };
     body(t, w[set][0], w[set][1], rd);
     __builtin_amdgcn_sched_barrier(0);
@@ -452,40 +448,24 @@ __device__ __forceinline__ void frag_stream2i(uint32_t lds_addr, Body&& body) {
 // write-back) are non-temporal (global_store ... nt).  As ordinary stores they displace the next block's operands from
 // the XCD's L2: in the whole-layer kernel the phase that starts a block (operand fetch + attention-output projection)
 // took 37 k cycles behind the previous block's 393 KB of plain q / k / v^T stores, 28 k behind nt stores, 26 k with the
-// residual write-back nt as well (microbench/rowgemm_ablate.hip -DOPK_TIMING).  -DOPK_PLAIN_STORES restores plain stores.
+// residual write-back nt as well (microbench/rowgemm_ablate.hip -DOPK_TIMING; plain-store / plain-load switches: microbench/experiments/rowgemm_ablation_hooks.patch).
 __device__ __forceinline__ void store_stream16(void* dst, const uint4& v) {
-#ifdef OPK_PLAIN_STORES
-  *reinterpret_cast<uint4*>(dst) = v;
-#else
   typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
   __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(dst));
-#endif
 }
 __device__ __forceinline__ void store_stream16(float* dst, const float4& v) {
-#ifdef OPK_PLAIN_STORES
-  *reinterpret_cast<float4*>(dst) = v;
-#else
   typedef float f32x4_nt __attribute__((ext_vector_type(4)));
   __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(dst));
-#endif
 }
 
 // The matching loads for operands a launch reads exactly once (activation fragments, residual rows): global_load ... nt.
 __device__ __forceinline__ bf16x8 load_stream_frag(const u16* src) {
-#ifdef OPK_PLAIN_LOADS
-  return *reinterpret_cast<const bf16x8*>(src);
-#else
   return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src));
-#endif
 }
 __device__ __forceinline__ float4 load_stream_f4(const float* src) {
-#ifdef OPK_PLAIN_LOADS
-  return *reinterpret_cast<const float4*>(src);
-#else
   typedef float f32x4_ntl __attribute__((ext_vector_type(4)));
   const f32x4_ntl v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ntl*>(src));
   return make_float4(v.x, v.y, v.z, v.w);
-#endif
 }
 
 // GELU (exact-erf form) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |x| he(|x|),  he(a) = erfc(a / sqrt 2) / 2,

@@ -6,15 +6,11 @@
 
 #include "opk_common.hip.h"
 
-// Measurement hooks (microbench/rowgemm_ablate.hip compiles this header with them; the library never defines them):
-//   OPK_TIMING / OPK_SEG_TIMING  cycle stamps of wave 0 at the phase boundaries (instrumentation only)
-//   OPK_ABL_NO_DMA, OPK_ABL_NO_BARRIER, OPK_ABL_NO_MLP_VALU  price one component of the loops (results are wrong)
-//   OPK_QKV_SINGLE  the F8 kernel sets' q / k / v^T projection with one chunk per barrier (the loop the (hi, lo) bf16 sets
-//                   use) instead of chunk pairs; OPK_QKV_STREAM_TIMING, OPK_ABL_NO_QKV_STORE, OPK_ABL_NO_QKV_RIDERS (and
-//                   OPK_ABL_NO_FRAG_READS / _WAIT in opk_common.hip.h) price the pair stream's parts
-//                   (profiles/r04_qkv_pair_loop.txt)
-// Experiments that did not ship (ring stream without a drain at the stage boundary, operand prefetch, the first
-// LayerNorm form, store / epilogue ablations) are recorded with their numbers in DESIGN.md section 4 and profiles/r0*.
+// Measurement hook kept in this header: OPK_TIMING / OPK_SEG_TIMING -- cycle stamps of wave 0 at the phase boundaries
+// (microbench/rowgemm_ablate.hip compiles the header with them; the library never defines them).  The ablation switches
+// that price one component of a loop with wrong results (no DMA, no barrier, no GeGLU arithmetic, the q / k / v^T pair
+// stream's parts, one chunk per barrier) are NOT here: microbench/experiments/rowgemm_ablation_hooks.patch adds them to a
+// scratch copy of csrc/ (scripts/ablate_x.sh); their numbers are in DESIGN.md section 4 and profiles/r0*.
 namespace opk {
 
 // ----------------------------------------------------------------------------------------------
@@ -528,11 +524,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   // 2t and 2t+1 back to back.  Instruction u of a wave copies piece u % GS of its group u / GS (GS consecutive pieces
   // through one pointer / M0 and the DMA's immediate offset); the chunk a group belongs to is a wave-uniform integer
   // select, never control flow (a DMA under a branch is drained at the join).
-#ifdef OPK_QKV_SINGLE
-  constexpr bool QKV_PAIRS = false;
-#else
   constexpr bool QKV_PAIRS = F8 != 0 && EPI == RE_QKV;
-#endif
+  constexpr int FRAG_ILV = 4;  // fragment groups in flight where the reads sit between the MFMAs (frag_stream2i); two measured slower in the forward
   constexpr int PAIR_DMA = QKV_PAIRS ? 2 * CHUNK_PIECES8 / WAVES : 1;  // DMA instructions per wave and pair
   constexpr int PAIR_GS = (2 * CHUNK_PIECES8 / 4) % WAVES == 0 ? 4 : 2;  // pieces per group (hidden 128 / 384: 2)
   static_assert(!QKV_PAIRS || (CHUNK_PIECES8 % PAIR_GS == 0 && (2 * CHUNK_PIECES8 / PAIR_GS) % WAVES == 0 && 2 * STAGE <= STAGE_ALLOC),
@@ -1192,17 +1185,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       constexpr int VPS = (NV + KS - 1) / KS;
       auto geglu_slice = [&](const f32x4 (&av)[2][MF], float (&gv)[MF][4], auto slice_tag, auto&& pack) {
         constexpr int sl = decltype(slice_tag)::value;
-#ifdef OPK_ABL_NO_MLP_VALU
-        // ablation: no GeGLU / split / pack; the accumulators stay live (in AGPRs) and h is opaque to the compiler
-        static_for<VPS>([&](auto j_tag) {
-          constexpr int i = sl * VPS + decltype(j_tag)::value;
-          if constexpr (i < NV) {
-            asm volatile("" ::"a"(av[0][i >> 2][i & 3]), "a"(av[1][i >> 2][i & 3]));
-            if constexpr ((i & 3) == 3) pack(std::integral_constant<int, (i >> 2)>{});
-          }
-        });
-        return;
-#endif
         // Stage-major: slice sl advances ALL NV values of the chunk by 8 / KS stages of gelu(input) * gate (five
         // polynomial FMAs, exp2, the final FMA, the product with the gate + split / pack), so consecutive vector
         // instructions belong to different values: no instruction waits for the one issued just before it.
@@ -1254,10 +1236,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       };
       auto pack_h = [&](auto mf_tag) {  // second half of a pair -> the pair's h fragment of this row fragment
         constexpr int mf = decltype(mf_tag)::value;
-#ifdef OPK_ABL_NO_MLP_VALU
-        asm volatile("" : "+v"(h_hi[mf]), "+v"(h_lo[mf]));
-        return;
-#endif
         uint2 h2, l2;
         if constexpr (F8) split4_f16(g_prev[mf], h2, l2);
         else split4<H_LO>(g_prev[mf], h2, l2);
@@ -1266,9 +1244,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       };
       auto pack_hold = [&](auto mf_tag) {
         constexpr int mf = decltype(mf_tag)::value;
-#ifdef OPK_ABL_NO_MLP_VALU
-        return;
-#endif
         if constexpr (F8) split4_f16(g_cur[mf], hold_hi[mf], hold_lo[mf]);
         else split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
       };
@@ -1283,13 +1258,6 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       auto geglu_ops72 = [&](const f32x4 (&av)[2][MF], float (&gv)[MF][4], auto begin_tag, auto end_tag, auto is_h_tag) {
         constexpr int B = decltype(begin_tag)::value, E = decltype(end_tag)::value;
         constexpr bool IS_H = decltype(is_h_tag)::value;
-#ifdef OPK_ABL_NO_MLP_VALU
-        if constexpr (E > B && E == RB_OPS) {
-          asm volatile("" ::"v"(av[0][0]), "v"(av[1][0]), "v"(av[0][1]), "v"(av[1][1]));
-          if constexpr (IS_H) asm volatile("" : "+v"(h_hi[0]), "+v"(h_lo[0]), "+v"(h_hi[1]), "+v"(h_lo[1]));
-        }
-        return;
-#endif
         static_for<(E > B ? E - B : 0)>([&](auto o_tag) {
           constexpr int o = B + decltype(o_tag)::value;
           if constexpr (o < 7 * NV) {
@@ -1483,9 +1451,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
               opk_seg_t = now;
             }
 #endif
-#ifndef OPK_ABL_NO_DMA
             if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
-#endif
             if constexpr (s < 2 * CS) {  // a chunk step
               constexpr bool FIRST_CHUNK = s < CS;
               constexpr int cs = FIRST_CHUNK ? s : s - CS;
@@ -1540,9 +1506,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         } else
         frag_stream2<2 * KS + NS, DEPTH, Off>(cur ? lds_stage[1] : lds_stage[0], [&](auto step_tag, bf16x8& w0, bf16x8& w1) {
           constexpr int s = decltype(step_tag)::value;
-#ifndef OPK_ABL_NO_DMA
           if constexpr (s < UNIT_DMA) stage_piece(step_tag, t + 1, cur ^ 1);
-#endif
           if constexpr (s < KS) {  // chunk 2t, with the GeGLU of chunk 2t-1 (-> h of pair t-1 ready for the slab)
             chunk_step(na, std::integral_constant<int, s>{}, w0, w1, no_rd);
             if constexpr (SLAB) geglu_slice(acc_b, g_prev, std::integral_constant<int, s>{}, pack_h);
@@ -1559,9 +1523,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         const unsigned long long opk_w0 = __builtin_readcyclecounter();
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (no other VMEM in this loop)
-#ifndef OPK_ABL_NO_BARRIER
         __builtin_amdgcn_s_barrier();
-#endif
 #ifdef OPK_TIMING
         opk_wait += __builtin_readcyclecounter() - opk_w0;
 #endif
@@ -1588,19 +1550,10 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           // tail: the stream is shorter than the DMA list -- the first tail half requests the last slab half up front,
           // the second one has nothing left to request
           if constexpr (!CHUNK && hb == 0) static_for<UNIT_DMA>([&](auto u) { stage_piece_w(u, c + 1, hb ^ 1); });
-#ifndef OPK_WLO_ILV
-#define OPK_WLO_ILV 4  // fragment groups in flight with the reads between the MFMAs (0: reads behind the step, DEPTH8 ahead)
-#endif
-#if OPK_WLO_ILV == 0
-          frag_stream2<CS + NSH - S0, DEPTH8, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&&... rd_opt) {
-#else
-          frag_stream2i<CS + NSH - S0, OPK_WLO_ILV, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&&... rd_opt) {
-#endif
+          frag_stream2i<CS + NSH - S0, FRAG_ILV, OffShift<OffW, S0>>(lds_stage[hb], [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&&... rd_opt) {
             auto&& rd = rd_or(no_rd, rd_opt...);
             constexpr int sr = decltype(step_tag)::value, st = sr + S0;
-#ifndef OPK_ABL_NO_DMA
             if constexpr (CHUNK && sr < UNIT_DMA) stage_piece_w(step_tag, c + 1, hb ^ 1);
-#endif
             if constexpr (st < CS) {
               auto& acc = *(hb == 0 ? &na : &nb);
               if constexpr (!C8::is_f8(st)) chunk_step(acc, std::integral_constant<int, C8::ks(st)>{}, w0, w1, rd);
@@ -1835,11 +1788,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     const int pairs_q = (p.hidden / ROW_CHUNK) >> 1;  // heads: chunk pairs of q (and of k)
     const int pairs_qk = p.n_swapped >> 1, pairs_all = p.n_chunks >> 1;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef OPK_ABL_NO_QKV_STORE  // measurement only: the values are computed and dropped
-    auto st16 = [&](u16* dst, const uint4& v) { asm volatile("" ::"v"(dst), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); };
-#else
     auto st16 = [&](u16* dst, const uint4& v) { store_stream16(dst, v); };
-#endif
 
     // one step (64 pipe cycles) of a chunk: SW = weights as the left operand (q / k: C rows = features), else v
     auto step = [&](auto sw_tag, f32x4 (&acc)[2][MF], auto cs_tag, const bf16x8& w0, const bf16x8& w1, auto&& rd) {
@@ -1949,14 +1898,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       const int nxt = t + 1 < pairs_all ? t + 1 : t;  // unconditional DMA: the last pair re-copies itself into the idle stage
       const float qscale = (t - 1) < pairs_q ? 0.125f * 1.44269504088896340736f : 1.0f;  // head_dim^-0.5 * log2(e) on q
       f32x4 na[2][MF], nb[2][MF], va[2][MF], vb[2][MF];
-#ifdef OPK_QKV_STREAM_TIMING  // (experiment: the streams' own cycles, reported in the MLP loop's wait slot)
-      const unsigned long long opk_s0 = __builtin_readcyclecounter();
-#endif
-      frag_stream2i<NST, OPK_WLO_ILV, OffP>(lds_stage[0] + (uint32_t)cur * (uint32_t)(STAGE_ALLOC * 2), [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&& rd) {
+      frag_stream2i<NST, FRAG_ILV, OffP>(lds_stage[0] + (uint32_t)cur * (uint32_t)(STAGE_ALLOC * 2), [&](auto step_tag, bf16x8& w0, bf16x8& w1, auto&& rd) {
         constexpr int s = decltype(step_tag)::value;
-#ifndef OPK_ABL_NO_DMA
         if constexpr (s < PAIR_DMA) stage_pair_piece(step_tag, nxt, cur ^ 1);
-#endif
         if constexpr (s < CS) step(sw_tag, na, step_tag, w0, w1, rd);
         else step(sw_tag, nb, std::integral_constant<int, s - CS>{}, w0, w1, rd);
         // a finished chunk leaves the accumulator file once
@@ -1980,12 +1924,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         }
         // riders: chunk 2t-2's half of the list over the first CS steps (its values are dead when va is written), chunk
         // 2t-1's over the next CS - 1; the stores behind the iteration's last DMA (step PAIR_DMA - 1 < CS)
-#ifdef OPK_ABL_NO_QKV_RIDERS  // measurement only: the bare stream (wrong results)
-        if constexpr (RIDE != 0 && s == NST - 1) asm volatile("" ::"v"(pa[0][0]), "v"(pa[1][0]), "v"(pa[0][1]), "v"(pa[1][1]), "v"(pb[0][0]), "v"(pb[1][0]), "v"(pb[0][1]), "v"(pb[1][1]));
-        if constexpr (false) {
-#else
         if constexpr (RIDE == 1) {
-#endif
           constexpr int H = QK_OPS / 2;
           constexpr int OB = s < CS ? s * H / CS : H + (s - CS) * H / (CS - 1);
           constexpr int OE = s < CS ? (s + 1) * H / CS : (s == NST - 1 ? QK_OPS : H + (s - CS + 1) * H / (CS - 1));
@@ -1995,11 +1934,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
             constexpr int done = H + 8 * decltype(mf_tag)::value + 8;
             if constexpr (OB < done && OE >= done) qk_store(t - 1, mf_tag);
           });
-#ifdef OPK_ABL_NO_QKV_RIDERS
-        } else if constexpr (false) {
-#else
         } else if constexpr (RIDE == 2) {
-#endif
           constexpr int H = V_OPS / 2;
           constexpr int OB = s < CS ? s * H / CS : H + (s - CS) * H / (CS - 1);
           constexpr int OE = s < CS ? (s + 1) * H / CS : (s == NST - 1 ? V_OPS : H + (s - CS + 1) * H / (CS - 1));
@@ -2008,16 +1943,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           if constexpr (s == NST - 1) v_store(t - 1, std::integral_constant<int, 1>{});
         }
       });
-#ifdef OPK_QKV_STREAM_TIMING
-      opk_wait += __builtin_readcyclecounter() - opk_s0;
-#endif
       // End of the iteration: this wave's share of the next pair must have landed, then all waves meet.  vmcnt retires in
       // order: everything but the stores issued behind the last DMA.
-#if defined(OPK_ABL_NO_QKV_STORE) || defined(OPK_ABL_NO_QKV_RIDERS)
-      constexpr int N_STORES = 0;
-#else
       constexpr int N_STORES = RIDE == 1 ? N_ST_QK : (RIDE == 2 ? N_ST_V : 0);
-#endif
 #ifdef OPK_TIMING
       const unsigned long long opk_w0 = __builtin_readcyclecounter();
 #endif
@@ -2026,9 +1954,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       const unsigned long long opk_w1 = __builtin_readcyclecounter();
       opk_wait1 += opk_w1 - opk_w0;
 #endif
-#ifndef OPK_ABL_NO_BARRIER
       __builtin_amdgcn_s_barrier();
-#endif
 #ifdef OPK_TIMING
       opk_wait2 += __builtin_readcyclecounter() - opk_w1;
 #endif
@@ -2242,9 +2168,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         }
       }
     }
-#ifndef OPK_ABL_NO_DMA
     stage_chunk(c + 1 < p.n_chunks ? c + 1 : c, cur ^ 1);
-#endif
     // Nothing crosses this point: the RoPE loads stay ahead of the DMA, and the epilogue's stores stay BEHIND it --
     // the counted wait in front of the barrier below relies on that order.
     __builtin_amdgcn_sched_barrier(0);
@@ -2296,9 +2220,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
     const unsigned long long opk_w1 = __builtin_readcyclecounter();
     opk_wait1 += opk_w1 - opk_w0;
 #endif
-#ifndef OPK_ABL_NO_BARRIER
     __builtin_amdgcn_s_barrier();
-#endif
 #ifdef OPK_TIMING
     opk_wait2 += __builtin_readcyclecounter() - opk_w1;
 #endif

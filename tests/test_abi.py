@@ -67,3 +67,27 @@ def test_unsupported_head_dim_is_rejected_before_touching_the_device(hip_library
     code = hip_library.op_create(ctypes.byref(cfg), ctypes.byref(handle))
     assert code == -2
     assert "head_dim" in _lib.last_error(hip_library, None)
+
+
+def test_product_kernel_headers_carry_no_ablation_switches(tmp_path):
+    """The whole-layer kernel's ablation hooks (OPK_ABL_*, OPK_QKV_*, OPK_PLAIN_*: builds with wrong results that price one
+    component of a loop) live in microbench/experiments/rowgemm_ablation_hooks.patch, not in the shipped headers; the
+    patch must still apply to them (scripts/instrumented_csrc.sh is what the microbenchmarks compile against)."""
+
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    check = subprocess.run([sys.executable, str(root / "scripts" / "strip_switches.py"), "--check"], capture_output=True, text=True)
+    assert check.returncode == 0, check.stdout
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1) here")
+    dst = tmp_path / "open_provence_amd"
+    dst.mkdir()
+    shutil.copytree(root / "open_provence_amd" / "csrc", dst / "csrc")
+    with open(root / "microbench" / "experiments" / "rowgemm_ablation_hooks.patch") as fh:
+        applied = subprocess.run(["patch", "-p1", "-s"], stdin=fh, cwd=tmp_path, capture_output=True, text=True)
+    assert applied.returncode == 0, applied.stdout + applied.stderr
+    assert "OPK_ABL_NO_DMA" in (dst / "csrc" / "opk_rowgemm.hip.h").read_text()
