@@ -521,6 +521,45 @@ class OpenProvenceModel:
             OpenProvenceForSequenceClassification.forward,
         )
 
+    # -- host-stage replicas (frontend.py, mode="host"): process() without a GPU, forwards run by the owner's process -----
+    def _host_stage_spec(self) -> dict[str, Any]:
+        """What a replica needs to run the host stages of ``process()`` exactly as this model does (picklable)."""
+
+        dims = getattr(self, "dims", None)
+        return {
+            "tokenizer": self.tokenizer,
+            "tokenizer_model_max_length": getattr(self.tokenizer, "model_max_length", None),
+            "max_length": int(self.max_length),
+            "default_threshold": getattr(self, "default_threshold", DEFAULT_PROCESS_THRESHOLD),
+            "default_splitter_language": getattr(self, "default_splitter_language", DEFAULT_SPLITTER_LANGUAGE),
+            "manual": (self._manual_special_tokens_required, self._manual_cls_token_id, self._manual_sep_token_id),
+            "vocab_size": int(dims.vocab_size) if dims is not None else None,
+            "num_labels": int(getattr(dims, "num_labels", 0) or getattr(self, "num_labels", 1) or 1),
+        }
+
+    @classmethod
+    def _host_stage_replica(cls, spec: Mapping[str, Any], remote_forward: Any) -> "OpenProvenceModel":
+        """A model object with the tokenizer and the request-level settings of ``spec`` and NO encoder: it splits,
+        tokenizes, assembles and post-processes; every forward goes through ``remote_forward`` (``submit`` / ``result``) to
+        the process that owns the GPU.  It cannot compute a forward by itself -- there is no CPU arithmetic path."""
+
+        model = cls.__new__(cls)
+        model.tokenizer = spec["tokenizer"] if spec.get("tokenizer") is not None else spec["tokenizer_factory"]()
+        if spec.get("tokenizer_model_max_length") is not None:
+            try:
+                model.tokenizer.model_max_length = spec["tokenizer_model_max_length"]
+            except Exception:  # pragma: no cover - exotic tokenizer objects
+                pass
+        model.max_length = int(spec["max_length"])
+        model.num_labels = int(spec["num_labels"])
+        model._runtime_device = torch.device("cpu")
+        model.default_threshold = spec["default_threshold"]
+        model.default_splitter_language = spec["default_splitter_language"]
+        model._manual_special_tokens_required, model._manual_cls_token_id, model._manual_sep_token_id = spec["manual"]
+        model._remote_forward = remote_forward
+        model._dist = None
+        return model
+
     # -- data parallelism over (query, block) rows (SURVEY.md section 8e) -----------------------------------
     def attach_process_group(self, group: Any | None = None, *, dst: int = 0, enabled: bool = True,
                              single_rank_gather: bool = False, shard: str = "jobs") -> None:
@@ -632,6 +671,9 @@ class OpenProvenceModel:
         over every range is taken there (``op_segment_means``: numpy's float32 pairwise order, bit for bit) and only
         4 bytes per range come back."""
 
+        remote = self.__dict__.get("_remote_forward")
+        if remote is not None:  # host-stage replica (frontend.py, mode="host"): the GPU owner's process runs the forward
+            return remote.submit(rows, segments)
         info = self._dist_info()
         shard = None
         if info is not None:
@@ -653,17 +695,42 @@ class OpenProvenceModel:
         handle["shard"] = shard
         return handle
 
+    @staticmethod
+    def _pack_launch(rows: list[list[int]], segments: list[list[tuple[int, int]]] | None):
+        """Rows (+ per-row token ranges) -> the arrays a launch consumes: packed ids, row offsets, the longest row, the
+        ranges as absolute (start, end) token positions of the packed batch, ranges per row.  This is also what a
+        host-stage replica sends to the GPU owner (frontend.py) -- a few numpy buffers instead of lists of Python ints."""
+
+        ids_np, cu_np, max_len = pack_rows(rows)
+        if segments is None:
+            return ids_np, cu_np, max_len, None, None
+        seg_counts = [len(s) for s in segments]
+        flat = np.empty(2 * sum(seg_counts), dtype=np.int32)
+        pos = 0
+        for i, segs in enumerate(segments):
+            base = int(cu_np[i])
+            for start, end in segs:
+                flat[pos] = base + start
+                flat[pos + 1] = base + end if end > start else base + start
+                pos += 2
+        return ids_np, cu_np, max_len, flat, seg_counts
+
     def _enqueue_local(self, rows: list[list[int]], segments: list[list[tuple[int, int]]] | None) -> dict[str, Any]:
-        """The launch of :meth:`_launch_rows` for THIS process's rows (also what the range guard of the fp16 + e4m3 kernel
-        sets repeats, see :meth:`_guard_launch`)."""
+        """The launch of :meth:`_launch_rows` for THIS process's rows."""
+
+        return self._enqueue_packed(*self._pack_launch(rows, segments))
+
+    def _enqueue_packed(self, ids_np: np.ndarray, cu_np: np.ndarray, max_len: int, seg_flat: np.ndarray | None,
+                        seg_counts: list[int] | None) -> dict[str, Any]:
+        """Enqueue one forward over packed rows (:meth:`_pack_launch`); also what the range guard of the fp16 + e4m3
+        kernel sets repeats, see :meth:`_guard_launch`."""
 
         shard = None
-        retry = (rows, segments)
-        ids_np, cu_np, max_len = pack_rows(rows)
+        retry = (ids_np, cu_np, max_len, seg_flat, seg_counts)
         self.encoder.check_ids(ids_np)
-        total, n_rows, nl = int(cu_np[-1]), len(rows), int(self.dims.num_labels)
+        total, n_rows, nl = int(cu_np[-1]), len(cu_np) - 1, int(self.dims.num_labels)
         if n_rows == 0:  # (more ranks than rows) nothing to enqueue here; the gather still runs on every rank
-            return {"event": None, "pool": None, "total": 0, "rows": 0, "cu": cu_np, "seg_counts": [] if segments is not None else None,
+            return {"event": None, "pool": None, "total": 0, "rows": 0, "cu": cu_np, "seg_counts": [] if seg_counts is not None else None,
                     "alive": None, "shard": shard, "retry": None}
         slot = self.__dict__["_staging_slot"] = (self.__dict__.get("_staging_slot", -1) + 1) % 2
         pool = self._staging(slot, total, n_rows)
@@ -673,26 +740,17 @@ class OpenProvenceModel:
         ids_dev = pool["ids"][:total].to(dev, non_blocking=True)
         cu_dev = pool["cu"][: n_rows + 1].to(dev, non_blocking=True)
         keep_dev = torch.empty(total, dtype=torch.float32, device=dev)
-        seg_counts = None
         seg_dev = means_dev = None
         n_seg = 0
-        if segments is not None:
-            seg_counts = [len(s) for s in segments]
+        if seg_counts is not None:
             n_seg = sum(seg_counts)
             if 2 * n_seg > pool["seg"].numel():
-                segments = seg_counts = None  # (cannot happen for non-empty fragments; fall back to the token payload)
-        if segments is not None:
-            flat = pool["seg_np"][: 2 * n_seg]
-            pos = 0
-            for i, segs in enumerate(segments):
-                base = int(cu_np[i])
-                for start, end in segs:
-                    flat[pos] = base + start
-                    flat[pos + 1] = base + end if end > start else base + start
-                    pos += 2
+                seg_flat = seg_counts = None  # (cannot happen for non-empty fragments; fall back to the token payload)
+        if seg_counts is not None:
+            np.copyto(pool["seg_np"][: 2 * n_seg], seg_flat)
             seg_dev = pool["seg"][: 2 * n_seg].to(dev, non_blocking=True).view(n_seg, 2)
         _, rank_dev = self.encoder.forward_packed(ids_dev, cu_dev, cu_np, max_len, keep_prob=keep_dev)
-        if segments is not None:
+        if seg_counts is not None:
             means_dev = self.encoder.segment_means(keep_dev, seg_dev)
             pool["keep"][:n_seg].copy_(means_dev, non_blocking=True)
         else:
@@ -720,9 +778,8 @@ class OpenProvenceModel:
         self.encoder.fall_back_from_f8("process")
         if self.encoder.f8_active():
             return handle  # (nothing to fall back to: the caller reports the NaN)
-        rows, segments = handle["retry"]
         handle["alive"] = None
-        again = self._enqueue_local(rows, segments)
+        again = self._enqueue_packed(*handle["retry"])
         again["shard"] = handle.get("shard")
         again["event"].synchronize()
         return again
@@ -731,6 +788,8 @@ class OpenProvenceModel:
         """-> (ranking logits, per row: its keep-probabilities, or -- launched with ``segments`` -- the list of its
         range means as Python floats)."""
 
+        if handle.get("remote") is not None:
+            return handle["remote"].result(handle)
         if handle.get("shard") is not None:
             return self._collect_rows_sharded(handle)
         handle["event"].synchronize()
@@ -748,6 +807,21 @@ class OpenProvenceModel:
             return rank, out
         keep = handle["pool"]["keep_np"][:total].copy()  # the slot is reused two launches later
         return rank, [keep[cu[i] : cu[i + 1]] for i in range(n_rows)]
+
+    def _collect_packed(self, handle: dict[str, Any]) -> tuple[np.ndarray, np.ndarray, bool]:
+        """:meth:`_collect_rows` without the per-row Python objects: (ranking logits [rows, nl], the launch's values as one
+        float32 array, reduced?) -- values = per-range means when the launch had ranges (reduced), else per-token
+        keep-probabilities.  What the GPU owner of a host-mode front-end sends back to its replicas (frontend.py)."""
+
+        handle["event"].synchronize()
+        handle = self._guard_launch(handle)
+        n_rows, nl = handle["rows"], int(self.dims.num_labels)
+        counts = handle.get("seg_counts")
+        n_val = sum(counts) if counts is not None else handle["total"]
+        rank = handle["pool"]["rank_np"][: n_rows * nl].copy().reshape(n_rows, nl)
+        values = handle["pool"]["keep_np"][:n_val].copy()  # the slot is reused two launches later
+        handle["alive"] = None
+        return rank, values, counts is not None
 
     def _collect_rows_sharded(self, handle: dict[str, Any]) -> tuple[torch.Tensor, list[Any]]:
         """The group form of :meth:`_collect_rows`: wait for this rank's launch, then ONE gather of fixed-size payloads
@@ -1344,8 +1418,6 @@ class OpenProvenceModel:
         handler) -- and ``dst`` then tells every rank who failed (one ``broadcast_object_list``), so that all ranks raise
         instead of the healthy ones waiting forever for a peer that has left."""
 
-        import torch.distributed as dist
-
         group, dst, rank, world = info["group"], info["dst"], info["rank"], info["world"]
         if world <= 1 and not info.get("force"):
             return result
@@ -1359,14 +1431,23 @@ class OpenProvenceModel:
             }
         else:
             mine = {"__error__": f"{type(error).__name__}: {error}"}
-        dst_global = dist.get_global_rank(group, dst) if group is not None and group is not dist.group.WORLD else dst
-        gathered = [None] * world if rank == dst else None
-        device = getattr(self, "device", None)
-        ctx = torch.cuda.device(device) if (device is not None and torch.device(device).type == "cuda") else contextlib.nullcontext()
-        with ctx:  # (the NCCL backend moves pickled objects through tensors on the CURRENT device)
-            dist.gather_object(mine, gathered, dst=dst_global, group=group)
-            failed = [{r: part["__error__"] for r, part in enumerate(gathered) if isinstance(part, dict) and "__error__" in part}] if rank == dst else [None]
-            dist.broadcast_object_list(failed, src=dst_global, group=group)
+        transport = info.get("transport")
+        if transport is not None:
+            # host-mode front-end (frontend.py): pipes instead of a collective.  A replica hands its part to the GPU owner
+            # and is done; the owner -- which owns no job -- serves the replicas' forwards until every part has arrived.
+            gathered = transport.exchange(self, mine)
+            failed = [{r: part["__error__"] for r, part in enumerate(gathered) if isinstance(part, dict) and "__error__" in part}]
+        else:
+            import torch.distributed as dist
+
+            dst_global = dist.get_global_rank(group, dst) if group is not None and group is not dist.group.WORLD else dst
+            gathered = [None] * world if rank == dst else None
+            device = getattr(self, "device", None)
+            ctx = torch.cuda.device(device) if (device is not None and torch.device(device).type == "cuda") else contextlib.nullcontext()
+            with ctx:  # (the NCCL backend moves pickled objects through tensors on the CURRENT device)
+                dist.gather_object(mine, gathered, dst=dst_global, group=group)
+                failed = [{r: part["__error__"] for r, part in enumerate(gathered) if isinstance(part, dict) and "__error__" in part}] if rank == dst else [None]
+                dist.broadcast_object_list(failed, src=dst_global, group=group)
         if failed[0]:
             if error is not None:
                 return result  # this rank's own exception is already propagating
@@ -1609,6 +1690,11 @@ class OpenProvenceModel:
             if self._can_pipeline() and not batch_explicit:
                 granule = -(-int(3.2 * total_jobs**0.5) // 16) * 16
                 preprocess_batch = min(preprocess_batch, max(32, granule))
+                if self.__dict__.get("_remote_forward") is not None:
+                    # host-stage replica: its batches are merged with the other replicas' by the GPU owner, so a launch
+                    # costs this process a pipe message, not a forward -- four batches per request keep the GPU busy from
+                    # the first quarter of the host work on
+                    preprocess_batch = min(preprocess_batch, max(8, -(-total_jobs // 4)))
             while True:
                 batch_jobs = list(itertools.islice(job_stream, preprocess_batch))
                 if not batch_jobs:

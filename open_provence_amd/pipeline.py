@@ -11,6 +11,7 @@ from __future__ import annotations
 import functools
 import math
 import os
+import heapq
 from collections import defaultdict
 from dataclasses import dataclass, field
 from typing import Any, Callable, Mapping, Sequence
@@ -70,7 +71,9 @@ class ContextState:
 # input normalisation (ref: _normalize_inputs :2261-2323)
 # ---------------------------------------------------------------------------------------------
 def _is_sequence(value: Any) -> bool:
-    return isinstance(value, Sequence) and not isinstance(value, (str, bytes, bytearray))
+    if isinstance(value, (str, bytes, bytearray)):  # (first: typing.Sequence's instance check costs microseconds per text)
+        return False
+    return isinstance(value, (list, tuple)) or isinstance(value, Sequence)
 
 
 def _normalize_collection(values: Sequence[Any]) -> list[Any]:
@@ -269,10 +272,10 @@ def assign_jobs(contexts: Sequence[Sequence[Any]], world: int) -> list[list[int]
             size = sum(len(str(s)) for s in entry) if isinstance(entry, (list, tuple)) else len(str(entry))
             costs.append((size + 64, q_idx, c_idx))  # + a per-context constant: many tiny contexts are not free
     owner = [[0] * len(per_query) for per_query in contexts]
-    loads = [0] * world
+    loads = [(0, rank) for rank in range(world)]  # a heap of (load, rank): the least loaded rank, the lowest on a tie
     for size, q_idx, c_idx in sorted(costs, key=lambda t: (-t[0], t[1], t[2])):
-        rank = min(range(world), key=lambda r: (loads[r], r))
-        loads[rank] += size
+        load, rank = loads[0]
+        heapq.heapreplace(loads, (load + size, rank))
         owner[q_idx][c_idx] = rank
     return owner
 

@@ -37,6 +37,16 @@ def make_request(n_contexts: int, chars: int, seed: int = 5):
     return "which greek letters appear here", contexts
 
 
+def build_e2e_tokenizer():
+    """Tokenizer factory (module level: HostFrontEnd's replicas rebuild it by name); kind from the environment."""
+
+    if os.environ.get("E2E_TOKENIZER", "char") == "wordpiece":
+        from helpers import build_wordpiece_tokenizer
+
+        return build_wordpiece_tokenizer(True)
+    return CharTokenizer()
+
+
 def build_e2e_model():
     """Model factory (module level: ProcessFrontEnd's worker processes rebuild it by name); tokenizer from the environment."""
 
@@ -62,6 +72,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--front-end", type=int, default=0,
                     help="N > 0: open_provence_amd.frontend.ProcessFrontEnd with N worker processes (all on cuda:0) beside the caller")
+    ap.add_argument("--host-front-end", type=int, default=0,
+                    help="N > 0: open_provence_amd.frontend.HostFrontEnd -- N host-stage replicas WITHOUT a GPU; this process runs every forward")
     ap.add_argument("--contexts", type=int, default=256)
     ap.add_argument("--chars", type=int, default=470)
     ap.add_argument("--reps", type=int, default=3)
@@ -81,6 +93,11 @@ def main():
         from open_provence_amd.frontend import ProcessFrontEnd
 
         front = ProcessFrontEnd(build_e2e_model, workers=args.front_end)
+        target = front
+    elif args.host_front_end > 0:
+        from open_provence_amd.frontend import HostFrontEnd
+
+        front = HostFrontEnd(build_e2e_model(), workers=args.host_front_end, tokenizer_factory=build_e2e_tokenizer)
         target = front
     else:
         target = build_e2e_model()
@@ -105,7 +122,7 @@ def main():
         if best is None or dt < best[0]:
             best = (dt, out["timing"], usage)
     dt, timing, usage = best
-    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "tokenizer": args.tokenizer, "workers": args.workers, "front_end_processes": args.front_end, "wall_s": dt, "contexts_per_s": args.contexts / dt, "rusage": usage,
+    print(json.dumps({"contexts": args.contexts, "chars": args.chars, "tokenizer": args.tokenizer, "workers": args.workers, "front_end_processes": args.front_end, "host_replicas": args.host_front_end, "wall_s": dt, "contexts_per_s": args.contexts / dt, "rusage": usage, "owner_trace": getattr(front, "last_trace", None),
                       "timing": {k: round(float(v), 5) for k, v in timing.items()}}))
     if args.profile:
         pr = cProfile.Profile()

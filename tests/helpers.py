@@ -279,6 +279,12 @@ def build_wordpiece_tokenizer(emit_specials: bool, legacy_methods: bool = True):
                mask_token="[MASK]", model_max_length=512)
 
 
+def wordpiece_tokenizer_for_workers():
+    """Module-level factory (HostFrontEnd's replicas import it by name)."""
+
+    return build_wordpiece_tokenizer(True)
+
+
 WORDPIECE_CASES = [
     dict(case="wp_single", question="How tall is the tower?",
          context="The tower is tall. It was built long ago! Many people visit it. Bread is made from flour.",

@@ -39,3 +39,51 @@ def test_front_end_equals_the_plain_call_and_survives_a_bad_request():
         assert again[key] == want[key], key
         assert got_top[key] == want_top[key], key
     assert len(got_top["pruned_context"]) == 9
+
+
+@pytest.mark.timeout(300)
+def test_host_front_end_equals_the_plain_call_and_survives_a_bad_request():
+    """mode "host": the workers are host-stage replicas without a model; every forward batch goes through a pipe to the
+    caller's process (here a stub forward: per-token keep-probabilities come back, the replicas take the means)."""
+
+    from open_provence_amd.frontend import HostFrontEnd
+
+    plain_model = frontend_stub_model()
+    want = plain_model.process(**_request())
+    want_top = plain_model.process(reorder=True, top_k=9, **_request())
+    with HostFrontEnd(frontend_stub_model(), workers=3) as front:
+        got = front.process(**_request())
+        got_top = front.process(reorder=True, top_k=9, **_request())
+        with pytest.raises((ValueError, RuntimeError)):
+            bad = _request()
+            bad.pop("sentence_splitter")
+            front.process(language="xx", **bad)
+        again = front.process(**_request())
+        few = front.process(question="which boats?", context=["Boats carry salt. The tower is tall."], sentence_splitter=period_splitter,
+                            show_progress=False, return_sentence_texts=True, threshold=0.4)  # fewer jobs than replicas
+    for key in want:
+        if key in ("timing", "performance_trace"):
+            continue
+        assert got[key] == want[key], key
+        assert again[key] == want[key], key
+        assert got_top[key] == want_top[key], key
+    assert len(got_top["pruned_context"]) == 9
+    want_few = plain_model.process(question="which boats?", context=["Boats carry salt. The tower is tall."], sentence_splitter=period_splitter,
+                                   show_progress=False, return_sentence_texts=True, threshold=0.4)
+    assert few["pruned_context"] == want_few["pruned_context"] and few["kept_sentences"] == want_few["kept_sentences"]
+    assert front.model._dist is None  # the owner model is a plain model again
+
+
+def test_host_front_end_refuses_an_unpicklable_tokenizer_and_accepts_a_factory():
+    from helpers import build_wordpiece_tokenizer, host_only_model, golden_stub_forward, wordpiece_tokenizer_for_workers
+    from open_provence_amd.frontend import HostFrontEnd
+
+    model = host_only_model(tokenizer=build_wordpiece_tokenizer(True), max_length=96, forward=golden_stub_forward)
+    with pytest.raises(TypeError, match="tokenizer_factory"):
+        HostFrontEnd(model, workers=1)  # (the helper's tokenizer class is local to a function)
+    want = model.process(**_request())
+    with HostFrontEnd(model, workers=2, tokenizer_factory=wordpiece_tokenizer_for_workers) as front:
+        got = front.process(**_request())
+    for key in want:
+        if key not in ("timing", "performance_trace"):
+            assert got[key] == want[key], key

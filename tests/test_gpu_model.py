@@ -61,6 +61,39 @@ def test_process_end_to_end_matches_reference():
         assert result["timing"]["inference_seconds"] > 0.0
 
 
+def test_host_front_end_on_the_gpu_equals_the_plain_call():
+    """``HostFrontEnd``: host-stage replicas without a GPU, every forward batch merged and run by this process -- the G3
+    cases against the reference, and a 90-context request against the plain call (probabilities and scores bit for
+    bit: a row's outputs do not depend on its batch companions, the fragment means are taken on the device either way)."""
+
+    from open_provence_amd.frontend import HostFrontEnd
+
+    model, meta = _g3_model()
+    words = "the tower is tall boats carry fish and salt to north city harbour many years ago it was new".split()
+    contexts = [
+        " ".join(" ".join(words[(i * 5 + s * 3 + k) % len(words)] for k in range(4 + (i + s) % 5)).capitalize() + "." for s in range(1 + i % 6))
+        for i in range(90)
+    ]
+    big = dict(question="which boats carry salt?", context=contexts, sentence_splitter=period_splitter, show_progress=False,
+               return_sentence_metrics=True, return_sentence_texts=True, batch_size=16, threshold=0.4)
+    want = model.process(**big)
+    want_top = model.process(reorder=True, top_k=7, **big)
+    with HostFrontEnd(model, workers=3) as front:
+        for case in meta["cases"]:
+            result = front.process(question=case["question"], context=case["context"], sentence_splitter=period_splitter,
+                                   show_progress=False, return_sentence_metrics=True, return_sentence_texts=True, batch_size=4,
+                                   **case["kwargs"])
+            assert_process_result_matches(result, case["expected"], prob_tol=1e-3, score_tol=1e-3)
+        got = front.process(**big)
+        got_top = front.process(reorder=True, top_k=7, **big)
+    for key in want:
+        if key in ("timing", "performance_trace"):
+            continue
+        assert got[key] == want[key], key
+        assert got_top[key] == want_top[key], key
+    assert model.process(**big)["pruned_context"] == want["pruned_context"]  # the model is a plain model again
+
+
 def test_padded_forward_boundary():
     from open_provence_amd.config import OpenProvenceConfig
     from open_provence_amd.modeling import OpenProvenceForTokenClassification, OpenProvenceModel
