@@ -85,6 +85,24 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+def cpu_quota_cores() -> float | None:
+    """CPU time this container may use per wall second (cgroup v2 cpu.max / v1 cfs quota), in cores; None = unlimited.
+    /proc/cpuinfo lists the host's cores whatever the quota: on the GPU boxes of this project it says 128 / 256 while
+    cpu.max is 1600000 100000 -- 16 cores, which is why 16 threads is the thread count that serves the CPU baseline best."""
+
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 ARITHMETIC_OF_KERNEL_SET = {
     # what the dominant kernels multiply with (the line's `dtype`): every set accumulates in fp32
     "f16-f8-w": "fp16 hi + e4m3 lo split operands (weights: fp16 + two e4m3 planes), fp32 accumulate",
@@ -182,11 +200,13 @@ def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
         "kind": "port",
         "physical_cores": n_phys,
         "logical_cpus": os.cpu_count(),
+        "cpu_quota_cores": cpu_quota_cores(),
         "batch_256_pairs_per_s": rate256,
         "single_thread_pairs_per_s": rate1,
         "sample": f"oracle/modernbert_oracle.py (torch-CPU fp32, SDPA): {iters32} x batch 32 x seq_len {seq_len} on {best_threads} threads "
         f"(best of {candidates}, one pass of batch 32 each), one pass of batch 256 on the same threads, one pass of batch 2 on 1 thread; "
-        f"{n_phys} physical cores / {os.cpu_count()} logical CPUs",
+        f"{n_phys} physical cores / {os.cpu_count()} logical CPUs on the host, container CPU quota "
+        f"{'none' if cpu_quota_cores() is None else format(cpu_quota_cores(), 'g') + ' cores'}",
     }
 
 
