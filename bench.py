@@ -144,14 +144,44 @@ def require_finite(what: str, *tensors) -> None:
             raise SystemExit(f"bench.py: non-finite outputs in {what}: refusing to report a rate for it")
 
 
-def output_checksum(prune: torch.Tensor, rank_logits: torch.Tensor) -> dict:
-    """Order-independent fingerprint of a forward's outputs (float64 sums on the device), printed with every record so
-    that two runs of the same command -- or the same workload through another kernel set -- can be compared at a glance;
-    tests/test_gpu_timed_path.py checks the same workloads against the oracle at their full size."""
+CHECKSUM_FILE = Path(__file__).resolve().parent / "tests" / "golden" / "bench_checksums.json"
+_checksums_seen: dict[str, dict] = {}
+_checksum_write_mode = False  # --write-checksums: record, do not compare
+
+
+def output_checksum(prune: torch.Tensor, rank_logits: torch.Tensor, key: str | None = None) -> dict:
+    """Order-independent fingerprint of a forward's outputs (float64 sums on the device), printed with every record.
+
+    With ``key`` (workload | shape | checkpoint dtype) it is compared with the value stored for that workload in
+    tests/golden/bench_checksums.json -- written by ``--write-checksums`` from a library whose outputs on exactly these
+    workloads tests/test_gpu_timed_path.py checks against the oracle at full size.  The kernels are deterministic (the same
+    sums on every box); the comparison allows what a change of kernel set moves (1e-4 of the absolute sum, 2e-4 per ranking
+    logit) and refuses anything else: a rate measured on wrong outputs is not reported."""
 
     p64 = prune.double()
-    return {"prune_sum": float(p64.sum().item()), "prune_abs_sum": float(p64.abs().sum().item()),
-            "rank_sum": float(rank_logits.double().sum().item())}
+    got = {"prune_sum": float(p64.sum().item()), "prune_abs_sum": float(p64.abs().sum().item()),
+           "rank_sum": float(rank_logits.double().sum().item())}
+    if key is None:
+        return got
+    _checksums_seen[key] = dict(got)
+    if _checksum_write_mode:
+        got["stored"] = "written by this run"
+        return got
+    try:
+        stored = json.loads(CHECKSUM_FILE.read_text()).get(key)
+    except (OSError, ValueError):
+        stored = None
+    if stored is None:
+        got["stored"] = "none for this workload"
+        return got
+    tol = 1e-4 * abs(stored["prune_abs_sum"])
+    ok = (abs(got["prune_abs_sum"] - stored["prune_abs_sum"]) <= tol and abs(got["prune_sum"] - stored["prune_sum"]) <= tol
+          and abs(got["rank_sum"] - stored["rank_sum"]) <= 2e-4 * max(1, rank_logits.numel()))
+    if not ok and not os.environ.get("OPEN_PROVENCE_BENCH_NO_CHECKSUM"):
+        raise SystemExit(f"bench.py: outputs of {key} differ from the stored checksum ({got} vs {stored}): refusing to report a "
+                         "rate for them (a deliberate change of arithmetic: re-run with --write-checksums after the GPU parity tests)")
+    got["stored"] = "match" if ok else "DIFFERS (check disabled)"
+    return got
 
 
 def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
@@ -227,11 +257,14 @@ def main() -> None:
                         "bf16, i.e. what the reference's GPU default makes of them at load time (standalone.py:219-233); "
                         "reported as the `bf16_checkpoint` sub-record of the default run.  The arithmetic policy is "
                         "--precision either way")
+    parser.add_argument("--write-checksums", action="store_true",
+                        help="store the output checksums of this run's workloads in tests/golden/bench_checksums.json (after a "
+                        "deliberate change of arithmetic, once the GPU parity tests are green); a plain run COMPARES with them")
     parser.add_argument("--no-other-dtype", action="store_true", help="skip the sub-record of the other checkpoint dtype")
     parser.add_argument("--chunk-rows", type=int, default=0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-long", action="store_true", help="skip the seq_len 2048 sub-record")
-    parser.add_argument("--no-base", action="store_true", help="skip the base-model (hidden 768, panel path) sub-record")
+    parser.add_argument("--no-base", action="store_true", help="skip the base-model (hidden 512, 19 layers: panel path) sub-record")
     parser.add_argument("--varlen", action="store_true",
                         help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
     parser.add_argument("--pipelines", type=int, default=0, choices=[0, 1, 2],
@@ -244,6 +277,8 @@ def main() -> None:
                         help="test hook: run the N > 1 code path (process group, ShardPlan, gather, MAX all-reduce) on a "
                         "one-rank RCCL group, so that it is executed on hardware even where only one GPU is granted")
     args = parser.parse_args()
+    global _checksum_write_mode
+    _checksum_write_mode = bool(args.write_checksums)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -387,7 +422,8 @@ def main() -> None:
         elapsed = float(t.item())
     require_finite("the headline workload", out[0], out[1])
     finite = True
-    checksum = output_checksum(out[0], out[1])
+    wl_key = f"{args.model}|{n_pairs_rank}x{'varlen' if args.varlen else args.seq_len}|"
+    checksum = output_checksum(out[0], out[1], wl_key + args.weights if world == 1 and args.precision == "bf16x3" else None)
     # per-kernel HIP-event timing on the launch stream (separate, un-timed passes)
     encoder.profile_enable(True)
     encoder.profile_reset()
@@ -595,7 +631,7 @@ def main() -> None:
                                 "ms_per_step": dt * 1e3, "algorithmic_gflop_per_pair": flops_l / 1e9,
                                 "whole_forward_frac": long_pairs / dt * flops_l / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                                 "shader_clock_ghz": probed_pass(encoder, long_step, long_steps, dt, sync_dev)["value"],
-                                "output_checksum": output_checksum(out_l[0], out_l[1])}
+                                "output_checksum": output_checksum(out_l[0], out_l[1], f"{args.model}|{long_pairs}x2048|{args.weights}" if args.precision == "bf16x3" else None)}
     if world == 1 and not args.varlen and not args.no_other_dtype:
         # the same workload with the OTHER checkpoint dtype, timed by the same command (sub-record, not the headline)
         other = "bf16" if args.weights == "fp32" else "fp32"
@@ -637,7 +673,7 @@ def main() -> None:
         sub = {"value": n_pairs_rank / dt_two, "unit": "pairs/s", "ms_per_step": dt_two * 1e3, "steps": args.steps,
                "one_pipeline": n_pairs_rank / dt_one, "checkpoint_dtype": other, "policy": policy_o,
                "dtype": arithmetic_label(policy_o), "shader_clock_ghz": clock_o["value"],
-               "output_checksum": output_checksum(out_o[0], out_o[1]),
+               "output_checksum": output_checksum(out_o[0], out_o[1], wl_key + other if args.precision == "bf16x3" else None),
                "whole_forward_frac": n_pairs_rank / dt_two * flops_pair / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in prof_o.items()}}
         if dom_o in flops_per_forward:
@@ -688,7 +724,7 @@ def main() -> None:
             enc_b.profile_enable(False)
             rec = {"value": args.pairs / dt_b, "ms_per_step": dt_b * 1e3, "kernel_set": enc_b.effective_policy()["kernel_set"],
                    "dtype": arithmetic_label(enc_b.effective_policy()), "shader_clock_ghz": clock_b["value"],
-                   "output_checksum": output_checksum(out_b[0], out_b[1]),
+                   "output_checksum": output_checksum(out_b[0], out_b[1], f"base|{args.pairs}x{args.seq_len}|{wdt}" if args.precision == "bf16x3" else None),
                    "whole_forward_frac": args.pairs / dt_b * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                    "kernel_ms_per_forward": {k: v["total_ms"] / 2 for k, v in prof_b.items()}}
             enc_b.close()
@@ -711,6 +747,13 @@ def main() -> None:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if args.write_checksums and rank == 0 and _checksums_seen:
+        try:
+            table = json.loads(CHECKSUM_FILE.read_text())
+        except (OSError, ValueError):
+            table = {}
+        table.update(_checksums_seen)
+        CHECKSUM_FILE.write_text(json.dumps(table, indent=1, sort_keys=True) + "\n")
     print(json.dumps(line), flush=True)
     if grouped:
         dist.destroy_process_group()

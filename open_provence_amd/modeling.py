@@ -1581,7 +1581,13 @@ class OpenProvenceModel:
                 stack.enter_context(warnings.catch_warnings())
                 warnings.simplefilter("ignore")
 
-            queries, contexts, structure = self._normalize_inputs(question, context)
+            # (host-mode front-end: the owner has normalised the request and assigned the jobs once for all replicas; a
+            # replica gets the normalised structure with the texts of the contexts it does not own blanked)
+            handed = (getattr(self, "_dist", None) or {}).get("prenormalized")
+            if handed is not None:
+                queries, contexts, structure = handed["queries"], handed["contexts"], handed["structure"]
+            else:
+                queries, contexts, structure = self._normalize_inputs(question, context)
             contexts, titles = self._resolve_titles(queries, contexts, title, first_line_as_title=first_line_as_title)
             if respect_sentence_boundaries:
                 max_fragment_tokens = max(16, self.max_length - 2)
@@ -1598,7 +1604,7 @@ class OpenProvenceModel:
                 job_shard = None
             owned = None
             if job_shard is not None:
-                owner = pl.assign_jobs(contexts, job_shard["world"])
+                owner = handed["owner"] if handed is not None else pl.assign_jobs(contexts, job_shard["world"])
                 owned = [[r == job_shard["rank"] for r in per_query] for per_query in owner]
                 total_jobs = sum(sum(per_query) for per_query in owned)
                 job_shard["local_only"] = True

@@ -92,3 +92,32 @@ def test_bench_multi_gpu_code_path_on_a_one_rank_group():
     assert REQUIRED <= set(line)
     assert line["n_gpus"] == 1 and line["config"]["outputs_finite"] is True and line["value"] > 0
     assert "one_pipeline" not in line  # a rank of a multi-GPU run executes one launch sequence
+
+
+def test_bench_refuses_outputs_that_differ_from_the_stored_checksum(tmp_path, monkeypatch):
+    """bench.py compares every record's output checksum with tests/golden/bench_checksums.json (CPU: the function alone)."""
+
+    import importlib.util
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", REPO_ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stored = tmp_path / "checksums.json"
+    monkeypatch.setattr(bench, "CHECKSUM_FILE", stored)
+    monkeypatch.delenv("OPEN_PROVENCE_BENCH_NO_CHECKSUM", raising=False)
+    torch.manual_seed(0)
+    prune, rank = torch.randn(4096, 2), torch.randn(8, 1)
+    assert bench.output_checksum(prune, rank, "w|8x512|fp32")["stored"].startswith("none")
+    plain = bench.output_checksum(prune, rank)
+    stored.write_text(json.dumps({"w|8x512|fp32": plain}))
+    assert bench.output_checksum(prune, rank, "w|8x512|fp32")["stored"] == "match"
+    assert bench.output_checksum(prune + 1e-7, rank, "w|8x512|fp32")["stored"] == "match"  # another kernel set's rounding
+    with pytest.raises(SystemExit, match="stored checksum"):
+        bench.output_checksum(prune * 1.01, rank, "w|8x512|fp32")
+    with pytest.raises(SystemExit, match="stored checksum"):
+        bench.output_checksum(prune, rank + 0.01, "w|8x512|fp32")
+    monkeypatch.setattr(bench, "_checksum_write_mode", True)
+    assert bench.output_checksum(prune * 2, rank, "w|8x512|fp32")["stored"] == "written by this run"
+    assert bench._checksums_seen["w|8x512|fp32"]["prune_abs_sum"] == pytest.approx(2 * plain["prune_abs_sum"])
