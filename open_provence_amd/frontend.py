@@ -34,8 +34,8 @@ which owns the GPU, takes no jobs itself, MERGES the batches that are waiting in
 + per-fragment means (4 bytes per fragment).  Same job assignment, same per-row arithmetic (a row's outputs do not depend
 on its batch companions), so the result equals the plain call's.  Measured (profiles/r04_process_e2e.txt; the GPU box's
 container has a CPU quota of 16 cores -- cpu.max 1600000 100000 -- so every figure with more than 16 busy processes is
-throttled): 1024 contexts, WordPiece tokenizer: 23.3 k contexts/s with 31 replicas (ProcessFrontEnd, 9 workers: 19.9 k;
-one process: 3.9 k), 4096 contexts: 29.7 k, 256: 16.7 k.  ``HostFrontEnd.last_trace`` holds the owner's time line of the
+throttled): 1024 contexts, WordPiece tokenizer: 24.1 k contexts/s with 31 replicas (ProcessFrontEnd, 9 workers: 19.8 k;
+one process: 4.85 k), 4096 contexts: 29.6 k, 256: 16.2-16.7 k.  ``HostFrontEnd.last_trace`` holds the owner's time line of the
 last request (launch sizes and times, the slowest replica's stamps).
 """
 
