@@ -61,6 +61,7 @@ def test_process_end_to_end_matches_reference():
         assert result["timing"]["inference_seconds"] > 0.0
 
 
+@pytest.mark.timeout(600)
 def test_host_front_end_on_the_gpu_equals_the_plain_call():
     """``HostFrontEnd``: host-stage replicas without a GPU, every forward batch merged and run by this process -- the G3
     cases against the reference, and a 90-context request against the plain call (probabilities and scores bit for
