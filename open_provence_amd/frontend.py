@@ -217,6 +217,8 @@ def _serve_host_stages(rank: int, world: int, conn: Any, spec: dict) -> None:
         message = conn.recv()
         if message is None:
             break
+        if isinstance(message[0], str):
+            continue  # the answer to a forward batch of a request this replica has already given up on
         link.request, shm_name, size, mine = message
         link.delivered = False
         link.stamps = {"request_received": perf_counter()}

@@ -74,6 +74,32 @@ def test_host_front_end_equals_the_plain_call_and_survives_a_bad_request():
     assert front.model._dist is None  # the owner model is a plain model again
 
 
+@pytest.mark.timeout(300)
+def test_host_front_end_titles_and_several_queries():
+    """The owner normalises the request and assigns the jobs once; a replica sees only its own texts -- explicit titles,
+    first-line titles and the aligned / nested input shapes must come out as in the plain call."""
+
+    from open_provence_amd.frontend import HostFrontEnd
+
+    base = _request()
+    contexts = base["context"][:12]
+    common = {k: v for k, v in base.items() if k not in ("question", "context")}
+    cases = [
+        dict(question=base["question"], context=contexts, title=[f"Title {i}" for i in range(len(contexts))], **common),
+        dict(question=base["question"], context=["Heading %d\n%s" % (i, c) for i, c in enumerate(contexts)], first_line_as_title=True, **common),
+        dict(question=["which boats?", "how tall is the tower?"], context=[contexts[:5], contexts[5:9]], **common),
+        dict(question=["which boats?", "how tall is the tower?"], context=[contexts[0], contexts[1]], **common),
+        dict(question="which boats?", context=contexts[3], **common),
+    ]
+    plain_model = frontend_stub_model()
+    with HostFrontEnd(frontend_stub_model(), workers=3) as front:
+        for case in cases:
+            want, got = plain_model.process(**case), front.process(**case)
+            for key in want:
+                if key not in ("timing", "performance_trace"):
+                    assert got[key] == want[key], (key, list(case)[:3])
+
+
 def test_host_front_end_refuses_an_unpicklable_tokenizer_and_accepts_a_factory():
     from helpers import build_wordpiece_tokenizer, host_only_model, golden_stub_forward, wordpiece_tokenizer_for_workers
     from open_provence_amd.frontend import HostFrontEnd
