@@ -46,7 +46,9 @@ def test_bench_json_line_contract():
     assert 0.5 < roof["shader_clock_ghz"] < 3.0 and 0.5 < other["shader_clock_ghz"] < 3.0
     assert 0.5 < line["seq_len_2048"]["shader_clock_ghz"] < 3.0
     for rec in (line["config"], other, line["seq_len_2048"]):
-        assert set(rec["output_checksum"]) == {"prune_sum", "prune_abs_sum", "rank_sum"}
+        assert {"prune_sum", "prune_abs_sum", "rank_sum"} <= set(rec["output_checksum"])
+        # (8 pairs: no stored checksum for this workload; the default workloads compare with tests/golden/bench_checksums.json)
+        assert rec["output_checksum"]["stored"].startswith("none")
     assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
     # the panel path (base dims) as a sub-record, both checkpoint dtypes: default flags = the (hi, lo) bf16 kernel sets
     base = line["base_model"]
