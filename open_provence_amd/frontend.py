@@ -47,7 +47,7 @@ import socket
 from time import perf_counter
 from typing import Any, Callable
 
-__all__ = ["ProcessFrontEnd", "HostFrontEnd"]
+__all__ = ["ProcessFrontEnd", "HostFrontEnd", "default_host_workers", "usable_cores"]
 
 
 def _free_port() -> int:
@@ -445,10 +445,41 @@ class _OwnerHub:
             val0 += n_vals
 
 
+def usable_cores() -> float:
+    """Cores this process may keep busy: the container's CPU quota (cgroup v2 ``cpu.max`` / v1 cfs quota) if there is one,
+    else its affinity mask.  ``os.cpu_count()`` reports the HOST's CPUs: on the GPU boxes of this project 256 under a quota
+    of 16."""
+
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1.0, float(quota) / float(period))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        if quota > 0:
+            return max(1.0, quota / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
+    except (OSError, ValueError):
+        pass
+    try:
+        return float(len(os.sched_getaffinity(0)))
+    except AttributeError:  # pragma: no cover - not Linux
+        return float(os.cpu_count() or 1)
+
+
+def default_host_workers() -> int:
+    """Replicas ``HostFrontEnd`` starts when the caller does not say: twice the usable cores minus the owner, at most 31
+    (measured under a quota of 16 cores: 15 replicas 19.2 k contexts/s, 23: 21.7 k, 31: 24.1 k at 1024 contexts -- a
+    replica spends part of a request waiting for the owner's answers, so a modest oversubscription pays)."""
+
+    return int(max(1, min(31, 2 * usable_cores() - 1)))
+
+
 class HostFrontEnd:
     """``workers`` host-stage replicas (no GPU, no model) behind ``model``, whose process owns every forward.
 
-        front = HostFrontEnd(model, workers=15)
+        front = HostFrontEnd(model)                                  # workers=None: default_host_workers()
         result = front.process(question, contexts, threshold=0.1)   # = model.process(...)
         front.close()
 
@@ -456,11 +487,13 @@ class HostFrontEnd:
     the model's tokenizer (Hugging Face tokenizers are) -- or pass ``tokenizer_factory``, a callable importable by name
     that builds the same tokenizer inside each replica."""
 
-    def __init__(self, model: Any, workers: int = 7, *, tokenizer_factory: Callable[[], Any] | None = None) -> None:
+    def __init__(self, model: Any, workers: int | None = None, *, tokenizer_factory: Callable[[], Any] | None = None) -> None:
         import pickle
 
         import torch.multiprocessing as mp
 
+        if workers is None:
+            workers = default_host_workers()
         if workers < 1:
             raise ValueError("workers must be >= 1 (use model.process() directly otherwise)")
         if getattr(model, "_dist", None):
