@@ -295,7 +295,11 @@ class _OwnerHub:
         self._shm = shared_memory.SharedMemory(create=True, size=max(len(blob), 1))
         self._shm.buf[: len(blob)] = blob
         for conn, share in zip(self.conns, shares):
-            conn.send((self.request, self._shm.name, len(blob), share))
+            try:
+                conn.send((self.request, self._shm.name, len(blob), share))
+            except (OSError, ValueError):  # the replica's process is gone: its jobs cannot be done -- the request fails, loudly
+                self.parts[self.index[id(conn)]] = {"__error__": "the worker process has gone (create a new HostFrontEnd)"}
+                self.waiting.remove(conn)
         self.trace["request_bytes"] = len(blob)
         self.trace["begin_seconds"] = perf_counter() - t0
 

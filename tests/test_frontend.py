@@ -113,3 +113,19 @@ def test_host_front_end_refuses_an_unpicklable_tokenizer_and_accepts_a_factory()
     for key in want:
         if key not in ("timing", "performance_trace"):
             assert got[key] == want[key], key
+
+
+@pytest.mark.timeout(300)
+def test_host_front_end_with_a_dead_worker_raises_instead_of_hanging():
+    from open_provence_amd.frontend import HostFrontEnd
+
+    front = HostFrontEnd(frontend_stub_model(), workers=2)
+    try:
+        assert front.process(**_request())["pruned_context"]
+        front._procs[1].terminate()
+        front._procs[1].join(timeout=30)
+        for _ in range(2):  # the request in which the loss is noticed, and the ones after it
+            with pytest.raises(RuntimeError, match="worker process has gone"):
+                front.process(**_request())
+    finally:
+        front.close()
