@@ -1505,6 +1505,26 @@ class OpenProvenceModel:
         compatibility; preprocessing runs in-process (the reference's worker processes only re-copied cached
         token ids) but the preprocess-batch heuristics that cap the forward batch are kept."""
 
+        # OPEN_PROVENCE_HOST_REPLICAS=N (or "auto"): large requests go through a HostFrontEnd kept on the model -- N worker
+        # processes run the host stages, this process runs every forward (frontend.py).  The environment's counterpart of
+        # the reference's DataLoader worker processes (standalone.py:3589) for callers that do not construct a front-end;
+        # a request whose arguments cannot be pickled (a lambda as sentence_splitter) takes the in-process path below.
+        replicas = os.environ.get("OPEN_PROVENCE_HOST_REPLICAS", "")
+        if (replicas and replicas != "0" and not getattr(self, "_dist", None) and self.__dict__.get("_remote_forward") is None
+                and not isinstance(context, str)):
+            routed = self._process_through_front_end(replicas, dict(
+                question=question, context=context, title=title, first_line_as_title=first_line_as_title, batch_size=batch_size,
+                threshold=threshold, always_select_title=always_select_title, reorder=reorder, top_k=top_k,
+                sentence_splitter=sentence_splitter, language=language, use_best_reranker_score=use_best_reranker_score,
+                zero_score_when_empty=zero_score_when_empty, show_progress=show_progress, debug_messages=debug_messages,
+                enable_warnings=enable_warnings, strip_sentences=strip_sentences,
+                respect_sentence_boundaries=respect_sentence_boundaries, return_sentence_metrics=return_sentence_metrics,
+                return_sentence_texts=return_sentence_texts, show_inference_progress=show_inference_progress,
+                preprocess_workers=preprocess_workers, preprocess_batch_size=preprocess_batch_size,
+                torch_dataloader_kwargs=torch_dataloader_kwargs))
+            if routed is not None:
+                return routed
+
         # The request's host pipeline allocates ~10 short-lived containers per context and no reference cycles: the
         # cyclic collector only adds pauses that grow with the request (measured: -22 % at 1024 contexts).
         import gc
@@ -1525,6 +1545,38 @@ class OpenProvenceModel:
         finally:
             if gc_was_enabled:
                 gc.enable()
+
+    def _process_through_front_end(self, replicas: str, call: dict[str, Any]) -> dict[str, Any] | None:
+        """``process()`` under OPEN_PROVENCE_HOST_REPLICAS: the request through a ``HostFrontEnd`` that lives on the model
+        (started on first use, restarted when the number changes).  None = take the in-process path (few contexts, or
+        arguments that cannot be sent to worker processes)."""
+
+        import pickle
+
+        from .frontend import HostFrontEnd, default_host_workers
+
+        try:
+            workers = default_host_workers() if replicas == "auto" else int(replicas)
+        except ValueError:
+            return None
+        ctx = call["context"]
+        n_contexts = sum(len(c) if isinstance(c, (list, tuple)) else 1 for c in ctx) if isinstance(ctx, (list, tuple)) else 1
+        if workers < 1 or n_contexts < 4 * workers:
+            return None  # (a replica's fixed cost per request is not worth a handful of contexts)
+        try:
+            pickle.dumps({k: v for k, v in call.items() if k not in ("question", "context")})
+        except Exception:
+            if not self.__dict__.get("_front_end_warned"):
+                self.__dict__["_front_end_warned"] = True
+                LOGGER.warning("OPEN_PROVENCE_HOST_REPLICAS: the arguments of this process() call cannot be pickled (a lambda or "
+                               "local function as sentence_splitter / debug_messages?): running it in this process")
+            return None
+        front = self.__dict__.get("_host_front_end")
+        if front is None or front.world != workers or not front._open:
+            if front is not None:
+                front.close()
+            front = self.__dict__["_host_front_end"] = HostFrontEnd(self, workers=workers)
+        return front.process(**call)
 
     def _process_impl(
         self,

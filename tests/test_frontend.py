@@ -129,3 +129,28 @@ def test_host_front_end_with_a_dead_worker_raises_instead_of_hanging():
                 front.process(**_request())
     finally:
         front.close()
+
+
+@pytest.mark.timeout(300)
+def test_process_routes_large_requests_through_replicas_when_the_environment_asks(monkeypatch):
+    """OPEN_PROVENCE_HOST_REPLICAS=N: ``model.process()`` itself keeps a HostFrontEnd and uses it for large requests; small
+    ones and calls whose arguments cannot be pickled run in-process; the results are the plain call's."""
+
+    plain_model = frontend_stub_model()
+    want = plain_model.process(**_request())
+    model = frontend_stub_model()
+    monkeypatch.setenv("OPEN_PROVENCE_HOST_REPLICAS", "2")
+    try:
+        got = model.process(**_request())
+        front = model.__dict__.get("_host_front_end")
+        assert front is not None and front.world == 2 and front.last_trace["rows"] > 0  # the replicas' forwards went through here
+        small = dict(_request(), context=_request()["context"][:3])
+        assert model.process(**small)["pruned_context"] == plain_model.process(**small)["pruned_context"]
+        local = dict(_request(), sentence_splitter=lambda text: period_splitter(text))  # cannot be pickled
+        assert model.process(**local)["pruned_context"] == want["pruned_context"]
+    finally:
+        if model.__dict__.get("_host_front_end") is not None:
+            model.__dict__["_host_front_end"].close()
+    for key in want:
+        if key not in ("timing", "performance_trace"):
+            assert got[key] == want[key], key
