@@ -1575,7 +1575,14 @@ class OpenProvenceModel:
         if front is None or front.world != workers or not front._open:
             if front is not None:
                 front.close()
-            front = self.__dict__["_host_front_end"] = HostFrontEnd(self, workers=workers)
+            if self.__dict__.get("_front_end_unavailable"):
+                return None
+            try:
+                front = self.__dict__["_host_front_end"] = HostFrontEnd(self, workers=workers)
+            except TypeError as exc:  # the tokenizer cannot be sent to worker processes
+                self.__dict__["_front_end_unavailable"] = True
+                LOGGER.warning("OPEN_PROVENCE_HOST_REPLICAS ignored: %s", exc)
+                return None
         return front.process(**call)
 
     def _process_impl(

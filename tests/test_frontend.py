@@ -148,6 +148,11 @@ def test_process_routes_large_requests_through_replicas_when_the_environment_ask
         assert model.process(**small)["pruned_context"] == plain_model.process(**small)["pruned_context"]
         local = dict(_request(), sentence_splitter=lambda text: period_splitter(text))  # cannot be pickled
         assert model.process(**local)["pruned_context"] == want["pruned_context"]
+        # a tokenizer that cannot be pickled: the variable is ignored (one warning), the call runs in-process
+        from helpers import build_wordpiece_tokenizer, golden_stub_forward, host_only_model
+
+        odd = host_only_model(tokenizer=build_wordpiece_tokenizer(True), max_length=96, forward=golden_stub_forward)
+        assert odd.process(**_request())["pruned_context"] and odd.__dict__.get("_front_end_unavailable") is True
     finally:
         if model.__dict__.get("_host_front_end") is not None:
             model.__dict__["_host_front_end"].close()
