@@ -62,7 +62,7 @@ def test_process_end_to_end_matches_reference():
 
 
 @pytest.mark.timeout(600)
-def test_host_front_end_on_the_gpu_equals_the_plain_call():
+def test_host_front_end_on_the_gpu_equals_the_plain_call(monkeypatch):
     """``HostFrontEnd``: host-stage replicas without a GPU, every forward batch merged and run by this process -- the G3
     cases against the reference, and a 90-context request against the plain call (probabilities and scores bit for
     bit: a row's outputs do not depend on its batch companions, the fragment means are taken on the device either way)."""
@@ -93,6 +93,16 @@ def test_host_front_end_on_the_gpu_equals_the_plain_call():
         assert got[key] == want[key], key
         assert got_top[key] == want_top[key], key
     assert model.process(**big)["pruned_context"] == want["pruned_context"]  # the model is a plain model again
+    # the same through the environment: process() itself keeps the front-end
+    monkeypatch.setenv("OPEN_PROVENCE_HOST_REPLICAS", "3")
+    try:
+        routed = model.process(**big)
+        assert model.__dict__["_host_front_end"].last_trace["rows"] > 0
+    finally:
+        model.__dict__["_host_front_end"].close()
+    for key in want:
+        if key not in ("timing", "performance_trace"):
+            assert routed[key] == want[key], key
 
 
 def test_padded_forward_boundary():
