@@ -34,8 +34,8 @@ which owns the GPU, takes no jobs itself, MERGES the batches that are waiting in
 + per-fragment means (4 bytes per fragment).  Same job assignment, same per-row arithmetic (a row's outputs do not depend
 on its batch companions), so the result equals the plain call's.  Measured (profiles/r04_process_e2e.txt; the GPU box's
 container has a CPU quota of 16 cores -- cpu.max 1600000 100000 -- so every figure with more than 16 busy processes is
-throttled): 1024 contexts, WordPiece tokenizer: 24.1 k contexts/s with 31 replicas (ProcessFrontEnd, 9 workers: 19.8 k;
-one process: 4.85 k), 4096 contexts: 29.6 k, 256: 16.2-16.7 k.  ``HostFrontEnd.last_trace`` holds the owner's time line of the
+throttled): 1024 contexts, WordPiece tokenizer: 24-27 k contexts/s with 31 replicas (ProcessFrontEnd, 9 workers: 19.8 k;
+one process: 4.85 k), 4096 contexts: 30.6 k, 256: 18.3 k.  ``HostFrontEnd.last_trace`` holds the owner's time line of the
 last request (launch sizes and times, the slowest replica's stamps).
 """
 
@@ -44,7 +44,7 @@ from __future__ import annotations
 import atexit
 import os
 import socket
-from time import perf_counter
+from time import perf_counter, process_time
 from typing import Any, Callable
 
 __all__ = ["ProcessFrontEnd", "HostFrontEnd", "default_host_workers", "usable_cores"]
@@ -192,7 +192,8 @@ class _ReplicaLink:
     # -- this replica's part of the result (OpenProvenceModel._gather_job_results) --------------------------------------
     def exchange(self, _model: Any, mine: dict) -> list:
         # (perf_counter is the system-wide monotonic clock: the owner can place these stamps on its own time line)
-        self.conn.send(("result", self.request, mine, dict(self.stamps, part_sent=perf_counter())))
+        self.conn.send(("result", self.request, mine, dict(self.stamps, part_sent=perf_counter(),
+                                                           cpu_seconds=process_time() - self.stamps.get("cpu0", process_time()))))
         self.delivered = True
         return []
 
@@ -221,18 +222,18 @@ def _serve_host_stages(rank: int, world: int, conn: Any, spec: dict) -> None:
             continue  # the answer to a forward batch of a request this replica has already given up on
         link.request, shm_name, size, mine = message
         link.delivered = False
-        link.stamps = {"request_received": perf_counter()}
+        link.stamps = {"request_received": perf_counter(), "cpu0": process_time()}
         try:
             block = shared_memory.SharedMemory(name=shm_name)
             try:
-                kwargs, handed = pickle.loads(bytes(block.buf[:size]))
+                kwargs, queries = pickle.loads(bytes(block.buf[:size]))
             finally:
                 block.close()
-            # this replica's texts into the shared skeleton (every other context stays blank: it is nobody's business here)
-            contexts = [list(per_query) for per_query in handed["contexts"]]
-            for q_idx, c_idx, entry in mine:
-                contexts[q_idx][c_idx] = entry
-            model._dist["prenormalized"] = dict(handed, contexts=contexts)
+            contexts, own_titles = mine  # per query: the texts this replica owns (the owner knows where they belong)
+            if own_titles is not None:
+                kwargs = dict(kwargs, title=own_titles)
+            model._dist["prenormalized"] = {"queries": queries, "contexts": contexts, "structure": "nested",
+                                            "owner": [[rank] * len(per_query) for per_query in contexts]}
             model.process(None, None, **kwargs)
         except Exception as exc:  # noqa: BLE001 - reported to the owner, which raises for the caller; keep serving
             if not link.delivered:
@@ -250,10 +251,12 @@ class _OwnerHub:
         self.waiting: list[Any] = []
 
     def _split_request(self, model: Any, args: tuple, kwargs: dict):
-        """Normalise the request and assign its jobs ONCE, here: -> (keyword arguments without question / context, the
-        structure every replica shares -- queries, the contexts' skeleton with every text blanked, the owner table --, per
-        replica the (query, context, text) entries it owns).  A replica that normalised and assigned all N contexts itself
-        spent ~4 ms per 1024 contexts on it before its first tokenizer call -- times the number of replicas in CPU time."""
+        """Normalise the request and assign its jobs ONCE, here: -> (what every replica shares: the keyword arguments
+        without question / context, the queries; per replica its own COMPACT request: per query the texts it owns -- and
+        their titles, when titles were given per context --; per replica and query the positions of those contexts in the
+        caller's request).  A replica then runs an ordinary small ``process()``: nothing in it grows with the size of the
+        whole request (normalising, assigning and post-processing placeholders for all N contexts in every replica was
+        ~2-4 ms per 1024 contexts and replica -- a sixth of all the CPU time of a call with 31 replicas)."""
 
         import inspect
 
@@ -262,21 +265,32 @@ class _OwnerHub:
         bound = inspect.signature(model.process).bind(*args, **kwargs)
         call = dict(bound.arguments)
         question, context = call.pop("question"), call.pop("context")
-        queries, contexts, structure = model._normalize_inputs(question, context)
-        resolved, _titles = model._resolve_titles(queries, contexts, call.get("title", "first_sentence"),
-                                                  first_line_as_title=call.get("first_line_as_title", False))
+        queries, contexts, _structure = model._normalize_inputs(question, context)
+        first_line = bool(call.get("first_line_as_title", False))
+        resolved, titles = model._resolve_titles(queries, contexts, call.get("title", "first_sentence"), first_line_as_title=first_line)
         owner = pl.assign_jobs(resolved, len(self.conns))  # (on the texts process() assigns on: after the title pass)
-        shares: list[list] = [[] for _ in self.conns]
-        skeleton = []
+        per_context_titles = (not first_line) and any(isinstance(t, list) for t in titles)
+        n = len(self.conns)
+        positions = [[[] for _ in queries] for _ in range(n)]
+        texts = [[[] for _ in queries] for _ in range(n)]
         for q_idx, per_query in enumerate(contexts):
-            skeleton.append([[] if isinstance(entry, list) else "" for entry in per_query])
             for c_idx, entry in enumerate(per_query):
-                shares[owner[q_idx][c_idx]].append((q_idx, c_idx, entry))
-        return call, {"queries": queries, "contexts": skeleton, "structure": structure, "owner": owner}, shares
+                rank = owner[q_idx][c_idx]
+                positions[rank][q_idx].append(c_idx)
+                texts[rank][q_idx].append(entry)
+        shares = []
+        for rank in range(n):
+            own_titles = None
+            if per_context_titles:  # prepare_titles' per-context form: a list of titles per query
+                own_titles = [[titles[q][c] for c in positions[rank][q]] if isinstance(titles[q], list) else titles[q]
+                              for q in range(len(queries))]
+            shares.append((texts[rank], own_titles))
+        self.positions = positions
+        return call, queries, shares
 
     def begin(self, model: Any, args: tuple, kwargs: dict) -> None:
-        """One request to every replica: the shared part (settings, queries, skeleton, owner table) is pickled ONCE into a
-        shared-memory block, each replica's own texts go down its pipe."""
+        """One request to every replica: the shared part (settings, queries) is pickled ONCE into a shared-memory block,
+        each replica's own compact request goes down its pipe."""
 
         import pickle
         from multiprocessing import shared_memory
@@ -284,13 +298,14 @@ class _OwnerHub:
         from time import perf_counter
 
         t0 = perf_counter()
+        self._cpu0 = process_time()
         self.request += 1
         self.parts = [None] * len(self.conns)
         self.waiting = list(self.conns)
         self.trace = {"request_bytes": 0, "begin_seconds": 0.0, "serve_seconds": 0.0, "launches": 0, "batches": 0, "rows": 0,
                       "first_batch_seconds": None, "last_part_seconds": None, "t0": t0}
-        kwargs, handed, shares = self._split_request(model, args, kwargs)
-        blob = pickle.dumps((kwargs, handed), protocol=pickle.HIGHEST_PROTOCOL)
+        kwargs, queries, shares = self._split_request(model, args, kwargs)
+        blob = pickle.dumps((kwargs, queries), protocol=pickle.HIGHEST_PROTOCOL)
         self.release()
         self._shm = shared_memory.SharedMemory(create=True, size=max(len(blob), 1))
         self._shm.buf[: len(blob)] = blob
@@ -376,10 +391,15 @@ class _OwnerHub:
                 elif kind == "rows":
                     backlog.append((conn, payload))
                 elif kind == "result" and request == self.request:
-                    self.parts[self.index[id(conn)]] = payload
+                    who = self.index[id(conn)]
+                    if isinstance(payload, dict) and "__error__" not in payload:  # a replica counts ITS contexts: back to the caller's
+                        payload = {(q, self.positions[who][q][c]): values for (q, c), values in payload.items()}
+                    self.parts[who] = payload
                     self.waiting.remove(conn)
                     trace["last_part_seconds"] = perf_counter() - trace["t0"]
-                    if stamps:  # the slowest replica's time line, relative to the start of the request
+                    if stamps:  # CPU time of all replicas; the slowest replica's time line, relative to the start of the request
+                        trace["replica_cpu_seconds"] = trace.get("replica_cpu_seconds", 0.0) + stamps.pop("cpu_seconds", 0.0)
+                        stamps.pop("cpu0", None)
                         rel = {k: v - trace["t0"] for k, v in stamps.items()}
                         if rel.get("part_sent", 0.0) >= trace.get("replica", {}).get("part_sent", 0.0):
                             trace["replica"] = rel
@@ -541,6 +561,7 @@ class HostFrontEnd:
         try:
             result = model.process(*args, **kwargs)
             self.last_trace = {k: v for k, v in hub.trace.items() if k != "t0"}  # where the owner's time went (seconds)
+            self.last_trace["owner_cpu_seconds"] = process_time() - hub._cpu0
             return result
         finally:
             model._dist = None

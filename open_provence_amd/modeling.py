@@ -1755,11 +1755,11 @@ class OpenProvenceModel:
             if self._can_pipeline() and not batch_explicit:
                 granule = -(-int(3.2 * total_jobs**0.5) // 16) * 16
                 preprocess_batch = min(preprocess_batch, max(32, granule))
-                if self.__dict__.get("_remote_forward") is not None:
-                    # host-stage replica: its batches are merged with the other replicas' by the GPU owner, so a launch
-                    # costs this process a pipe message, not a forward -- four batches per request keep the GPU busy from
-                    # the first quarter of the host work on
-                    preprocess_batch = min(preprocess_batch, max(8, -(-total_jobs // 4)))
+                if preprocess_batch < total_jobs <= preprocess_batch * 3 // 2:
+                    preprocess_batch = total_jobs  # (no separate launch for a remainder of less than half a granule)
+                # (a host-stage replica keeps this granule: with many replicas the GPU owner already sees a stream of
+                # batches, and every extra batch costs a replica ~1 ms of fixed work -- measured at 1024 contexts and 31
+                # replicas: one batch per replica 27.2 k contexts/s, four 23.8 k, six 22.8 k)
             while True:
                 batch_jobs = list(itertools.islice(job_stream, preprocess_batch))
                 if not batch_jobs:

@@ -90,6 +90,9 @@ def test_host_front_end_titles_and_several_queries():
         dict(question=["which boats?", "how tall is the tower?"], context=[contexts[:5], contexts[5:9]], **common),
         dict(question=["which boats?", "how tall is the tower?"], context=[contexts[0], contexts[1]], **common),
         dict(question="which boats?", context=contexts[3], **common),
+        dict(question=base["question"], context=contexts, title="One title for all", **common),
+        dict(question=base["question"], context=contexts, title=None, always_select_title=True, **common),
+        dict(question=["which boats?", "how tall is the tower?"], context=[contexts[:5], contexts[5:9]], title=["Boats", "Towers"], **common),
     ]
     plain_model = frontend_stub_model()
     with HostFrontEnd(frontend_stub_model(), workers=3) as front:
