@@ -494,7 +494,7 @@ def usable_cores() -> float:
 
 def default_host_workers() -> int:
     """Replicas ``HostFrontEnd`` starts when the caller does not say: twice the usable cores minus the owner, at most 31
-    (measured under a quota of 16 cores: 15 replicas 19.2 k contexts/s, 23: 21.7 k, 31: 24.1 k at 1024 contexts -- a
+    (measured under a quota of 16 cores: 15 replicas 19-21 k contexts/s, 23: 22-25 k, 31: 24-27 k at 1024 contexts -- a
     replica spends part of a request waiting for the owner's answers, so a modest oversubscription pays)."""
 
     return int(max(1, min(31, 2 * usable_cores() - 1)))
