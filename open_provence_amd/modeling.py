@@ -1369,7 +1369,12 @@ class OpenProvenceModel:
 
     def _store_raw_predictions(self, chunk, ranges_per_job, queries, states, rank, keeps) -> None:
         rank_scores = rank[:, 0] if rank.ndim == 2 and rank.shape[1] > 1 else rank.reshape(-1)
-        scores = torch.sigmoid(rank_scores.to(torch.float32)).tolist()  # = _ranking_score row by row (ref :2913-2916)
+        # = _ranking_score row by row (ref :2913-2916), bit for bit: ATen's vectorized sigmoid of a contiguous batch differs
+        # from the scalar one the reference's one-row tensors take by 1 ulp in ~4 % of the elements -- and by WHICH elements
+        # depends on a row's position in the batch.  A strided view sends every element through the scalar functor.
+        spread = torch.empty((rank_scores.numel(), 2), dtype=torch.float32)
+        spread[:, 0] = rank_scores.reshape(-1).to(torch.float32)
+        scores = torch.sigmoid(spread[:, 0]).tolist()
         for i, job in enumerate(chunk):
             reduced = isinstance(keeps[i], list)  # per-fragment means from the device (see _launch_rows)
             if (scores[i] != scores[i] or (reduced and any(m != m for m in keeps[i]))) and not self.__dict__.get("_nan_warned"):

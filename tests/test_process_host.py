@@ -180,3 +180,25 @@ def test_fast_tokenizer_requests_take_worker_threads_by_default_and_change_nothi
     assert any(name.startswith("open-provence-prep") for name in seen), seen
     for key in ("pruned_context", "reranking_score", "kept_sentences", "removed_sentences", "sentence_probabilities"):
         assert own[key] == single[key] and asked[key] == single[key], key
+
+
+def test_ranking_scores_of_a_batch_equal_the_reference_row_by_row_sigmoid():
+    """The reference scores one row at a time (torch.sigmoid of a one-row tensor: ATen's scalar path, standalone.py:2913-2916);
+    a vectorized sigmoid over the whole batch differs from it by 1 ulp in a few per cent of the rows, and in WHICH rows
+    depends on their position -- the batch form must give every row the reference's value wherever it stands."""
+
+    import torch
+
+    from open_provence_amd import pipeline as pl
+
+    model = host_only_model(forward=golden_stub_forward)
+    torch.manual_seed(3)
+    rank = torch.randn(257, 1) * 4
+    states = {(0, i): pl.ContextState(sentences=[], fragments=[], blocks=[[]], prefix_length=0, prefix_sentences=[],
+                                      prefix_token_counts=[], title_is_first_sentence=False, original_text="") for i in range(257)}
+    chunk = [{"query_idx": 0, "context_idx": i, "block_idx": 0, "texts": []} for i in range(257)]
+    keeps = [torch.zeros(1).numpy() for _ in range(257)]
+    model._store_raw_predictions(chunk, [[] for _ in range(257)], ["q"], states, rank, keeps)
+    got = [states[(0, i)].raw_blocks[0][1].ranking_score for i in range(257)]
+    want = [model._ranking_score(rank[i]) for i in range(257)]
+    assert got == want  # (torch.sigmoid(rank.reshape(-1)) differs from `want` in ~4 % of the rows on an AVX2 / AVX-512 host)
