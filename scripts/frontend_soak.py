@@ -24,6 +24,8 @@ def main() -> None:
     ap.add_argument("--requests", type=int, default=150)
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--stub", action="store_true")
+    ap.add_argument("--self", dest="self_check", action="store_true",
+                    help="no front-end: the plain call against itself with another batch size, preprocess batch and worker threads")
     args = ap.parse_args()
     from open_provence_amd.frontend import HostFrontEnd
 
@@ -40,7 +42,9 @@ def main() -> None:
         return " ".join(" ".join(rng.choice(words) for _ in range(rng.randint(2, 9))).capitalize() + "." for _ in range(rng.randint(1, 8)))
 
     bad, t0 = 0, time.time()
-    with HostFrontEnd(owner, workers=args.workers) as front:
+    import contextlib
+
+    with (contextlib.nullcontext() if args.self_check else HostFrontEnd(owner, workers=args.workers)) as front:
         for trial in range(args.requests):
             shape = rng.choice(["list", "nested", "str", "aligned"])
             if shape == "str":
@@ -60,7 +64,12 @@ def main() -> None:
             if rng.random() < 0.2 and shape == "list":
                 kw["title"] = [f"T{i}" for i in range(len(c))]
             want = plain.process(q, c, **kw)
-            got = front.process(q, c, **kw)
+            if args.self_check:
+                other = dict(kw, batch_size=rng.choice([1, 3, 16, 64]), preprocess_batch_size=rng.choice([None, 5, 40]),
+                             preprocess_workers=rng.choice([None, 0, 2]))
+                got = owner.process(q, c, **other)
+            else:
+                got = front.process(q, c, **kw)
             for key in want:
                 if key not in ("timing", "performance_trace") and want[key] != got[key]:
                     bad += 1
