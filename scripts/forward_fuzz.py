@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""GPU fuzz of the HIP forward against the oracle: random ragged batches whose row lengths sit on and around every
+granularity the kernels tile by (1, 16, 32, 64, 128, 256 tokens; the sliding window's +-64; the 32-row alignment of a
+sequence), on the published shapes at reduced depth, both checkpoint dtypes, default flags.  Prints the worst error per
+configuration; exits 1 on a non-finite output or an error above 8e-4 (the path's bar is 1e-3).
+
+    python scripts/forward_fuzz.py [--trials 40] [--seed 0]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from open_provence_amd.engine import HipEncoder  # noqa: E402
+from open_provence_amd.packing import pack_rows  # noqa: E402
+from open_provence_amd.synthetic import named_dims, pad_rows, synth_state_dict  # noqa: E402
+from oracle.modernbert_oracle import oracle_forward  # noqa: E402  (the checker)
+
+NASTY = [1, 2, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 95, 96, 127, 128, 129, 160, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 511, 512, 513, 640]
+
+
+def random_rows(rng: np.random.Generator, dims, n_rows: int, long_row: bool) -> list[list[int]]:
+    rows = []
+    for i in range(n_rows):
+        n = int(rng.choice(NASTY)) if rng.random() < 0.8 else int(rng.integers(1, 700))
+        if long_row and i == 0:
+            n = int(rng.choice([1023, 1024, 1025, 1500, 2048]))
+        body = rng.integers(1000, dims.vocab_size - 1000, size=max(n - 2, 0)).tolist()
+        rows.append(([dims.cls_token_id or 1] + body + [dims.sep_token_id or 2])[:n])
+    return rows
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    torch.set_num_threads(16)
+    rng = np.random.default_rng(args.seed)
+    configs = [("xsmall", {}), ("base", {"num_hidden_layers": 4}), ("en-gte", {"num_hidden_layers": 4}), ("large", {"num_hidden_layers": 4})]
+    failed = False
+    for model, overrides in configs:
+        dims = named_dims(model, **overrides)
+        for weights in ("fp32", "bf16"):
+            state = synth_state_dict(dims, seed=7)
+            if weights == "bf16":
+                state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+            enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+            enc.load_state_dict(state)
+            _SETS[(dims.hidden_size, weights)] = enc.effective_policy()["kernel_set"]
+            worst, worst_at, tokens = 0.0, None, 0
+            for trial in range(args.trials):
+                rows = random_rows(rng, dims, int(rng.integers(1, 13)), long_row=trial % 10 == 9)
+                ids_np, cu_np, max_len = pack_rows(rows)
+                prune, rank = enc.forward_packed(torch.from_numpy(ids_np).cuda(), torch.from_numpy(cu_np).cuda(), cu_np, max_len)
+                prune, rank = prune.cpu().numpy(), rank.cpu().numpy()
+                tokens += int(cu_np[-1])
+                if not (np.isfinite(prune).all() and np.isfinite(rank).all()):
+                    print(f"NON-FINITE {model} {weights} trial {trial} lengths {[len(r) for r in rows]}", flush=True)
+                    failed = True
+                    continue
+                ids, mask = pad_rows(rows)
+                with torch.no_grad():
+                    ref = oracle_forward(state, dims, ids, mask, attn="sdpa")
+                rp, rr = ref.pruning_logits.numpy(), ref.ranking_logits.numpy()
+                for i, row in enumerate(rows):
+                    err = max(float(np.abs(prune[cu_np[i] : cu_np[i + 1]] - rp[i, : len(row)]).max()), float(np.abs(rank[i] - rr[i]).max()))
+                    if err > worst:
+                        worst, worst_at = err, (trial, i, len(row), [len(r) for r in rows])
+            enc.close()
+            flag = "  <-- ABOVE 8e-4" if worst > 8e-4 else ""
+            failed = failed or worst > 8e-4
+            print(f"{model:7s} {dims.num_layers:2d} layers {weights:5s} {enc_kernel_set(dims, weights):22s} {args.trials} batches {tokens:7d} tokens  worst |error| {worst:.2e} at {worst_at}{flag}", flush=True)
+    sys.exit(1 if failed else 0)
+
+
+_SETS: dict = {}
+
+
+def enc_kernel_set(dims, weights) -> str:
+    return _SETS.get((dims.hidden_size, weights), "")
+
+
+if __name__ == "__main__":
+    main()
