@@ -14,6 +14,7 @@ Schemes (left = activation-side operand, right = weight / key / value):
   f16            single pass fp16
   f16+f8         left = fp16 hi + e4m3 lo (x 2^S), right fp16 for the hi product and e4m3 for the lo product
   f16+2f8        as f16+f8 plus  e4m3(left) x e4m3(lo(right))  (fp32-valued weights)
+  f16+alo16+f8w  f16+2f8 with lo(left) as an fp16 fragment; f16+f8a+wlo16: with lo(right) as one; f16x3: both
 
     python scripts/precision_emulate.py [--fixtures g0c_hd64_synth,g1_xsmall] [--bf16-weights]
 """
@@ -83,6 +84,13 @@ def make_mm(scheme: str, families: set[str] | None = None):
             if base == "f16+2f8":
                 out = out + f8(ah, as_) @ f8(bl, ls + ws)
             return out
+        if sch in ("f16+alo16+f8w", "f16+f8a+wlo16", "f16x3"):
+            # the lo part of ONE side (or both) as an fp16 fragment instead of e4m3: one more 16-bit MFMA for that term
+            ah, al = split_pair(a, torch.float16)
+            bh, bl = split_pair(b, torch.float16)
+            left = rne(al, torch.float16) @ bh if sch != "f16+f8a+wlo16" else f8(al, LO_SHIFT) @ f8(bh, 0)
+            right = ah @ rne(bl, torch.float16) if sch != "f16+alo16+f8w" else f8(ah, 0) @ f8(bl, LO_SHIFT)
+            return ah @ bh + left + right
         if sch == "bf16+f8":
             ah, al = split_pair(a, torch.bfloat16)
             return ah @ rne(b, torch.bfloat16) + f8(al, 9) @ f8(rne(b, torch.bfloat16))
