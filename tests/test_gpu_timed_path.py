@@ -19,7 +19,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 PAIRS, SEQ_LEN = 256, 512
-CHECKED = [0, 1, 63, 126, 127, 128, 129, 200, 254, 255]  # first / last pair of each half of the batch, and spread ones
+CHECKED = list(range(PAIRS))  # EVERY pair of the timed batch (the oracle takes ~10 s for 256 x 512 on the box's 16 cores):
+# the maximum over 256 rows sits 1.3-1.4 x above what ten spot-checked pairs show (profiles/r04_error_tail.txt)
 
 
 def _bench_setup(weights: str):
@@ -41,9 +42,13 @@ def _oracle(state, dims, rows):
     from oracle.modernbert_oracle import oracle_forward
 
     ids, mask = pad_rows(rows)
+    prune, rank = [], []
     with torch.no_grad():
-        ref = oracle_forward(state, dims, ids, mask, attn="sdpa")
-    return ref.pruning_logits.numpy(), ref.ranking_logits.numpy()
+        for start in range(0, len(rows), 32):  # (in batches the CPU caches like)
+            ref = oracle_forward(state, dims, ids[start : start + 32], mask[start : start + 32], attn="sdpa")
+            prune.append(ref.pruning_logits.numpy())
+            rank.append(ref.ranking_logits.numpy())
+    return np.concatenate(prune), np.concatenate(rank)
 
 
 @pytest.mark.parametrize("weights,kernel_set", [("bf16", "f16-f8"), ("fp32", "f16-f8-w")])
@@ -87,7 +92,8 @@ def test_bench_configuration_matches_the_oracle(weights, kernel_set):
 
     ref_prune, ref_rank = _oracle(state, dims, [rows[i] for i in CHECKED])
     got_prune, got_rank = prune1[CHECKED], rank1[CHECKED]
-    # bar of the path: 1e-3; regression bound of THIS configuration: 8e-4 (measured <= 6.0e-4 on either checkpoint dtype)
+    # bar of the path: 1e-3; regression bound of THIS configuration: 8e-4 (measured over all 256 pairs: 6.5e-4 fp32-valued,
+    # 4.9e-4 bf16-valued)
     assert np.abs(got_prune - ref_prune).max() < 8e-4, float(np.abs(got_prune - ref_prune).max())
     assert np.abs(got_rank - ref_rank).max() < 8e-4, float(np.abs(got_rank - ref_rank).max())
     # the decision quantity of process(): keep-probabilities (standalone.py:2918-2924)
