@@ -91,6 +91,18 @@ def make_mm(scheme: str, families: set[str] | None = None):
             left = rne(al, torch.float16) @ bh if sch != "f16+f8a+wlo16" else f8(al, LO_SHIFT) @ f8(bh, 0)
             right = ah @ rne(bl, torch.float16) if sch != "f16+alo16+f8w" else f8(ah, 0) @ f8(bl, LO_SHIFT)
             return ah @ bh + left + right
+        if sch in ("f16+alo2f8", "f16+alo_exact_wf8", "f16+alof8_wexact"):
+            # diagnostics of the lo(left) x e4m3(right) term: which rounding is its error -- lo(left)'s or right's?
+            ah, al = split_pair(a, torch.float16)
+            bh, bl = split_pair(b, torch.float16)
+            if sch == "f16+alo2f8":      # lo(left) as TWO e4m3 planes (a second K = 128 product on the same e4m3(right))
+                l1 = f8(al, LO_SHIFT)
+                left = (l1 + f8(al - l1, LO_SHIFT + 4)) @ f8(bh, 0)
+            elif sch == "f16+alo_exact_wf8":
+                left = al @ f8(bh, 0)
+            else:
+                left = f8(al, LO_SHIFT) @ bh
+            return ah @ bh + left + f8(ah, 0) @ f8(bl, LO_SHIFT)
         if sch == "bf16+f8":
             ah, al = split_pair(a, torch.bfloat16)
             return ah @ rne(b, torch.bfloat16) + f8(al, 9) @ f8(rne(b, torch.bfloat16))
