@@ -44,6 +44,7 @@ from __future__ import annotations
 import atexit
 import os
 import socket
+import threading
 from time import perf_counter, process_time
 from typing import Any, Callable
 
@@ -547,13 +548,20 @@ class HostFrontEnd:
                 raise RuntimeError("a host-stage worker did not start")
         self._hub = _OwnerHub(conns)
         self._open = True
+        self._lock = threading.Lock()
         atexit.register(self.close)
 
     def process(self, *args: Any, **kwargs: Any):
-        """``OpenProvenceModel.process`` with the host stages on the replicas and every forward on this process's GPU."""
+        """``OpenProvenceModel.process`` with the host stages on the replicas and every forward on this process's GPU.
+        One request at a time (calls from several threads are serialised here); while a request runs the model is the
+        owner of a job-sharded call -- do not call ``model.process`` directly from another thread meanwhile."""
 
         if not self._open:
             raise RuntimeError("the front-end has been closed")
+        with self._lock:
+            return self._process_locked(args, kwargs)
+
+    def _process_locked(self, args: tuple, kwargs: dict):
         hub, model = self._hub, self.model
         hub.begin(model, args, kwargs)
         model._dist = {"group": None, "dst": self.world, "rank": self.world, "world": self.world, "force": True, "shard": "jobs",
