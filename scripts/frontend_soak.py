@@ -24,6 +24,7 @@ def main() -> None:
     ap.add_argument("--requests", type=int, default=150)
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--stub", action="store_true")
+    ap.add_argument("--ranks", action="store_true", help="ProcessFrontEnd (worker ranks with a model each, gloo) instead of HostFrontEnd")
     ap.add_argument("--self", dest="self_check", action="store_true",
                     help="no front-end: the plain call against itself with another batch size, preprocess batch and worker threads")
     args = ap.parse_args()
@@ -44,7 +45,16 @@ def main() -> None:
     bad, t0 = 0, time.time()
     import contextlib
 
-    with (contextlib.nullcontext() if args.self_check else HostFrontEnd(owner, workers=args.workers)) as front:
+    if args.ranks:
+        from open_provence_amd.frontend import ProcessFrontEnd
+
+        factory = frontend_stub_model
+        if not args.stub:
+            from process_e2e import build_e2e_model as factory
+        make_front = lambda: ProcessFrontEnd(factory, workers=args.workers, model=owner)  # noqa: E731
+    else:
+        make_front = lambda: HostFrontEnd(owner, workers=args.workers)  # noqa: E731
+    with (contextlib.nullcontext() if args.self_check else make_front()) as front:
         for trial in range(args.requests):
             shape = rng.choice(["list", "nested", "str", "aligned"])
             if shape == "str":
