@@ -47,7 +47,7 @@ sys.path.insert(0, str(ROOT))
 from open_provence_amd.config import EncoderDims  # noqa: E402
 from open_provence_amd.engine import HipEncoder  # noqa: E402
 from open_provence_amd.packing import pack_rows  # noqa: E402
-from open_provence_amd.synthetic import named_dims, synth_pair_batch, synth_state_dict, synth_varlen_lengths  # noqa: E402
+from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch, synth_state_dict, synth_varlen_lengths  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FRAGMENT_TOKENS = 32  # synthetic sentence length for the multi-GPU exchange (one fp32 per sentence is gathered)
@@ -112,7 +112,27 @@ ARITHMETIC_OF_KERNEL_SET = {
     "bf16-weights+wi-f16-f8": "bf16 (hi, lo) split activations x single-plane bf16 weights; Wi GEMM: fp16 hi + e4m3 lo; fp32 accumulate",
     "bf16-weights": "bf16 (hi, lo) split activations x single-plane bf16 weights, fp32 accumulate",
     "bf16": "bf16 single pass, fp32 accumulate",
+    "f16": "fp16 single pass (11 significant bits per operand), fp32 accumulate",
 }
+
+
+def make_state(dims: EncoderDims, init: str, weights: str) -> dict:
+    """The synthetic checkpoint of a record.  ``init``: "refinit" = the reference's own initialisation (truncated normal,
+    initializer_range 0.02: SURVEY.md section 8d "seeded random init (oracle recipe)", synthetic.refinit_state_dict) or
+    "o1" = every GEMM weight of O(1) magnitude (synthetic.synth_state_dict: the harshest case for an operand format, no
+    checkpoint of the reference looks like it -- kept as the worst-case record).  ``weights``: "fp32" as saved, or "bf16" =
+    the GEMM weights rounded to bf16 (what a bf16-stored checkpoint holds)."""
+
+    state = (refinit_state_dict if init == "refinit" else synth_state_dict)(dims, seed=7)
+    if weights == "bf16":
+        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    return state
+
+
+def checksum_key(model: str, shape: str, init: str, weights: str) -> str:
+    """Key into tests/golden/bench_checksums.json (the O(1) workloads keep the keys of rounds 3 / 4)."""
+
+    return f"{model}|{shape}|{weights if init == 'o1' else init + '-' + weights}"
 
 
 def arithmetic_label(policy: dict) -> str:
@@ -257,6 +277,17 @@ def main() -> None:
                         "bf16, i.e. what the reference's GPU default makes of them at load time (standalone.py:219-233); "
                         "reported as the `bf16_checkpoint` sub-record of the default run.  The arithmetic policy is "
                         "--precision either way")
+    parser.add_argument("--init", default="refinit", choices=["refinit", "o1"],
+                        help="what the synthetic weights look like.  refinit (default, the headline since round 5): the "
+                        "reference's own initialisation -- truncated normal, initializer_range 0.02 -- which is the recipe SURVEY.md "
+                        "section 8d prescribes for the bench weights and the scale a trained checkpoint's weights have; the library "
+                        "then CALIBRATES its arithmetic on them (op_calibrate: the cheapest kernel set within 1e-4 of the (hi, lo) "
+                        "bf16 kernels).  o1: every GEMM weight O(1) (the headline of rounds 1-4), where no cheaper set holds and "
+                        "the all-terms sets run: reported by the default run as the `worst_case_o1_weights` sub-record")
+    parser.add_argument("--calibrate", default=None,
+                        help="tolerance of the load-time calibration (default: OPEN_PROVENCE_CALIBRATE or 1e-4; 0 = off: the default "
+                        "selection of op_weights_ready)")
+    parser.add_argument("--no-worst-case", action="store_true", help="skip the O(1)-weights sub-record")
     parser.add_argument("--write-checksums", action="store_true",
                         help="store the output checksums of this run's workloads in tests/golden/bench_checksums.json (after a "
                         "deliberate change of arithmetic, once the GPU parity tests are green); a plain run COMPARES with them")
@@ -301,11 +332,10 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     dims = named_dims(args.model)
-    state = synth_state_dict(dims, seed=7)
-    if args.weights == "bf16":  # the GEMM weights as a bf16 checkpoint stores them (values exactly representable in bf16)
-        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    state = make_state(dims, args.init, args.weights)
+    calibrate = None if args.calibrate is None else float(args.calibrate)
     encoder = HipEncoder(dims, device=device, precision=args.precision, chunk_rows=args.chunk_rows or None)
-    encoder.load_state_dict(state)
+    encoder.load_state_dict(state, calibrate=calibrate)
     policy = encoder.effective_policy()
 
     # 1 query x (pairs * world) contexts, sharded over the ranks by the product's own plan (token-balanced partition,
@@ -422,8 +452,8 @@ def main() -> None:
         elapsed = float(t.item())
     require_finite("the headline workload", out[0], out[1])
     finite = True
-    wl_key = f"{args.model}|{n_pairs_rank}x{'varlen' if args.varlen else args.seq_len}|"
-    checksum = output_checksum(out[0], out[1], wl_key + args.weights if world == 1 and args.precision == "bf16x3" else None)
+    wl_shape = f"{n_pairs_rank}x{'varlen' if args.varlen else args.seq_len}"
+    checksum = output_checksum(out[0], out[1], checksum_key(args.model, wl_shape, args.init, args.weights) if world == 1 and args.precision == "bf16x3" else None)
     # per-kernel HIP-event timing on the launch stream (separate, un-timed passes)
     encoder.profile_enable(True)
     encoder.profile_reset()
@@ -570,7 +600,11 @@ def main() -> None:
             f"V={dims.vocab_size}), "
             + (f"{n_pairs_rank} pairs/GPU of mixed length 128..2048 ({total_tokens} tokens, varlen-packed)" if args.varlen
                else f"{args.pairs} pairs/GPU x seq_len {args.seq_len}")
-            + ", 1 query x N contexts, random-init weights",
+            + ", 1 query x N contexts, "
+            + ("random weights in the reference's initialisation (truncated normal, initializer_range 0.02: SURVEY.md 8d)" if args.init == "refinit"
+               else "random weights of O(1) magnitude (worst case for an operand format)"),
+            "weights_init": args.init,
+            "calibration": encoder.calibration,  # how the kernel set was chosen from the loaded weights (op_calibrate)
             "pairs_per_gpu": n_pairs_rank,
             "seq_len": args.seq_len,
             "global_pairs": n_pairs_rank * world,
@@ -631,15 +665,14 @@ def main() -> None:
                                 "ms_per_step": dt * 1e3, "algorithmic_gflop_per_pair": flops_l / 1e9,
                                 "whole_forward_frac": long_pairs / dt * flops_l / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                                 "shader_clock_ghz": probed_pass(encoder, long_step, long_steps, dt, sync_dev)["value"],
-                                "output_checksum": output_checksum(out_l[0], out_l[1], f"{args.model}|{long_pairs}x2048|{args.weights}" if args.precision == "bf16x3" else None)}
-    if world == 1 and not args.varlen and not args.no_other_dtype:
-        # the same workload with the OTHER checkpoint dtype, timed by the same command (sub-record, not the headline)
-        other = "bf16" if args.weights == "fp32" else "fp32"
-        state_o = synth_state_dict(dims, seed=7)
-        if other == "bf16":
-            state_o = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state_o.items()}
+                                "output_checksum": output_checksum(out_l[0], out_l[1], checksum_key(args.model, f"{long_pairs}x2048", args.init, args.weights) if args.precision == "bf16x3" else None)}
+    def sub_record(init: str, weights: str, what: str) -> dict:
+        """The SAME batch on another synthetic checkpoint (other stored dtype, or the O(1) worst-case weights), timed by the same
+        command: pairs/s as the headline's launch form and as one launch sequence, the kernel set chosen for those weights,
+        per-kernel times and the dominant kernel's roofline fraction."""
+
         enc_o = HipEncoder(dims, device=device, precision=args.precision, chunk_rows=args.chunk_rows or None)
-        enc_o.load_state_dict(state_o)
+        enc_o.load_state_dict(make_state(dims, init, weights), calibrate=calibrate)
         policy_o = enc_o.effective_policy()
 
         def step_o(two: bool):
@@ -668,12 +701,13 @@ def main() -> None:
         enc_o.profile_enable(False)
         dom_o = max(prof_o.items(), key=lambda kv: kv[1]["total_ms"])[0]
         out_o = enc_o.forward_packed(ids, cu, cu_np, max_len)
-        require_finite(f"the {other}-checkpoint sub-record", out_o[0], out_o[1])
+        require_finite(what, out_o[0], out_o[1])
         clock_o = probed_pass(enc_o, lambda: step_o(True), args.steps, dt_two, lambda: torch.cuda.synchronize(device))
         sub = {"value": n_pairs_rank / dt_two, "unit": "pairs/s", "ms_per_step": dt_two * 1e3, "steps": args.steps,
-               "one_pipeline": n_pairs_rank / dt_one, "checkpoint_dtype": other, "policy": policy_o,
+               "one_pipeline": n_pairs_rank / dt_one, "weights_init": init, "checkpoint_dtype": weights, "policy": policy_o,
+               "calibration": enc_o.calibration,
                "dtype": arithmetic_label(policy_o), "shader_clock_ghz": clock_o["value"],
-               "output_checksum": output_checksum(out_o[0], out_o[1], wl_key + other if args.precision == "bf16x3" else None),
+               "output_checksum": output_checksum(out_o[0], out_o[1], checksum_key(args.model, wl_shape, init, weights) if args.precision == "bf16x3" else None),
                "whole_forward_frac": n_pairs_rank / dt_two * flops_pair / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in prof_o.items()}}
         if dom_o in flops_per_forward:
@@ -681,8 +715,20 @@ def main() -> None:
             sub["roofline"] = {"kernel": dom_o, "avg_launch_ms": prof_o[dom_o]["avg_ms"], "avg_launch_ms_source": "event_bracketed",
                                "shader_clock_ghz": clock_o["value"],
                                "frac": flops_per_forward[dom_o] / lpf / (prof_o[dom_o]["avg_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
-        line[f"{other}_checkpoint"] = sub
         enc_o.close()
+        return sub
+
+    if world == 1 and not args.varlen and not args.no_other_dtype:
+        # the same workload with the OTHER checkpoint dtype, timed by the same command (sub-record, not the headline)
+        other = "bf16" if args.weights == "fp32" else "fp32"
+        line[f"{other}_checkpoint"] = sub_record(args.init, other, f"the {other}-checkpoint sub-record")
+    if world == 1 and not args.varlen and args.init != "o1" and not args.no_worst_case:
+        # The worst case for an operand format: every GEMM weight of O(1) magnitude (`value` of rounds 1-4).  No checkpoint of
+        # the reference looks like this (its initialisation and its trained weights are ~0.02) -- on such weights every dropped
+        # correction term costs >= 7e-3 on a logit, the calibration keeps the all-terms kernel sets, and this is their price.
+        line["worst_case_o1_weights"] = {w: sub_record("o1", w, f"the O(1)-weights sub-record ({w} checkpoint)") for w in ("fp32", "bf16")}
+        line["worst_case_o1_weights"]["what"] = ("the same batch on synthetic weights of O(1) magnitude (synthetic.synth_state_dict; `value` of rounds 1-4): "
+                                                 "op_calibrate finds no cheaper kernel set within 1e-4 there and the all-terms sets run")
     if world == 1 and not args.varlen and args.model == "xsmall" and not args.no_base:
         # the panel path (base dims: hidden 512, 19 layers) on the same batch, both checkpoint dtypes (sub-record; the
         # full record of that model is `bench.py --model base`)
@@ -692,8 +738,7 @@ def main() -> None:
         ids_b, cu_b = torch.from_numpy(ids_b_np).to(device), torch.from_numpy(cu_b_np).to(device)
         flops_b = algorithmic_flops_per_pair(dims_b, args.seq_len)
         base_steps = max(5, args.steps // 10)
-        sub_b = {"unit": "pairs/s", "model": "base", "steps": base_steps, "algorithmic_gflop_per_pair": flops_b / 1e9}
-        from open_provence_amd import _lib as _oplib
+        sub_b = {"unit": "pairs/s", "model": "base", "steps": base_steps, "algorithmic_gflop_per_pair": flops_b / 1e9, "weights_init": args.init}
 
         def timed_base(enc_b):
             for _ in range(2):
@@ -705,38 +750,40 @@ def main() -> None:
             torch.cuda.synchronize(device)
             return (time.perf_counter() - t1) / base_steps
 
-        for wdt in ("fp32", "bf16"):
-            state_b = synth_state_dict(dims_b, seed=7)
-            if wdt == "bf16":
-                state_b = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state_b.items()}
+        def base_record(state_b, wdt: str, tol, kernel_set=None, profile_it=True) -> dict:
             enc_b = HipEncoder(dims_b, device=device, precision=args.precision)
-            enc_b.load_state_dict(state_b)
+            enc_b.load_state_dict(state_b, calibrate=tol, kernel_set=kernel_set)
             dt_b = timed_base(enc_b)
             out_b = enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
             require_finite(f"the base-model sub-record ({wdt} checkpoint)", out_b[0], out_b[1])
-            clock_b = probed_pass(enc_b, lambda: enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b), base_steps, dt_b,
-                                  lambda: torch.cuda.synchronize(device))
-            enc_b.profile_enable(True)
-            enc_b.profile_reset()
-            for _ in range(2):
-                enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
-            prof_b = enc_b.profile_read()
-            enc_b.profile_enable(False)
-            rec = {"value": args.pairs / dt_b, "ms_per_step": dt_b * 1e3, "kernel_set": enc_b.effective_policy()["kernel_set"],
-                   "dtype": arithmetic_label(enc_b.effective_policy()), "shader_clock_ghz": clock_b["value"],
-                   "output_checksum": output_checksum(out_b[0], out_b[1], f"base|{args.pairs}x{args.seq_len}|{wdt}" if args.precision == "bf16x3" else None),
-                   "whole_forward_frac": args.pairs / dt_b * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                   "kernel_ms_per_forward": {k: v["total_ms"] / 2 for k, v in prof_b.items()}}
+            pol_b = enc_b.effective_policy()
+            rec = {"value": args.pairs / dt_b, "ms_per_step": dt_b * 1e3, "kernel_set": pol_b["kernel_set"], "dtype": arithmetic_label(pol_b),
+                   "calibration": enc_b.calibration,
+                   "whole_forward_frac": args.pairs / dt_b * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+            if profile_it:
+                rec["shader_clock_ghz"] = probed_pass(enc_b, lambda: enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b), base_steps, dt_b,
+                                                      lambda: torch.cuda.synchronize(device))["value"]
+                enc_b.profile_enable(True)
+                enc_b.profile_reset()
+                for _ in range(2):
+                    enc_b.forward_packed(ids_b, cu_b, cu_b_np, max_b)
+                prof_b = enc_b.profile_read()
+                enc_b.profile_enable(False)
+                rec["kernel_ms_per_forward"] = {k: v["total_ms"] / 2 for k, v in prof_b.items()}
+                rec["output_checksum"] = output_checksum(out_b[0], out_b[1], checksum_key("base", f"{args.pairs}x{args.seq_len}", args.init, wdt)
+                                                         if (args.precision == "bf16x3" and kernel_set is None and tol is calibrate) else None)
             enc_b.close()
-            # the opt-in fp16 + e4m3 kernel sets of this path (OP_FLAG_PANEL_F8; off by default for their error at this depth)
-            enc_f = HipEncoder(dims_b, device=device, precision=args.precision, flags=_oplib.OP_FLAG_PANEL_F8)
-            enc_f.load_state_dict(state_b)
+            return rec
+
+        for wdt in ("fp32", "bf16"):
+            state_b = make_state(dims_b, args.init, wdt)
+            rec = base_record(state_b, wdt, calibrate)  # the product's default: calibrated at 1e-4
+            # beside it: what op_weights_ready selects without calibration, and the single-pass fp16 set -- which a tolerance
+            # of 2e-4 (still 5 x inside the path's 1e-3) selects at this depth (19 layers: 1.6e-4 to the (hi, lo) bf16 kernels)
+            rec["uncalibrated"] = base_record(state_b, wdt, False, profile_it=False)
+            if args.init == "refinit":
+                rec["calibrate_2e-4"] = base_record(state_b, wdt, 2e-4, profile_it=False)
             del state_b
-            dt_f = timed_base(enc_f)
-            out_f = enc_f.forward_packed(ids_b, cu_b, cu_b_np, max_b)
-            require_finite(f"the base-model opt-in fp16 + e4m3 sub-record ({wdt} checkpoint)", out_f[0], out_f[1])
-            rec["opt_in_panel_f8"] = {"value": args.pairs / dt_f, "ms_per_step": dt_f * 1e3, "kernel_set": enc_f.effective_policy()["kernel_set"]}
-            enc_f.close()
             sub_b[f"{wdt}_checkpoint"] = rec
         line["base_model"] = sub_b
     if world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 5 /* 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
+#define OP_ABI_VERSION 6 /* 6: op_select_kernel_set, op_calibrate, kernel set 7 ("f16": single-pass fp16 operands); 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
@@ -153,12 +153,67 @@ size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int 
  * of 0 in that format with the weights' lo part as a second e4m3 plane -- 2 units instead of 3 and
  * one kernel per layer instead of two), or -1 when the policy runs on the all-terms kernels with
  * cleared lo operands (same numerics, no speed-up); 5 / 6 = sets 0 / 1 on the panel path with the Wi GEMM alone in the
- * format of sets 4 / 3 (OP_FLAG_PANEL_F8_WI).  Sets 3 / 4 replace 1 / 0 for hidden <= 256
+ * format of sets 4 / 3 (OP_FLAG_PANEL_F8_WI); 7 = "f16", single-pass fp16 operands (only ever chosen by op_calibrate /
+ * op_select_kernel_set: then terms_out holds that set's masks, not the checkpoint's).  Sets 3 / 4 replace 1 / 0 for hidden <= 256
  * (hidden 512 / 768: with OP_FLAG_PANEL_F8) unless OP_FLAG_NO_F8 is set, set 3 needs every GEMM
  * weight to be exactly an fp16 value, and neither is taken for a checkpoint with a weight TENSOR
  * scaled into fp16's subnormal range (checked at load time).  Their fp16 operand plane has fp16's
  * range: an MLP activation beyond it turns the outputs into NaN (on purpose: not clamped). */
 int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set);
+
+/* Kernel sets (the numbering of op_effective_policy).  MFMA pipe time per algorithmic product in 16-bit units:
+ * BF16X3 3, BF16X3_WI_F8 ~2.5 (panel path), F16_F8_W 2, BF16_WEIGHTS 2, BF16_WEIGHTS_WI_F8 ~1.75, F16_F8 1.5, BF16 1,
+ * F16 1.  F16 (round 5) = the kernels and layouts of BF16 with every operand carried as fp16 (11 significant bits
+ * instead of 8; fp16's range: an activation beyond 65504 turns the outputs into NaN, as on sets 3 / 4). */
+enum op_kernel_set {
+  OP_KS_AUTO = -1, /* op_select_kernel_set: back to the default selection of op_weights_ready */
+  OP_KS_BF16X3 = 0,
+  OP_KS_BF16_WEIGHTS = 1,
+  OP_KS_BF16 = 2,
+  OP_KS_F16_F8 = 3,
+  OP_KS_F16_F8_W = 4,
+  OP_KS_BF16X3_WI_F8 = 5,
+  OP_KS_BF16_WEIGHTS_WI_F8 = 6,
+  OP_KS_F16 = 7,
+  OP_KS_COUNT = 8
+};
+
+/* Pin the kernel set the forward runs on (OP_KS_AUTO: un-pin).  A set with fewer product terms than the loaded
+ * checkpoint carries (e.g. OP_KS_F16 on any checkpoint, OP_KS_F16_F8 on fp32-valued weights) is an APPROXIMATION of the
+ * requested policy: op_calibrate is the call that measures it first.  OP_ERR_UNSUPPORTED when the handle cannot run the
+ * set (shape without those kernels, packs not built because of OP_FLAG_NO_F8, a weight tensor below fp16's reach).
+ * Replaces: the reference choosing its arithmetic from the device and what loads (standalone.py:219-244, 1589-1615). */
+int op_select_kernel_set(op_handle* h, int kernel_set);
+
+/* Choose the arithmetic from the checkpoint that is loaded.  The default selection of op_weights_ready is safe for ANY
+ * weights (it only drops terms that are identically zero) -- and therefore priced for the worst case: weights of O(1)
+ * scale, where every dropped term costs >= 7e-3 on a logit.  A trained checkpoint's weights are ~0.02: there most of
+ * the correction terms are below the parity bar by orders of magnitude.  op_calibrate runs one batch (ids_host /
+ * cu_seqlens_host / n_seqs: the caller's sample of real inputs; NULL / NULL / 0: 24 rows x min(512, max positions) + 8
+ * ragged rows of uniform token ids) through the (hi, lo) bf16 realisation of the requested policy (`reference_set`) and
+ * through every available kernel set CHEAPER than the default one, cheapest first, and keeps the first whose
+ * max |logit difference| (pruning and ranking logits) to the reference outputs is <= tolerance and finite; if none is,
+ * the default selection stays (unless its own outputs on that batch are not finite: then the reference set runs).  The north_star bar against the fp32 CPU reference is 1e-3; 1e-4 is the tolerance the
+ * Python layer uses.  Synchronous (load-time call; its temporary device buffers are freed before it returns).
+ * Replaces: standalone.py:219-244 / 1589-1615 / 1631-1642 (dtype and attention implementation chosen per device and
+ * checkpoint, with a retry) -- the reference decides its arithmetic at load time too. */
+typedef struct op_calibration {
+  uint32_t struct_bytes; /* = sizeof(op_calibration), checked when a report is requested */
+  float tolerance;
+  int32_t reference_set; /* the (hi, lo) bf16 kernel set the candidates were compared with */
+  int32_t default_set;   /* what op_weights_ready selects for this checkpoint */
+  int32_t chosen_set;    /* what the forward runs on from now on */
+  int32_t n_candidates;
+  int32_t candidate_set[8];
+  float candidate_err[8]; /* max |difference| to the reference outputs; +inf: non-finite outputs */
+  int32_t n_rows, n_tokens; /* the calibration batch */
+  float default_err;        /* the default set's own difference to the reference outputs on that batch.  It is not held to
+                             * the tolerance (it is the set the parity tests stand on), but when it is NOT FINITE -- an
+                             * activation beyond fp16's range on sets 3 - 6 -- and no candidate passes, the reference set is
+                             * chosen right away instead of at the first forward that overflows */
+} op_calibration;
+int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const int32_t* cu_seqlens_host, int n_seqs,
+                 op_calibration* report);
 
 /* Run-time switch between the fp16 + e4m3 kernel sets (3 / 4) and the (hi, lo) bf16 sets (1 / 0) they replace: both
  * weight packs of a handle stay resident, so this only re-runs the selection of op_weights_ready (with enabled = 0 as if
@@ -166,7 +221,8 @@ int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set);
  * activation beyond fp16's range -- and repeats that forward, so that process() returns what the reference returns
  * instead of raising.  Replaces: nothing; precedent for a silent, correct retry: the reference's own fallback from an
  * unsupported dtype / attention implementation at load time (standalone.py:1631-1642).  Returns OP_OK; *changed (may
- * be NULL) = 1 when the evaluated kernel set is different afterwards.  The workspace size may change: query
+ * be NULL) = 1 when the evaluated kernel set is different afterwards (sets 5 / 6 and a pinned / calibrated set count:
+ * enabled = 0 also drops a set chosen by op_select_kernel_set / op_calibrate).  The workspace size may change: query
  * op_workspace_bytes again. */
 int op_set_compact_operands(op_handle* h, int enabled, int* changed);
 

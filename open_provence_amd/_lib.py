@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 
 OP_MAX_LAYERS = 128
-OP_ABI_VERSION = 5
+OP_ABI_VERSION = 6
 
 OP_OK = 0
 OP_DTYPE_F32, OP_DTYPE_BF16, OP_DTYPE_F16 = 0, 1, 2
@@ -30,6 +30,13 @@ OP_FLAG_ATTN_XCD_GROUP = 1024
 OP_FLAG_PANEL_F8 = 2048
 OP_FLAG_PANEL_F8_WI = 4096
 OP_POOL_CLS, OP_POOL_MEAN = 0, 1
+# enum op_kernel_set (op_effective_policy / op_select_kernel_set / op_calibrate)
+OP_KS_AUTO = -1
+KERNEL_SET_NAMES = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", 4: "f16-f8-w", 5: "bf16x3+wi-f16-f8-w",
+                    6: "bf16-weights+wi-f16-f8", 7: "f16", -1: "all-terms kernels, cleared lo operands"}
+KERNEL_SET_IDS = {name: number for number, name in KERNEL_SET_NAMES.items() if number >= 0}
+# kernel sets with an fp16 operand plane: an activation beyond fp16's range comes out as NaN (range guard in engine.py)
+FP16_PLANE_SETS = ("f16-f8", "f16-f8-w", "bf16x3+wi-f16-f8-w", "bf16-weights+wi-f16-f8", "f16")
 
 LIB_NAME = "libopenprovence_hip.so"
 
@@ -41,6 +48,8 @@ EXPORTED_SYMBOLS = (
     "op_weights_ready",
     "op_effective_policy",
     "op_set_compact_operands",
+    "op_select_kernel_set",
+    "op_calibrate",
     "op_workspace_bytes",
     "op_forward_packed",
     "op_segment_means",
@@ -82,6 +91,22 @@ class OpConfig(ctypes.Structure):
         ("terms", ctypes.c_uint8 * 8),
         ("flags", ctypes.c_uint32),
         ("prune_pre_final_norm", ctypes.c_int32),
+    ]
+
+
+class OpCalibration(ctypes.Structure):
+    _fields_ = [
+        ("struct_bytes", ctypes.c_uint32),
+        ("tolerance", ctypes.c_float),
+        ("reference_set", ctypes.c_int32),
+        ("default_set", ctypes.c_int32),
+        ("chosen_set", ctypes.c_int32),
+        ("n_candidates", ctypes.c_int32),
+        ("candidate_set", ctypes.c_int32 * 8),
+        ("candidate_err", ctypes.c_float * 8),
+        ("n_rows", ctypes.c_int32),
+        ("n_tokens", ctypes.c_int32),
+        ("default_err", ctypes.c_float),
     ]
 
 
@@ -134,6 +159,11 @@ def load_library() -> ctypes.CDLL:
     if hasattr(lib, "op_set_compact_operands"):  # (absent only in an older library loaded for a same-box A/B, see below)
         lib.op_set_compact_operands.restype = ci
         lib.op_set_compact_operands.argtypes = [vp, ci, ctypes.POINTER(ci)]
+    if hasattr(lib, "op_select_kernel_set"):
+        lib.op_select_kernel_set.restype = ci
+        lib.op_select_kernel_set.argtypes = [vp, ci]
+        lib.op_calibrate.restype = ci
+        lib.op_calibrate.argtypes = [vp, ctypes.c_float, vp, vp, ci, ctypes.POINTER(OpCalibration)]
     lib.op_segment_means.restype = ci
     lib.op_segment_means.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     lib.op_debug_capture_hidden.restype = ci

@@ -33,6 +33,7 @@ UNITS = [
     ("op_launch_row3", CSRC / "op_launch_row.hip", ["-DOPL_ROW_PART=3"], _INTERNAL),
     ("op_launch_row4", CSRC / "op_launch_row.hip", ["-DOPL_ROW_PART=4"], _INTERNAL),
     ("op_launch_row5", CSRC / "op_launch_row.hip", ["-DOPL_ROW_PART=5"], _INTERNAL),
+    ("op_launch_row6", CSRC / "op_launch_row.hip", ["-DOPL_ROW_PART=6"], _INTERNAL),
     ("op_launch_layer32", CSRC / "op_launch_layer32.hip", [], _INTERNAL),
     ("op_launch_attn", CSRC / "op_launch_attn.hip", [], _INTERNAL),
     ("op_launch_panel", CSRC / "op_launch_panel.hip", [], _INTERNAL),

@@ -77,6 +77,8 @@ struct LayerWeights {
   // the same kernel sets on the panel path: per weight fp16 slabs + e4m3 slabs (w, then lo(w)) (pack_panel_f8_kernel)
   u16 *wqkv_p16 = nullptr, *wqkv_p8 = nullptr, *wo_p16 = nullptr, *wo_p8 = nullptr, *wi_p16 = nullptr, *wi_p8 = nullptr,
       *wo2_p16 = nullptr, *wo2_p8 = nullptr;
+  // kernel set "f16" (single-pass fp16 operands): the layouts of wqkv_pk / wi_pk / wo2_pk / wo_ks with fp16 values in the hi plane
+  u16 *wqkv_h16 = nullptr, *wi_h16 = nullptr, *wo2_h16 = nullptr, *wo_h16 = nullptr;
 };
 
 struct ProfileEvent {
@@ -99,6 +101,10 @@ struct op_handle {
                                    // [OP_FAM_COUNT]: some GEMM weight is not exactly an fp16 value (no "f16 + fp8" set)
   bool f8_packs = false;           // the "f16 + fp8" weight packs exist (row path, hidden a multiple of 128)
   bool f8_off = false;             // op_set_compact_operands(h, 0): keep the (hi, lo) bf16 sets although the packs exist
+  bool h16_packs = false;          // the fp16 single-plane weight packs of kernel set "f16" exist
+  int forced_set = -1;             // op_select_kernel_set / op_calibrate: run this kernel set (op_kernel_set numbering), -1 = the default selection
+  int default_set = 0;             // the kernel set the default selection gives for this checkpoint (valid once resolved)
+  bool f16_unfit = false;          // some weight TENSOR sits on fp16's subnormal grid: no kernel set with an fp16 weight plane
   bool wi_f8 = false;              // panel path, OP_FLAG_PANEL_F8_WI: the Wi GEMM (and its LayerNorm) in the fp16 + e4m3 format
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
@@ -338,6 +344,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
 
   // rows >= `rows` are never produced by the attention kernel: keep its output finite there
   const bool o_f8 = (h->pi == opl::PI_F16_F8 || h->pi == opl::PI_F16_F8_W) && !h->emulate;  // o = fp16 pieces (ws.o_hi) + e4m3 pieces (ws.o_lo)
+  const bool f16 = h->pi == opl::PI_F16 && !h->emulate;  // kernel set "f16": set 2's layouts, fp16 values, the fp16 weight packs
   if (fp_layout && o_f8) {
     const size_t n16 = (size_t)((r_pad - rows) / 16);
     if (n16) OP_HIP(h, hipMemsetAsync(ws.o_hi + (size_t)(rows / 16) * (H / 32) * 512, 0, n16 * (H / 32) * 512 * sizeof(u16), st));
@@ -464,7 +471,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     rp.max_pos = h->max_pos;
     rp.x_in = ws.x;
     rp.ln_w = lw.attn_norm;
-    rp.wp = lw.wqkv_pk;
+    rp.wp = f16 ? lw.wqkv_h16 : lw.wqkv_pk;
     rp.n_chunks = 3 * H / ROW_CHUNK;
     rp.n_swapped = 2 * H / ROW_CHUNK;
     rp.o0_hi = ws.q_hi;
@@ -544,12 +551,12 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         }
         RowGemmParams rl = qkv_params(with_qkv ? li + 1 : li);
         rl.a1_fp = ws.o_hi;
-        rl.w1p = lw.wo_ks;
+        rl.w1p = f16 ? lw.wo_h16 : lw.wo_ks;
         rl.k1_steps = H / 32;
         rl.x_io = ws.x;
         rl.ln_w_mlp = lw.mlp_norm;
-        rl.wi_pk = lw.wi_pk;
-        rl.wo2_ks = lw.wo2_pk;
+        rl.wi_pk = f16 ? lw.wi_h16 : lw.wi_pk;
+        rl.wo2_ks = f16 ? lw.wo2_h16 : lw.wo2_pk;
         rl.n_pairs = I / 32;
         if (o_f8) {  // the "f16 + fp8" packs of the same weights
           rl.a1_lo8 = ws.o_lo;
@@ -643,6 +650,9 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         if (with_lo)
           hipLaunchKernelGGL((ln_fp_kernel<true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
                              w ? 1 : 0, ws.ln_hi);
+        else if (f16)
+          hipLaunchKernelGGL((ln_fp_kernel<false, true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                             w ? 1 : 0, ws.ln_hi);
         else
           hipLaunchKernelGGL((ln_fp_kernel<false>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
                              w ? 1 : 0, ws.ln_hi);
@@ -677,7 +687,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       pp.a_fp = ws.ln_hi;
       pp.a_lo8 = ws.ln_lo;
       pp.n_ksteps = H / 32;
-      pp.wp = pf8 ? lw.wqkv_p16 : lw.wqkv_pk;
+      pp.wp = pf8 ? lw.wqkv_p16 : (f16 ? lw.wqkv_h16 : lw.wqkv_pk);
       pp.wp8 = lw.wqkv_p8;
       pp.w8_lo_off = (size_t)3 * H * H / 2;  // u16 elements: the tensor's e4m3(w) slabs, then those of lo(w)
       pp.o0 = ws.q_hi;
@@ -688,7 +698,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         OP_TRY(panel(PK_GEMM_QKV_ROPE, 102, pp, 3 * H / 256));
       } else {
         OP_TRY(panel(PK_GEMM_QK_ROPE, PE_QK, pp, 2 * H / 256));
-        pp.wp = lw.wqkv_pk + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
+        pp.wp = (f16 ? lw.wqkv_h16 : lw.wqkv_pk) + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
         pp.o0 = ws.vt_hi;
         OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
       }
@@ -696,7 +706,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       OP_TRY(attention(is_global));
       pp.a_fp = ws.o_hi;
       pp.a_lo8 = ws.o_lo;
-      pp.wp = pf8 ? lw.wo_p16 : lw.wo_ks;
+      pp.wp = pf8 ? lw.wo_p16 : (f16 ? lw.wo_h16 : lw.wo_ks);
       pp.wp8 = lw.wo_p8;
       pp.w8_lo_off = (size_t)H * H / 2;
       pp.x = ws.x;
@@ -706,7 +716,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp && !wi8, wi8));
       pp.a_fp = ws.ln_hi;
       pp.a_lo8 = ws.ln_lo;
-      pp.wp = (pf8 || wi8) ? lw.wi_p16 : lw.wi_pk;
+      pp.wp = (pf8 || wi8) ? lw.wi_p16 : (f16 ? lw.wi_h16 : lw.wi_pk);
       pp.wp8 = lw.wi_p8;
       pp.w8_lo_off = (size_t)2 * I * H / 2;
       pp.o0 = ws.h_hi;
@@ -717,7 +727,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       pp.a_fp = ws.h_hi;
       pp.a_lo8 = ws.h_lo;
       pp.n_ksteps = I / 32;
-      pp.wp = pf8 ? lw.wo2_p16 : lw.wo2_pk;
+      pp.wp = pf8 ? lw.wo2_p16 : (f16 ? lw.wo2_h16 : lw.wo2_pk);
       pp.wp8 = lw.wo2_p8;
       pp.w8_lo_off = (size_t)H * I / 2;
       pp.ld_out = H;
@@ -947,6 +957,10 @@ int op_create(const op_config* cfg, op_handle** out) {
   // (panel path: the packs are always built -- the Wi GEMM takes the format by default for fp32-valued weights, see
   // resolve_policy; OP_FLAG_PANEL_F8 extends it to every GEMM of the layer)
   h->f8_packs = ((h->row_path && (H / 32) % 4 == 0) || h->panel_path) && !(cfg->flags & OP_FLAG_NO_F8);
+  // kernel set "f16": whole-layer kernel shapes (hidden 128 / 256) or the panel path; never with the A/B flags that pick
+  // another layer structure
+  h->h16_packs = ((h->row_path && (H == 128 || H == 256)) || h->panel_path) &&
+                 !(cfg->flags & (OP_FLAG_NO_F8 | OP_FLAG_NO_LAYER_FUSION | OP_FLAG_NO_POLICY_KERNELS));
   OP_CREATE_TRY(dev_alloc(h, &h->emb, (size_t)h->V * H));
   OP_CREATE_TRY(dev_alloc(h, &h->emb_norm, H));
   OP_CREATE_TRY(dev_alloc(h, &h->final_norm, H));
@@ -981,6 +995,12 @@ int op_create(const op_config* cfg, op_handle** out) {
       OP_CREATE_TRY(dev_alloc(h, &lw.wi_pk, (size_t)2 * 2 * I * H));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pk, (size_t)2 * H * I));
       OP_CREATE_TRY(dev_alloc(h, &lw.wo_ks, 2 * HH));
+      if (h->h16_packs) {
+        OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_h16, 2 * 3 * HH));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wi_h16, (size_t)2 * 2 * I * H));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo2_h16, (size_t)2 * H * I));
+        OP_CREATE_TRY(dev_alloc(h, &lw.wo_h16, 2 * HH));
+      }
       if (h->f8_packs && h->panel_path) {  // 4 bytes per weight element: fp16 + e4m3(w) + e4m3(lo(w))
         OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_p16, 3 * HH));
         OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_p8, 3 * HH));
@@ -1051,6 +1071,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   u16* dst_p32 = nullptr; // additional packing for the 32x32x16 whole-layer kernel
   u16 *dst_f8a = nullptr, *dst_f8b = nullptr;  // "f16 + fp8" packs: chunked (a) or k-streamed fp16 (a) + e4m3 (b)
   u16 *dst_p16 = nullptr, *dst_p8 = nullptr;   // ... on the panel path: fp16 slabs + e4m3 slabs
+  u16 *dst_pk_h16 = nullptr, *dst_ks_h16 = nullptr;  // kernel set "f16": the layouts of dst_pk / dst_ks with fp16 values
   int p32_mode = 0, p32_kmajor = 0;
   int pk_mode = -1;
   int family = -1;        // op_gemm_family of a GEMM weight
@@ -1098,24 +1119,28 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
       dst_p32 = lw.wqkv_p32; p32_mode = L32_QKV; p32_kmajor = 0;
       dst_f8a = lw.wqkv_f8;
       dst_p16 = lw.wqkv_p16; dst_p8 = lw.wqkv_p8;
+      dst_pk_h16 = lw.wqkv_h16;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
       dst_pk = nullptr; pk_mode = 101; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
       dst_p32 = lw.wo_p32; p32_mode = L32_RESID; p32_kmajor = 1;
       dst_f8a = lw.wo_f16; dst_f8b = lw.wo_f8;
       dst_p16 = lw.wo_p16; dst_p8 = lw.wo_p8;
+      dst_ks_h16 = lw.wo_h16;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
       dst_pk = lw.wi_pk; pk_mode = RE_GEGLU; family = OP_FAM_WI;
       dst_p32 = lw.wi_p32; p32_mode = L32_GEGLU; p32_kmajor = 0;
       dst_f8a = lw.wi_f8;
       dst_p16 = lw.wi_p16; dst_p8 = lw.wi_p8;
+      dst_pk_h16 = lw.wi_h16;
     } else if (t == "mlp.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo2_hi; dst_lo = lw.wo2_lo; expect(H, I);
       dst_pk = lw.wo2_pk; pk_mode = 100; family = OP_FAM_MLP_OUT;  // k-streamed
       dst_p32 = lw.wo2_p32; p32_mode = L32_RESID; p32_kmajor = 1;
       dst_f8a = lw.wo2_f16;
       dst_p16 = lw.wo2_p16; dst_p8 = lw.wo2_p8;
+      dst_pk_h16 = lw.wo2_h16;
     } else {
       return fail(h, OP_ERR_INVALID, "op_load_weight: unknown tensor name '%s'", name_c);
     }
@@ -1203,6 +1228,23 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     } else {
       pack(H / 256, PE_RESIDUAL, dst_pk);  // MLP output projection
     }
+    if (dst_pk_h16 || dst_ks_h16) {  // kernel set "f16": the same panels with fp16 values
+      auto pack16 = [&](int n_tiles, int mode, u16* dst) {
+        const size_t total = (size_t)n_tiles * 256 * K;
+        hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, f32, n_tiles, K, mode,
+                           H, I, dst, 1, any_lo, 1);
+      };
+      if (pk_mode == RE_QKV) {
+        pack16(2 * H / 256, PE_QK, dst_pk_h16);
+        pack16(H / 256, PE_V, dst_pk_h16 + (size_t)(2 * H / 256) * (K / 32) * 2 * 8192);
+      } else if (pk_mode == 101) {
+        pack16(H / 256, PE_RESIDUAL, dst_ks_h16);
+      } else if (pk_mode == RE_GEGLU) {
+        pack16(I / 128, PE_GEGLU, dst_pk_h16);
+      } else {
+        pack16(H / 256, PE_RESIDUAL, dst_pk_h16);
+      }
+    }
   }
   if ((dst_pk || dst_ks) && h->row_path) {
     if (dst_pk && pk_mode == 100)
@@ -1212,6 +1254,13 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
                          zero_lo, any_lo);
     if (dst_ks)
       hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_ks, zero_lo, any_lo);
+    // kernel set "f16": the same layouts with fp16 values in the hi plane
+    if (dst_pk_h16 && pk_mode == 100)
+      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_pk_h16, 1, any_lo, 1);
+    else if (dst_pk_h16)
+      hipLaunchKernelGGL(pack_rowgemm_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, pk_mode, H, I, dst_pk_h16, 1, any_lo, 1);
+    if (dst_ks_h16)
+      hipLaunchKernelGGL(pack_kstream_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, 1, dst_ks_h16, 1, any_lo, 1);
     if (dst_f8a) {  // "f16 + fp8" kernel set; raises the not-fp16 flag (any_lo_dev[OP_FAM_COUNT]) for a weight it cannot hold exactly
       int* not_f16 = h->any_lo_dev + OP_FAM_COUNT;
       if (pk_mode == 100 || pk_mode == 101)
@@ -1237,6 +1286,41 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
 }  // extern "C"
 
 namespace {
+// op_kernel_set number of the handle's current selection (op_effective_policy)
+int public_set(const op_handle* h) {
+  if (h->emulate) return -1;
+  if (h->pi == opl::PI_F16) return OP_KS_F16;
+  return h->wi_f8 ? 5 + h->pi : h->pi;  // 5 / 6: sets 0 / 1 with the Wi GEMM in the fp16 + e4m3 format
+}
+
+// Can this handle run kernel set `set` (op_kernel_set numbering)?  Packs present, a path that has the kernels, and no
+// weight tensor below the reach of an fp16 plane for the sets that carry one.
+bool set_available(const op_handle* h, int set) {
+  const bool fast_path = h->row_path || h->panel_path;
+  const bool row_layer_ok = !h->row_path || !(h->cfg.flags & (OP_FLAG_NO_LAYER_FUSION | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32));
+  if (h->cfg.flags & OP_FLAG_NO_POLICY_KERNELS) return set == OP_KS_BF16X3;
+  switch (set) {
+    case OP_KS_BF16X3: return true;
+    case OP_KS_BF16_WEIGHTS:
+    case OP_KS_BF16: return fast_path;
+    case OP_KS_F16_F8:
+    case OP_KS_F16_F8_W: return fast_path && h->f8_packs && !h->f16_unfit && row_layer_ok;
+    case OP_KS_BF16X3_WI_F8:
+    case OP_KS_BF16_WEIGHTS_WI_F8: return h->panel_path && h->f8_packs && !h->f16_unfit;
+    case OP_KS_F16: return h->h16_packs && !h->f16_unfit && row_layer_ok;
+    default: return false;
+  }
+}
+
+// Run kernel set `set`: the evaluated terms become the set's own (a set with fewer terms than the checkpoint carries is
+// an approximation -- op_calibrate measures it before choosing it).
+void apply_set(op_handle* h, int set) {
+  h->wi_f8 = set == OP_KS_BF16X3_WI_F8 || set == OP_KS_BF16_WEIGHTS_WI_F8;
+  h->pi = set == OP_KS_F16 ? opl::PI_F16 : (h->wi_f8 ? set - 5 : set);
+  h->eff = opl::kPolicies[h->pi];
+  h->emulate = false;
+}
+
 // Evaluated policy = requested policy minus the hi x lo(weight) terms whose lo planes are identically zero for this
 // checkpoint (bf16 weights: dropping the term changes no bit of the result), then the curated kernel set that has
 // exactly those terms -- or kernel set 0 with the unused lo operands cleared.
@@ -1286,8 +1370,52 @@ int resolve_policy(op_handle* h) {
   } else if (opl::kPolicies[0] == e) {
     h->emulate = false;
   }
+  h->f16_unfit = any_lo[OP_FAM_COUNT + 2] != 0;
+  h->default_set = public_set(h);
+  // a kernel set pinned by op_select_kernel_set / chosen by op_calibrate replaces the default selection
+  if (h->forced_set >= 0 && set_available(h, h->forced_set)) apply_set(h, h->forced_set);
   h->resolved = true;
   return OP_OK;
+}
+
+// ---- calibration: the cheapest kernel set whose outputs stay within `tolerance` of the (hi, lo) bf16 kernels' ----------
+// MFMA pipe time per algorithmic product of each kernel set, in 16-bit units (the panel path's sets 4
+// and 5 measured in that order on base: 5.15 k vs 4.80 k pairs/s).  Candidates are tried in this order.
+float set_cost(const op_handle* h, int set) {
+  switch (set) {
+    case OP_KS_F16: return 1.0f;
+    case OP_KS_BF16: return 1.01f;  // same MFMA count as "f16", 8 instead of 11 significant bits: tried second
+    case OP_KS_F16_F8: return 1.5f;
+    case OP_KS_BF16_WEIGHTS_WI_F8: return 1.75f;
+    case OP_KS_BF16_WEIGHTS: return 2.0f;
+    case OP_KS_F16_F8_W: return h->panel_path ? 2.1f : 1.99f;
+    case OP_KS_BF16X3_WI_F8: return 2.5f;
+    default: return 3.0f;
+  }
+}
+
+// deterministic calibration batch: 24 rows of min(512, max_pos) tokens + 8 ragged rows, ids uniform over the vocabulary
+// (specials avoided as bench.py does: [1000, V - 1000) when the vocabulary is that large)
+void synthetic_calibration_rows(const op_handle* h, std::vector<int32_t>& ids, std::vector<int32_t>& cu) {
+  const int full = std::min(512, h->max_pos);
+  const int ragged[8] = {1, 17, 64, 130, 257, 333, 511, 96};
+  std::vector<int> lens(24, full);
+  for (int r : ragged) lens.push_back(std::min(r, h->max_pos));
+  const int lo = h->V > 4000 ? 1000 : 0, span = h->V > 4000 ? h->V - 2000 : h->V;
+  uint64_t state = 0x9E3779B97F4A7C15ull;
+  cu.assign(1, 0);
+  ids.clear();
+  for (int len : lens) {
+    for (int i = 0; i < len; ++i) {
+      state += 0x9E3779B97F4A7C15ull;  // splitmix64
+      uint64_t z = state;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      ids.push_back(lo + (int32_t)(z % (uint64_t)span));
+    }
+    cu.push_back((int32_t)ids.size());
+  }
 }
 }  // namespace
 
@@ -1313,12 +1441,167 @@ int op_set_compact_operands(op_handle* h, int enabled, int* changed) {
   if (!h) return fail(nullptr, OP_ERR_INVALID, "op_set_compact_operands: NULL handle");
   int rc = op_weights_ready(h);
   if (rc != OP_OK) return rc;
-  const int before = h->pi;
+  const int before = public_set(h);
   h->f8_off = enabled == 0;
+  if (!enabled) h->forced_set = -1;  // a pinned / calibrated compact set goes too
   h->resolved = false;
   rc = resolve_policy(h);
-  if (changed) *changed = (rc == OP_OK && h->pi != before) ? 1 : 0;
+  if (changed) *changed = (rc == OP_OK && public_set(h) != before) ? 1 : 0;
   return rc;
+}
+
+int op_select_kernel_set(op_handle* h, int kernel_set) {
+  if (!h) return fail(nullptr, OP_ERR_INVALID, "op_select_kernel_set: NULL handle");
+  int rc = op_weights_ready(h);
+  if (rc != OP_OK) return rc;
+  if (kernel_set != OP_KS_AUTO && !set_available(h, kernel_set))
+    return fail(h, OP_ERR_UNSUPPORTED, "op_select_kernel_set: kernel set %d cannot run on this handle (shape, flags or weights)", kernel_set);
+  h->forced_set = kernel_set == OP_KS_AUTO ? -1 : kernel_set;
+  h->resolved = false;
+  return resolve_policy(h);
+}
+
+int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const int32_t* cu_seqlens_host, int n_seqs,
+                 op_calibration* report) {
+  if (!h) return fail(nullptr, OP_ERR_INVALID, "op_calibrate: NULL handle");
+  if (report && report->struct_bytes != sizeof(op_calibration))
+    return fail(h, OP_ERR_INVALID, "op_calibrate: op_calibration.struct_bytes=%u, library expects %zu", report->struct_bytes, sizeof(op_calibration));
+  if (!(tolerance >= 0.f)) return fail(h, OP_ERR_INVALID, "op_calibrate: tolerance must be >= 0");
+  if ((ids_host == nullptr) != (cu_seqlens_host == nullptr) || (ids_host && n_seqs <= 0))
+    return fail(h, OP_ERR_INVALID, "op_calibrate: ids_host / cu_seqlens_host / n_seqs must be given together");
+  int rc = op_weights_ready(h);
+  if (rc != OP_OK) return rc;
+  OP_HIP(h, hipSetDevice(h->cfg.device_id));
+
+  // the default selection and its (hi, lo) bf16 realisation = the reference of the comparison
+  const bool f8_off_before = h->f8_off;
+  h->forced_set = -1;
+  h->resolved = false;
+  OP_TRY(resolve_policy(h));
+  const int default_set = public_set(h);
+  h->f8_off = true;
+  h->resolved = false;
+  OP_TRY(resolve_policy(h));
+  const int reference_set = public_set(h);
+  h->f8_off = f8_off_before;
+  h->resolved = false;
+  OP_TRY(resolve_policy(h));
+
+  op_calibration rep;
+  memset(&rep, 0, sizeof(rep));
+  rep.struct_bytes = sizeof(rep);
+  rep.tolerance = tolerance;
+  rep.reference_set = reference_set;
+  rep.default_set = default_set;
+  rep.chosen_set = default_set;
+  auto finish = [&]() {
+    if (report) *report = rep;
+    return OP_OK;
+  };
+  if (default_set < 0 || reference_set < 0) return finish();  // a custom policy on the all-terms kernels: nothing cheaper is defined
+
+  // candidates: every available kernel set cheaper than the default one, cheapest first
+  std::vector<int> cand;
+  for (int set = 0; set < OP_KS_COUNT; ++set)
+    if (set != default_set && set_available(h, set) && set_cost(h, set) < set_cost(h, default_set)) cand.push_back(set);
+  std::sort(cand.begin(), cand.end(), [&](int a, int b) { return set_cost(h, a) < set_cost(h, b); });
+  if (cand.size() > 8) cand.resize(8);
+  if (cand.empty()) return finish();
+
+  std::vector<int32_t> ids, cu;
+  if (ids_host) {
+    cu.assign(cu_seqlens_host, cu_seqlens_host + n_seqs + 1);
+    if (cu[0] != 0 || cu[n_seqs] <= 0) return fail(h, OP_ERR_INVALID, "op_calibrate: cu_seqlens must start at 0 and hold at least one token");
+    ids.assign(ids_host, ids_host + cu[n_seqs]);
+  } else {
+    synthetic_calibration_rows(h, ids, cu);
+    n_seqs = (int)cu.size() - 1;
+  }
+  const int total = cu[n_seqs];
+  int max_len = 0;
+  for (int s = 0; s < n_seqs; ++s) max_len = std::max(max_len, cu[s + 1] - cu[s]);
+  rep.n_rows = n_seqs;
+  rep.n_tokens = total;
+
+  const size_t ws_bytes = op_workspace_bytes(h, n_seqs, total, max_len);
+  const size_t n_prune = (size_t)total * 2, n_rank = (size_t)n_seqs * h->nl;
+  int32_t *ids_dev = nullptr, *cu_dev = nullptr;
+  float* out_dev = nullptr;
+  void* ws_dev = nullptr;
+  hipStream_t st = nullptr;
+  auto release = [&]() {
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(ids_dev);
+    (void)hipFree(cu_dev);
+    (void)hipFree(out_dev);
+    (void)hipFree(ws_dev);
+  };
+  hipError_t e = hipMalloc((void**)&ids_dev, ids.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&cu_dev, cu.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&out_dev, (n_prune + n_rank) * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ws_dev, ws_bytes + 256);
+  if (e == hipSuccess) e = hipStreamCreate(&st);
+  if (e == hipSuccess) e = hipMemcpy(ids_dev, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(cu_dev, cu.data(), cu.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    release();
+    return fail(h, OP_ERR_HIP, "op_calibrate: staging failed: %s", hipGetErrorString(e));
+  }
+  void* ws_aligned = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(ws_dev) + 255) / 256 * 256);
+  std::vector<float> ref(n_prune + n_rank), got(n_prune + n_rank);
+  const bool profiling = h->profiling;
+  float* const capture = h->capture;
+  h->profiling = false;
+  h->capture = nullptr;
+  auto run = [&](int set, std::vector<float>& out) -> int {
+    h->forced_set = set;
+    h->resolved = false;
+    OP_TRY(resolve_policy(h));
+    OP_TRY(op_forward_packed(h, ids_dev, cu_dev, cu.data(), n_seqs, total, max_len, out_dev, out_dev + n_prune, nullptr, ws_aligned,
+                             ws_bytes, st));
+    OP_HIP(h, hipStreamSynchronize(st));
+    OP_HIP(h, hipMemcpy(out.data(), out_dev, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+    return OP_OK;
+  };
+  rc = run(reference_set, ref);
+  bool ref_finite = true;
+  for (float v : ref) ref_finite = ref_finite && std::isfinite(v);
+  int chosen = -1;
+  auto max_diff = [&]() {
+    float err = 0.f;
+    for (size_t i = 0; i < got.size(); ++i) {
+      const float d = std::fabs(got[i] - ref[i]);
+      err = (d <= err) ? err : d;  // a NaN difference propagates: (NaN <= err) is false
+    }
+    return std::isfinite(err) ? err : INFINITY;
+  };
+  if (rc == OP_OK && ref_finite && default_set != reference_set) {
+    rc = run(default_set, got);
+    if (rc == OP_OK) rep.default_err = max_diff();
+  }
+  if (rc == OP_OK && ref_finite) {
+    for (size_t c = 0; c < cand.size() && rc == OP_OK; ++c) {
+      rc = run(cand[c], got);
+      if (rc != OP_OK) break;
+      const float err = max_diff();
+      rep.candidate_set[rep.n_candidates] = cand[c];
+      rep.candidate_err[rep.n_candidates] = err;
+      rep.n_candidates += 1;
+      if (chosen < 0 && err <= tolerance) chosen = cand[c];
+    }
+  }
+  h->profiling = profiling;
+  h->capture = capture;
+  release();
+  // nothing cheaper holds: the default stays -- unless it cannot even represent this batch (fp16 range)
+  if (rc == OP_OK && chosen < 0 && ref_finite && !std::isfinite(rep.default_err)) chosen = reference_set;
+  h->forced_set = (rc == OP_OK && chosen >= 0) ? chosen : -1;
+  h->resolved = false;
+  const int rc2 = resolve_policy(h);
+  if (rc != OP_OK) return rc;
+  if (rc2 != OP_OK) return rc2;
+  rep.chosen_set = public_set(h);
+  return finish();
 }
 
 int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set) {
@@ -1331,7 +1614,7 @@ int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set) {
   terms_out[OP_FAM_ATTN_OUT] = (uint8_t)h->eff.attn_out;
   terms_out[OP_FAM_WI] = (uint8_t)h->eff.wi;
   terms_out[OP_FAM_MLP_OUT] = (uint8_t)h->eff.mlp_out;
-  *kernel_set = h->emulate ? -1 : (h->wi_f8 ? 5 + h->pi : h->pi);  // 5 / 6: sets 0 / 1 with the Wi GEMM in the fp16 + e4m3 format
+  *kernel_set = public_set(h);
   return OP_OK;
 }
 

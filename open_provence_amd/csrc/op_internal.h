@@ -19,7 +19,7 @@ namespace opl {
 //   wqkv: LN(x) x Wqkv    qk: q x k    pv: p x v    attn_out: o x Wo    wi: LN(x) x Wi    mlp_out: h x Wo
 struct Policy {
   int wqkv, qk, pv, attn_out, wi, mlp_out;
-  int fmt = 0;  // operand format of the whole-layer kernel: 0 = (hi, lo) bf16 planes, 1 = fp16 hi + e4m3 lo (opk_common.hip.h)
+  int fmt = 0;  // operand format: 0 = (hi, lo) bf16 planes, 1 = fp16 hi + e4m3 lo in the whole-layer kernel (opk_common.hip.h), 2 = fp16 single plane everywhere
   constexpr bool operator==(const Policy& o) const {
     return wqkv == o.wqkv && qk == o.qk && pv == o.pv && attn_out == o.attn_out && wi == o.wi && mlp_out == o.mlp_out;
   }
@@ -39,14 +39,18 @@ struct Policy {
 //   4  f16 + fp8, all terms   the terms of set 0 (fp32-valued weights) in the same format: the weight's lo part rides as a
 //                             third e4m3 plane (bf16 for the MLP output projection): 2 MFMA units per product instead of 3,
 //                             and ONE kernel per layer where set 0 needs two with h through HBM.  resolve_policy(): 0 -> 4.
+//   5  f16                    (round 5) single pass with every operand as fp16: the kernels and layouts of set 2, 11 instead of
+//                             8 significant bits per operand.  Never matched by terms and never a default: op_calibrate /
+//                             op_select_kernel_set choose it when the loaded weights allow (reported as kernel set 7).
 constexpr Policy kPolicies[] = {
     {3, 3, 3, 3, 3, 3},
     {1, 3, 3, 1, 1, 1},
     {0, 0, 0, 0, 0, 0},
     {1, 3, 3, 1, 1, 1, 1},
     {3, 3, 3, 3, 3, 3, 1},
+    {0, 0, 0, 0, 0, 0, 2},
 };
-constexpr int PI_ALL_TERMS = 0, PI_BF16_WEIGHTS = 1, PI_F16_F8 = 3, PI_F16_F8_W = 4;
+constexpr int PI_ALL_TERMS = 0, PI_BF16_WEIGHTS = 1, PI_BF16 = 2, PI_F16_F8 = 3, PI_F16_F8_W = 4, PI_F16 = 5;
 constexpr int N_POLICIES = (int)(sizeof(kPolicies) / sizeof(kPolicies[0]));
 
 // template arguments each kernel family derives from a policy
@@ -66,6 +70,9 @@ bool launch_row_layer_fused(hipStream_t st, const opk::RowGemmParams& p, int ks,
 // ... of the "f16 + fp8" kernel set (hidden 128 / 256)
 bool launch_row_layer_f8(hipStream_t st, const opk::RowGemmParams& p, int ks, bool with_qkv, unsigned grid);
 bool launch_row_layer_f8w(hipStream_t st, const opk::RowGemmParams& p, int ks, bool with_qkv, unsigned grid);  // kernel set 4
+// ... of the "f16" kernel set (PI_F16): the layer-0 q / k / v projection and the whole-layer kernel with fp16 operands
+bool launch_row_qkv0_h16(hipStream_t st, const opk::RowGemmParams& p, int ks, bool small, unsigned grid);
+bool launch_row_layer_h16(hipStream_t st, const opk::RowGemmParams& p, int ks, bool with_qkv, unsigned grid, bool waves8);
 // the same launch on the 32x32x16 shape (hidden = 256; kernel sets 1 and 2)
 bool has_layer32(int pi);
 bool launch_layer32(hipStream_t st, const opk::Layer32Params& p, int pi, bool with_qkv, unsigned grid);

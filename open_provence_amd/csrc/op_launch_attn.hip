@@ -16,7 +16,7 @@ void launch_one(hipStream_t st, const AttnFpParams& p, dim3 grid) {
 #define OPK_ATTN_LOCAL_STAGES 2
 #endif
   constexpr int NST = KT == 1 ? OPK_ATTN_LOCAL_STAGES : 2;
-  hipLaunchKernelGGL((attn_fp_kernel<P.qk, P.pv, o_lo(P), WAVES, KT, false, P.fmt == 1, NST>), grid, dim3(WAVES * 64), 0, st, p);
+  hipLaunchKernelGGL((attn_fp_kernel<P.qk, P.pv, o_lo(P), WAVES, KT, false, P.fmt == 1, NST, P.fmt == 2>), grid, dim3(WAVES * 64), 0, st, p);
 }
 
 template <int PI>
@@ -39,8 +39,9 @@ bool launch_attn(hipStream_t st, const AttnFpParams& p, int waves, int kt, int p
     else return false;
     return true;
   }
-  static_assert(N_POLICIES == 5, "extend the switch below");
+  static_assert(N_POLICIES == 6, "extend the switch below");
   switch (pi) {
+    case 5: return launch_pi<5>(st, p, waves, kt, grid);
     case 0: return launch_pi<0>(st, p, waves, kt, grid);
     case 1: return launch_pi<1>(st, p, waves, kt, grid);
     case 2: return launch_pi<2>(st, p, waves, kt, grid);

@@ -23,20 +23,21 @@ bool launch_pi(hipStream_t st, const Layer32Params& p, bool with_qkv, unsigned g
 }  // namespace
 
 bool has_layer32(int pi) {
-  if (pi < 0 || pi >= N_POLICIES) return false;
+  if (pi < 0 || pi >= N_POLICIES || kPolicies[pi].fmt != 0) return false;
   const Policy& P = kPolicies[pi];
   return ((P.wqkv | P.attn_out | P.wi | P.mlp_out) & 2) == 0 && (P.wqkv & 1) == (P.attn_out & 1) &&
          (P.wi & 1) == (P.mlp_out & 1) && (P.wqkv & 1) == (P.wi & 1);
 }
 
 bool launch_layer32(hipStream_t st, const Layer32Params& p, int pi, bool with_qkv, unsigned grid) {
-  static_assert(N_POLICIES == 5, "extend the switch");
+  static_assert(N_POLICIES == 6, "extend the switch");
   switch (pi) {
     case 0: return launch_pi<0>(st, p, with_qkv, grid);
     case 1: return launch_pi<1>(st, p, with_qkv, grid);
     case 2: return launch_pi<2>(st, p, with_qkv, grid);
     case 3:
-    case 4: return false;  // kernel sets 3 and 4 have their own whole-layer kernel
+    case 4:
+    case 5: return false;  // kernel sets 3, 4 and "f16" have their own whole-layer kernels
     default: return false;
   }
 }

@@ -10,17 +10,18 @@ namespace {
 template <int PI>
 bool launch_pi(hipStream_t st, const PanelParams& p, int epi, dim3 grid) {
   constexpr Policy P = kPolicies[PI];
+  constexpr bool H16 = P.fmt == 2;  // kernel set "f16": fp16 operands
   const dim3 block(256);
   if (epi == PE_QK)
-    hipLaunchKernelGGL((panel_gemm_kernel<PE_QK, P.wqkv, (P.qk & 3)>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_QK, P.wqkv, (P.qk & 3), H16>), grid, block, 0, st, p);
   else if (epi == PE_V)
-    hipLaunchKernelGGL((panel_gemm_kernel<PE_V, P.wqkv, ((P.pv & 2) ? 1 : 0)>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_V, P.wqkv, ((P.pv & 2) ? 1 : 0), H16>), grid, block, 0, st, p);
   else if (epi == PE_GEGLU)
-    hipLaunchKernelGGL((panel_gemm_kernel<PE_GEGLU, P.wi, h_olo(P)>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_GEGLU, P.wi, h_olo(P), H16>), grid, block, 0, st, p);
   else if (epi == 100)  // attention output projection
-    hipLaunchKernelGGL((panel_gemm_kernel<PE_RESIDUAL, P.attn_out, 0>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_RESIDUAL, P.attn_out, 0, H16>), grid, block, 0, st, p);
   else if (epi == 101)  // MLP output projection
-    hipLaunchKernelGGL((panel_gemm_kernel<PE_RESIDUAL, P.mlp_out, 0>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((panel_gemm_kernel<PE_RESIDUAL, P.mlp_out, 0, H16>), grid, block, 0, st, p);
   else
     return false;
   return true;
@@ -29,31 +30,33 @@ bool launch_pi(hipStream_t st, const PanelParams& p, int epi, dim3 grid) {
 template <int PI>
 void launch_qkv_pi(hipStream_t st, const PanelParams& p, dim3 grid) {
   constexpr Policy P = kPolicies[PI];
-  hipLaunchKernelGGL((panel_qkv_kernel<P.wqkv, (P.qk & 3), ((P.pv & 2) ? 1 : 0)>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((panel_qkv_kernel<P.wqkv, (P.qk & 3), ((P.pv & 2) ? 1 : 0), P.fmt == 2>), grid, dim3(256), 0, st, p);
 }
 
 }  // namespace
 
 bool launch_panel_qkv(hipStream_t st, const PanelParams& p, int pi, dim3 grid) {
-  static_assert(N_POLICIES == 5, "extend the switch below");
+  static_assert(N_POLICIES == 6, "extend the switch below");
   switch (pi) {
     case 0: launch_qkv_pi<0>(st, p, grid); return true;
     case 1: launch_qkv_pi<1>(st, p, grid); return true;
     case 2: launch_qkv_pi<2>(st, p, grid); return true;
     case 3: launch_qkv_pi<1>(st, p, grid); return true;
     case 4: launch_qkv_pi<0>(st, p, grid); return true;
+    case 5: launch_qkv_pi<5>(st, p, grid); return true;
     default: return false;
   }
 }
 
 bool launch_panel(hipStream_t st, const PanelParams& p, int epi, int pi, dim3 grid) {
-  static_assert(N_POLICIES == 5, "extend the switch below");
+  static_assert(N_POLICIES == 6, "extend the switch below");
   switch (pi) {
     case 0: return launch_pi<0>(st, p, epi, grid);
     case 1: return launch_pi<1>(st, p, epi, grid);
     case 2: return launch_pi<2>(st, p, epi, grid);
     case 3: return launch_pi<1>(st, p, epi, grid);
     case 4: return launch_pi<0>(st, p, epi, grid);
+    case 5: return launch_pi<5>(st, p, epi, grid);
     default: return false;
   }
 }

@@ -29,8 +29,9 @@ bool launch_ks(hipStream_t st, const RowGemmParams& p, int ks, bool small, unsig
 }  // namespace
 
 // (kernel set 3 = the operand terms of set 1; only the whole-layer kernel has its own instantiation: OPL_ROW_PART 4)
+// (kernel set "f16" = PI_F16 has its own launchers: OPL_ROW_PART 6; the two-kernels-per-layer forms do not exist for it)
 #define OPL_SWITCH(CALL)                              \
-  static_assert(N_POLICIES == 5, "extend the switch"); \
+  static_assert(N_POLICIES == 6, "extend the switch"); \
   switch (pi) {                                       \
     case 0: return CALL(0);                           \
     case 1: return CALL(1);                           \
@@ -58,6 +59,7 @@ bool launch_row_qkv_fused(hipStream_t st, const RowGemmParams& p, int ks, bool s
 
 #if OPL_ROW_PART == 2
 bool launch_row_qkv0(hipStream_t st, const RowGemmParams& p, int ks, bool small, int pi, unsigned grid) {
+  if (pi == PI_F16) return launch_row_qkv0_h16(st, p, ks, small, grid);
 #define OPL_CALL(PI) (launch_ks<RE_QKV, RP_SPLIT, 0, kPolicies[PI].wqkv, qkv_olo(kPolicies[PI])>(st, p, ks, small, grid))
   OPL_SWITCH(OPL_CALL)
 #undef OPL_CALL
@@ -114,12 +116,13 @@ bool launch_layer_pi(hipStream_t st, const RowGemmParams& p, int ks, bool with_q
 }  // namespace
 
 bool has_row_layer_fused(int pi) {
-  return pi == PI_F16_F8_W || (pi >= 0 && pi < N_POLICIES && (kPolicies[pi].wi & 2) == 0 && (kPolicies[pi].mlp_out & 2) == 0);
+  return pi == PI_F16_F8_W || pi == PI_F16 || (pi >= 0 && pi < N_POLICIES && (kPolicies[pi].wi & 2) == 0 && (kPolicies[pi].mlp_out & 2) == 0);
 }
 
 bool launch_row_layer_fused(hipStream_t st, const RowGemmParams& p, int ks, int pi, bool with_qkv, unsigned grid, bool waves8) {
   if (pi == PI_F16_F8) return !waves8 && launch_row_layer_f8(st, p, ks, with_qkv, grid);
   if (pi == PI_F16_F8_W) return !waves8 && launch_row_layer_f8w(st, p, ks, with_qkv, grid);
+  if (pi == PI_F16) return launch_row_layer_h16(st, p, ks, with_qkv, grid, waves8);
 #define OPL_CALL(PI) (launch_layer_pi<PI>(st, p, ks, with_qkv, grid, waves8))
   OPL_SWITCH(OPL_CALL)
 #undef OPL_CALL
@@ -167,6 +170,42 @@ void launch_layer_f8w_ks(hipStream_t st, const RowGemmParams& p, bool with_qkv, 
 bool launch_row_layer_f8w(hipStream_t st, const RowGemmParams& p, int ks, bool with_qkv, unsigned grid) {
   if (ks == 8) launch_layer_f8w_ks<8>(st, p, with_qkv, grid);
   else if (ks == 4) launch_layer_f8w_ks<4>(st, p, with_qkv, grid);
+  else return false;
+  return true;
+}
+#endif
+
+#if OPL_ROW_PART == 6
+// Kernel set "f16" (PI_F16): the single-pass instantiations with fp16 operands (rowgemm_kernel<..., H16 = true>).
+namespace {
+template <int KS>
+void launch_qkv0_h16_ks(hipStream_t st, const RowGemmParams& p, bool small, unsigned grid) {
+  if (small) hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_SPLIT, 0, 0, 0, 4, 1, 0, 0, 0, true>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_SPLIT, 0, 0, 0, 4, 2, 0, 0, 0, true>), dim3(grid), dim3(256), 0, st, p);
+}
+template <int KS>
+void launch_layer_h16_ks(hipStream_t st, const RowGemmParams& p, bool with_qkv, unsigned grid, bool waves8) {
+  if (waves8 && with_qkv)
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, 0, 0, 0, 8, 1, 0, 0, 0, true>), dim3(grid), dim3(512), 0, st, p);
+  else if (waves8)
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, 0, 0, 0, 8, 1, 0, 0, 0, true>), dim3(grid), dim3(512), 0, st, p);
+  else if (with_qkv)
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, 0, 0, 0, 4, 2, 0, 0, 0, true>), dim3(grid), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, 0, 0, 0, 4, 2, 0, 0, 0, true>), dim3(grid), dim3(256), 0, st, p);
+}
+}  // namespace
+
+bool launch_row_qkv0_h16(hipStream_t st, const RowGemmParams& p, int ks, bool small, unsigned grid) {
+  if (ks == 8) launch_qkv0_h16_ks<8>(st, p, small, grid);
+  else if (ks == 4) launch_qkv0_h16_ks<4>(st, p, small, grid);
+  else return false;
+  return true;
+}
+
+bool launch_row_layer_h16(hipStream_t st, const RowGemmParams& p, int ks, bool with_qkv, unsigned grid, bool waves8) {
+  if (ks == 8) launch_layer_h16_ks<8>(st, p, with_qkv, grid, waves8);
+  else if (ks == 4) launch_layer_h16_ks<4>(st, p, with_qkv, grid, waves8);
   else return false;
   return true;
 }

@@ -67,9 +67,12 @@ constexpr int ATT_ITEM_GROUP = 4;
 // NST: LDS stages of the K / V^T tile ring.  2 (shipped): the next tile is requested while this one is multiplied.
 // 3 (experiment, see op_launch_attn.hip: slower): two tiles ahead, the end-of-tile wait counts the newest request out
 // (vmcnt retires in order) instead of draining everything.
-template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false, bool OF8 = false, int NST = 2>
+// H16 (kernel set "f16"): q / k / v^T / p / o are single-plane fp16 (the layouts of the single-pass bf16 set), products on
+// v_mfma_f32_16x16x32_f16.  p <= 2^6 by the lazy reference; a p below 2^-24 is flushed (it is summed into l_run in fp32).
+template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false, bool OF8 = false, int NST = 2, bool H16 = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) {
   if constexpr (OF8) set_saturating_conversions();
+  static_assert(!H16 || (TQK == 0 && TPV == 0 && !O_LO && !OF8 && !ZP), "fp16 operands: single pass only");
   constexpr int ATT_FP_BQ = WAVES * 32;
   constexpr int TILE_KEYS = 32 * KT;
   constexpr bool Q_LO = (TQK & T_LEFT_LO) != 0, K_LO = (TQK & T_RIGHT_LO) != 0;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
           for (int qf = 0; qf < 2; ++qf) {
             if (K_LO) sacc[m][qf] = mfma16(kl, qf_hi[qf][ks], sacc[m][qf]);
             if (Q_LO) sacc[m][qf] = mfma16(kh, qf_lo[qf][ks], sacc[m][qf]);
-            sacc[m][qf] = mfma16(kh, qf_hi[qf][ks], sacc[m][qf]);
+            sacc[m][qf] = mfma16x<H16>(kh, qf_hi[qf][ks], sacc[m][qf]);
           }
         }
       }
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
           const float v0[4] = {sacc[2 * t][qf][0], sacc[2 * t][qf][1], sacc[2 * t][qf][2], sacc[2 * t][qf][3]};
           const float v1[4] = {sacc[2 * t + 1][qf][0], sacc[2 * t + 1][qf][1], sacc[2 * t + 1][qf][2], sacc[2 * t + 1][qf][3]};
           uint2 h0, l0, h1, l1;
-          split4<P_LO>(v0, h0, l0);
-          split4<P_LO>(v1, h1, l1);
+          split4x<P_LO, H16>(v0, h0, l0);
+          split4x<P_LO, H16>(v1, h1, l1);
           ph[t][qf] = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
           pl[t][qf] = ZP ? as_frag(make_uint4(0u, 0u, 0u, 0u)) : as_frag(make_uint4(l0.x, l0.y, l1.x, l1.y));
         }
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
           for (int qf = 0; qf < 2; ++qf) {
             if (V_LO) oacc[n][qf] = mfma16(vl, ph[t][qf], oacc[n][qf]);
             if (P_LO) oacc[n][qf] = mfma16(vh, pl[t][qf], oacc[n][qf]);
-            oacc[n][qf] = mfma16(vh, ph[t][qf], oacc[n][qf]);
+            oacc[n][qf] = mfma16x<H16>(vh, ph[t][qf], oacc[n][qf]);
           }
         }
       }
@@ -379,8 +382,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
         const float v1[4] = {oacc[2 * half + 1][qf][0] * inv, oacc[2 * half + 1][qf][1] * inv,
                              oacc[2 * half + 1][qf][2] * inv, oacc[2 * half + 1][qf][3] * inv};
         uint2 h0, l0, h1, l1;
-        split4<O_LO>(v0, h0, l0);
-        split4<O_LO>(v1, h1, l1);
+        split4x<O_LO, H16>(v0, h0, l0);
+        split4x<O_LO, H16>(v1, h1, l1);
         u16* dst = p.o_fp + (((q_rb + qf) * kbn + head * 2 + half) * 2) * 512 + lane * 8;
         store_stream16(dst, make_uint4(h0.x, h0.y, h1.x, h1.y));
         if (O_LO) store_stream16(dst + 512, make_uint4(l0.x, l0.y, l1.x, l1.y));

@@ -41,8 +41,9 @@ __device__ __forceinline__ int panel_source_row(int mode, int tile, int nf, int 
 
 #ifdef OPK_PACK_KERNELS  // weight re-packing runs in op_api.hip only
 // dst[tile][ks][plane][nf 0..15][lane = 16 g + i][8] <- W[source_row(tile, nf, i)][ks*32 + g*8 + e]
+// f16 = 1 (kernel set "f16"): hi plane = RNE_fp16(w), lo plane zeros, any_lo untouched
 __global__ void pack_panel_kernel(const float* __restrict__ src, int n_tiles, int K, int mode, int H, int I,
-                                  u16* __restrict__ dst, int zero_lo, int* __restrict__ any_lo) {
+                                  u16* __restrict__ dst, int zero_lo, int* __restrict__ any_lo, int f16 = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_tiles * 256 * K;
   if (idx >= total) return;
@@ -56,8 +57,13 @@ __global__ void pack_panel_kernel(const float* __restrict__ src, int n_tiles, in
   const int tile = (int)(t / KS);
   const int srow = panel_source_row(mode, tile, nf, i, H, I);
   const float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
-  const u16 h = f2bf(v);
   const size_t base = (((size_t)tile * KS + ks) * 2) * 8192 + (size_t)nf * 512 + (size_t)g * 128 + i * 8 + e;
+  if (f16) {
+    dst[base] = f2h(v);
+    dst[base + 8192] = (u16)0;
+    return;
+  }
+  const u16 h = f2bf(v);
   const u16 l = f2bf(v - bf2f(h));
   if ((l & 0x7fffu) != 0) *any_lo = 1;
   dst[base] = h;
@@ -139,7 +145,8 @@ constexpr int panel_stage_elems(int T) { return 16 * (((T & T_RIGHT_LO) != 0) ? 
 
 // One block's panel: rows [row_block * 128, +128) x panel `wtile_index` of the packed weights; `tile` is the panel's index
 // inside its own output tensor (q / k panels count from 0, so do the v^T panels of the fused launch).
-template <int EPI, int T, int OLO>
+// H16 (kernel set "f16"): the single-pass instantiation with fp16 operands (opk_common.hip.h)
+template <int EPI, int T, int OLO, bool H16 = false>
 __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block, int wtile_index, int tile, u16* __restrict__ o0,
                                             u16 (&sW)[2][panel_stage_elems(T)]) {
   constexpr int NF = 16;
@@ -151,6 +158,7 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
   constexpr int WAVE_PIECES = (NF * PLANES) / 4;
   constexpr bool SWAPPED = (EPI != PE_V);    // weights as the MFMA row operand, except for v^T
   static_assert(STAGE == panel_stage_elems(T), "stage size");
+  static_assert(!H16 || (T == 0 && OLO == 0), "fp16 operands: single pass only");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -229,7 +237,7 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
           for (int mf = 0; mf < 2; ++mf) {
             const bf16x8 w = term == 0 ? (j ? wl1 : wl0) : (j ? wh1 : wh0);
             const bf16x8 a = term == 1 ? a_lo[mf] : a_hi[mf];
-            acc[nf + j][mf] = SWAPPED ? mfma16(w, a, acc[nf + j][mf]) : mfma16(a, w, acc[nf + j][mf]);
+            acc[nf + j][mf] = SWAPPED ? mfma16x<H16>(w, a, acc[nf + j][mf]) : mfma16x<H16>(a, w, acc[nf + j][mf]);
           }
       }
     };
@@ -283,7 +291,7 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
           v[4 + r] = gelu_erf(acc[2 * s + 1][mf][r]) * acc[8 + 2 * s + 1][mf][r];
         }
         bf16x8 hi, lo;
-        pack8<O0_LO>(v, hi, lo);
+        pack8x<O0_LO, H16>(v, hi, lo);
         u16* dst = o0 + ((rb * kb_out + (size_t)(tile * 4 + s)) * 2) * 512 + lane * 8;
         store_stream16(dst, as_u4(hi));
         if (O0_LO) store_stream16(dst + 512, as_u4(lo));
@@ -321,8 +329,8 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
             hi_half[4 * u + r] = rope_hi(x1, x2, c4[u][r], s4[u][r]) * qscale;
           }
         bf16x8 h0, l0, h1, l1;
-        pack8<(O0_LO || O1_LO)>(lo_half, h0, l0);
-        pack8<(O0_LO || O1_LO)>(hi_half, h1, l1);
+        pack8x<(O0_LO || O1_LO), H16>(lo_half, h0, l0);
+        pack8x<(O0_LO || O1_LO), H16>(hi_half, h1, l1);
         u16* dst = out + ((rb * kb_out + (size_t)((tq * 4 + hh) * 2)) * 2) * 512 + lane * 8;
         store_stream16(dst, as_u4(h0));
         store_stream16(dst + 1024, as_u4(h1));
@@ -340,7 +348,7 @@ __device__ __forceinline__ void panel_block(const PanelParams& p, int row_block,
       const float v[8] = {acc[nf][0][0], acc[nf][0][1], acc[nf][0][2], acc[nf][0][3],
                           acc[nf][1][0], acc[nf][1][1], acc[nf][1][2], acc[nf][1][3]};
       bf16x8 hi, lo;
-      pack8<O0_LO>(v, hi, lo);
+      pack8x<O0_LO, H16>(v, hi, lo);
       u16* dst = o0 + (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + (size_t)(nf & 3)) * 512 + lane * 8;
       store_stream16(dst, as_u4(hi));
       if (O0_LO) store_stream16(dst + 2048, as_u4(lo));
@@ -358,24 +366,24 @@ __device__ __forceinline__ bool panel_block_map(const PanelParams& p, int& row_b
   return row_block * ROW_BM < p.r_pad;  // the grid is rounded up to whole groups
 }
 
-template <int EPI, int T, int OLO>
+template <int EPI, int T, int OLO, bool H16 = false>
 __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(PanelParams p) {
   __shared__ __attribute__((aligned(16))) u16 sW[2][panel_stage_elems(T)];
   int row_block, tile;
   if (!panel_block_map(p, row_block, tile)) return;
-  panel_block<EPI, T, OLO>(p, row_block, tile, tile, p.o0, sW);
+  panel_block<EPI, T, OLO, H16>(p, row_block, tile, tile, p.o0, sW);
 }
 
 // q, k and v^T of a layer in ONE launch: the three projections read the same normalised rows, so their panels sit side
 // by side in the XCD-local group (the rows are fetched once for all 3 H / 256 panels) and a launch is saved per layer.
 // The v^T panels use the un-swapped MFMA orientation: a block-uniform branch picks the instantiation.
-template <int T, int OLO_QK, int OLO_V>
+template <int T, int OLO_QK, int OLO_V, bool H16 = false>
 __global__ __launch_bounds__(256, 2) void panel_qkv_kernel(PanelParams p) {
   __shared__ __attribute__((aligned(16))) u16 sW[2][panel_stage_elems(T)];
   int row_block, tile;
   if (!panel_block_map(p, row_block, tile)) return;
-  if (tile < p.n_qk_tiles) panel_block<PE_QK, T, OLO_QK>(p, row_block, tile, tile, p.o0, sW);
-  else panel_block<PE_V, T, OLO_V>(p, row_block, tile, tile - p.n_qk_tiles, p.o2, sW);
+  if (tile < p.n_qk_tiles) panel_block<PE_QK, T, OLO_QK, H16>(p, row_block, tile, tile, p.o0, sW);
+  else panel_block<PE_V, T, OLO_V, H16>(p, row_block, tile, tile - p.n_qk_tiles, p.o2, sW);
 }
 
 // ----------------------------------------------------------------------------------------------

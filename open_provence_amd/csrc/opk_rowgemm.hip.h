@@ -111,8 +111,9 @@ __device__ __forceinline__ int rowgemm_source_row(int mode, int c, int pr, int H
 
 #ifdef OPK_PACK_KERNELS  // weight re-packing runs in op_api.hip only
 // dst[chunk][ks][plane][nf][g][i][e] <- src[source_row(chunk, nf*16+i)][ks*32 + g*8 + e]
+// f16 = 1 (kernel set "f16"): the hi plane holds RNE_fp16(w), the lo plane zeros; any_lo is not touched
 __global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, int K, int mode, int H, int I,
-                                    u16* __restrict__ dst, int zero_lo, int* __restrict__ any_lo) {
+                                    u16* __restrict__ dst, int zero_lo, int* __restrict__ any_lo, int f16 = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_rows * K;
   if (idx >= total) return;
@@ -126,8 +127,13 @@ __global__ void pack_rowgemm_kernel(const float* __restrict__ src, int n_rows, i
   const int c = (int)(t / KS);
   const int srow = rowgemm_source_row(mode, c, nf * 16 + i, H, I);
   const float v = src[(size_t)srow * K + ks * 32 + g * 8 + e];
-  const u16 h = f2bf(v);
   const size_t base = (((size_t)c * KS + ks) * 2) * 1024 + (size_t)nf * 512 + (size_t)g * 128 + i * 8 + e;
+  if (f16) {
+    dst[base] = f2h(v);
+    dst[base + 1024] = (u16)0;
+    return;
+  }
+  const u16 h = f2bf(v);
   const u16 l = f2bf(v - bf2f(h));
   if ((l & 0x7fffu) != 0) *any_lo = 1;
   dst[base] = h;
@@ -223,7 +229,7 @@ struct MlpStreamOff {
 // One weight chunk (32 output features x K) against this wave's 32 rows: 2 x 2 accumulators, K/32 k-steps of
 // 4 MFMAs per product term, weight fragments two k-steps deep in registers (see above).  `lds_addr` = LDS byte
 // address of this lane's 16 bytes in piece 0 of stage 0; STAGE_BYTES = compile-time offset of the stage to read.
-template <int KS, int MF, int T, bool SWAPPED, int STAGE_BYTES, bool PIN_AGPR = false, int DEPTH = 1>
+template <int KS, int MF, int T, bool SWAPPED, int STAGE_BYTES, bool PIN_AGPR = false, int DEPTH = 1, bool H16 = false>
 __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16x8 (&a_hi)[MF][KS],
                                                    const bf16x8 (&a_lo)[MF][KS], f32x4 (&acc)[2][MF]) {
   constexpr bool W_LO = (T & T_RIGHT_LO) != 0, A_LO = (T & T_LEFT_LO) != 0;
@@ -263,7 +269,7 @@ __device__ __forceinline__ void rowgemm_chunk_mfma(uint32_t lds_addr, const bf16
         for (int mf = 0; mf < MF; ++mf) {
           const bf16x8 w = term == 0 ? wl[S][nf] : wh[S][nf];
           const bf16x8 a = term == 1 ? a_lo[mf][ks] : a_hi[mf][ks];
-          acc[nf][mf] = SWAPPED ? mfma16(w, a, acc[nf][mf]) : mfma16(a, w, acc[nf][mf]);
+          acc[nf][mf] = SWAPPED ? mfma16x<H16>(w, a, acc[nf][mf]) : mfma16x<H16>(a, w, acc[nf][mf]);
         }
       }
     }
@@ -387,9 +393,13 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
 // e4m3 x 2^12 for the K = hidden contractions (multiplied against e4m3(activation): 0.5 MFMA units), unscaled fp16 for the
 // MLP output projection (against the fp16 hi fragment of h) -- 2 MFMA units per product where the (hi, lo) bf16 kernels need 3; one Wi chunk +
 // half a Wo slab per LDS stage (a stage of two chunks + a slab with their lo planes would be 96 KiB).
-template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0, int F8 = 0>
+// H16 (kernel set "f16", round 5): the single-pass instantiation (every term mask 0) with fp16 operands -- weights from the
+// fp16 packs (pack_*_kernel with f16 = 1), activations converted with v_cvt_pk_f16_f32, products on v_mfma_f32_16x16x32_f16.
+template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0, int F8 = 0, bool H16 = false>
 __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : ((MF == 1 && WAVES == 8) ? 4 : 2)) void rowgemm_kernel(RowGemmParams p) {
   constexpr bool WLO = F8 == 2;
+  static_assert(!H16 || (F8 == 0 && T1 == 0 && T2 == 0 && OLO == 0 && TW == 0 && TM == 0 && PRO != RP_KSTREAM && EPI != RE_GEGLU),
+                "fp16 operands: the single-pass whole-layer / layer-0 q/k/v kernels only");
   constexpr int TF8 = WLO ? 3 : T_LEFT_LO;  // the term masks this instantiation stands for
   static_assert(!F8 || (PRO == RP_MLP && WAVES == 4 && MF == 2 && KS % 4 == 0 && T1 == TF8 && TW == TF8 && TM == TF8 &&
                         (EPI == RE_NONE || T2 == TF8)),
@@ -733,9 +743,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
             for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, a_lo[mf][ks], acc1[nf + 1][mf]);
           }
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, a_hi[mf][ks], acc1[nf][mf]);
+          for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16x<H16>(w0, a_hi[mf][ks], acc1[nf][mf]);
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, a_hi[mf][ks], acc1[nf + 1][mf]);
+          for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16x<H16>(w1, a_hi[mf][ks], acc1[nf + 1][mf]);
         });
         __syncthreads();
       });
@@ -944,7 +954,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           } else {
           uint32_t h[4], l[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) split2_pk<LO>(pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]), h[j], l[j]);
+          for (int j = 0; j < 4; ++j) split2x_pk<LO, H16>(pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]), h[j], l[j]);
           a_hi[mf][ks] = as_frag(make_uint4(h[0], h[1], h[2], h[3]));
           a_lo[mf][ks] = as_frag(make_uint4(l[0], l[1], l[2], l[3]));
           if constexpr (LO && LOAD && MF == 2) asm volatile("" : "+a"(a_lo[mf][ks]));  // parked where the MLP wants it (see below)
@@ -1238,14 +1248,14 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         constexpr int mf = decltype(mf_tag)::value;
         uint2 h2, l2;
         if constexpr (F8) split4_f16(g_prev[mf], h2, l2);
-        else split4<H_LO>(g_prev[mf], h2, l2);
+        else split4x<H_LO, H16>(g_prev[mf], h2, l2);
         h_hi[mf] = as_frag(make_uint4(hold_hi[mf].x, hold_hi[mf].y, h2.x, h2.y));
         h_lo[mf] = as_frag(make_uint4(hold_lo[mf].x, hold_lo[mf].y, l2.x, l2.y));
       };
       auto pack_hold = [&](auto mf_tag) {
         constexpr int mf = decltype(mf_tag)::value;
         if constexpr (F8) split4_f16(g_cur[mf], hold_hi[mf], hold_lo[mf]);
-        else split4<H_LO>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
+        else split4x<H_LO, H16>(g_cur[mf], hold_hi[mf], hold_lo[mf]);
       };
       // The GeGLU of one chunk + the split / pack of its values as ONE list of RB_OPS = 9 NV micro-operations, so that it
       // can be cut anywhere (OPK_X_REBAL spreads it over the steps that follow the chunk in proportion to their MFMA pipe
@@ -1320,9 +1330,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16(w1, a_lo[mf][ks], ks == 0 ? zero : acc[1][mf]);
         }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[0][mf] = mfma16(w0, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[0][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc[0][mf] = mfma16x<H16>(w0, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[0][mf]);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16(w1, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[1][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc[1][mf] = mfma16x<H16>(w1, a_hi[mf][ks], (ks == 0 && !A_LOW) ? zero : acc[1][mf]);
       };
       // F8: lo(LN(x)) x Wi as e4m3, fragment nf of the chunk, K-step s8: (w0, w1) are the fragment's two halves
       auto chunk_step8 = [&](f32x4 (&acc)[2][MF], auto nf_tag, auto s8_tag, const bf16x8& w0, const bf16x8& w1, auto&& rd) {
@@ -1356,9 +1366,9 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, h_lo[mf], acc1[nf + 1][mf]);
         }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16(w0, h_hi[mf], acc1[nf][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc1[nf][mf] = mfma16x<H16>(w0, h_hi[mf], acc1[nf][mf]);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16(w1, h_hi[mf], acc1[nf + 1][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc1[nf + 1][mf] = mfma16x<H16>(w1, h_hi[mf], acc1[nf + 1][mf]);
       };
       // WLO: e4m3(LN(x)) x lo(Wi), and one output fragment of the slab with all three terms:
       //   lo(h) x Wo, h x lo(Wo) (w1 = that plane's fragment: unscaled fp16, see pack_kstream_f8_kernel) and h x Wo, all
@@ -1723,7 +1733,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           y[j] = pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]);
-          split2_pk<A_LO>(y[j], hb[j], lb[j]);
+          split2x_pk<A_LO, H16>(y[j], hb[j], lb[j]);
         }
         store_stream16(xrow + ks * 32, make_float4(y[0].x, y[0].y, y[1].x, y[1].y));
         store_stream16(xrow + ks * 32 + 4, make_float4(y[2].x, y[2].y, y[3].x, y[3].y));
@@ -1740,7 +1750,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
         const float4 f0 = load_stream_f4(p.x_in + row * K + ks * 32 + g * 8);
         const float4 f1 = load_stream_f4(p.x_in + row * K + ks * 32 + g * 8 + 4);
         const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-        pack8<A_LO>(v, a_hi[mf][ks], a_lo[mf][ks]);
+        pack8x<A_LO, H16>(v, a_hi[mf][ks], a_lo[mf][ks]);
       }
     }
   }
@@ -2050,8 +2060,8 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
             hi_half[r] = rope_hi(x1, x2, c4[r], s4[r]) * qscale;
           }
           uint2 h0, l0, h1, l1;
-          split4<QK_LO>(lo_half, h0, l0);
-          split4<QK_LO>(hi_half, h1, l1);
+          split4x<QK_LO, H16>(lo_half, h0, l0);
+          split4x<QK_LO, H16>(hi_half, h1, l1);
           if (PP == 0) {
             qk_hold[mf][0] = h0; qk_hold[mf][1] = l0; qk_hold[mf][2] = h1; qk_hold[mf][3] = l1;
           } else {
@@ -2080,11 +2090,11 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           st_p[nf] = p.o2_hi + (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + n) * 512 + lane * 8 + half;
           const float v0[4] = {av[nf][0][0], av[nf][0][1], av[nf][0][2], av[nf][0][3]};
           uint2 h0, l0;
-          split4<O2_LO>(v0, h0, l0);
+          split4x<O2_LO, H16>(v0, h0, l0);
           if (MF == 2) {
             const float v1[4] = {av[nf][MF - 1][0], av[nf][MF - 1][1], av[nf][MF - 1][2], av[nf][MF - 1][3]};
             uint2 h1, l1;
-            split4<O2_LO>(v1, h1, l1);
+            split4x<O2_LO, H16>(v1, h1, l1);
             st_v[nf][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
             if (O2_LO) st_v[nf][1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
           } else {
@@ -2180,7 +2190,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (F8) rowgemm_chunk_mfma_f8<KS, MF, SW, true, WLO>(lds_stage[cur], a_hi, a_lo8, a_h8, acc);
-    else rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP)>(lds_stage[cur], a_hi, a_lo, acc);
+    else rowgemm_chunk_mfma<KS, MF, T2, SW, 0, (PRO == RP_MLP), 1, H16>(lds_stage[cur], a_hi, a_lo, acc);
     if (!FIRST) epilogue_store(c - 1, std::integral_constant<int, (cur ^ 1)>{}, swp_tag);
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
@@ -2268,7 +2278,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #ifdef OPK_PACK_KERNELS  // weight re-packing runs in op_api.hip only
 // dst[ks][plane][nf][g][i][e] <- W[nf*16 + i][ks*32 + g*8 + e]   (W is [N][K]; chunk = one k-step of all N)
 __global__ void pack_kstream_kernel(const float* __restrict__ src, int N, int K, int permute, u16* __restrict__ dst,
-                                    int zero_lo, int* __restrict__ any_lo) {
+                                    int zero_lo, int* __restrict__ any_lo, int f16 = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * K) return;
   const int NF = N / 16;
@@ -2282,8 +2292,13 @@ __global__ void pack_kstream_kernel(const float* __restrict__ src, int N, int K,
   // accumulators of fragments (2s, 2s+1) ARE the 8 k-values of lane slot g' of k-step s of the next GEMM.
   const int row = permute ? (32 * (nf >> 1) + 8 * (i >> 2) + 4 * (nf & 1) + (i & 3)) : (nf * 16 + i);
   const float v = src[(size_t)row * K + ks * 32 + g * 8 + e];
-  const u16 h = f2bf(v);
   const size_t base = ((size_t)ks * 2 * NF + nf) * 512 + (size_t)g * 128 + i * 8 + e;
+  if (f16) {  // kernel set "f16": fp16 hi plane, zero lo plane
+    dst[base] = f2h(v);
+    dst[base + (size_t)NF * 512] = (u16)0;
+    return;
+  }
+  const u16 h = f2bf(v);
   const u16 l = f2bf(v - bf2f(h));
   if ((l & 0x7fffu) != 0) *any_lo = 1;
   dst[base] = h;

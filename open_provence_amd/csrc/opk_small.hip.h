@@ -369,7 +369,8 @@ __global__ void transpose_f32_kernel(const float* __restrict__ src, int rows, in
 // row, all k) spread over all banks; the pieces then leave as whole coalesced 1 KiB stores.
 constexpr int LN_FP_SLAB = 16 * 16 + 16;  // bytes per (k-step, k-group) slab in the staging buffer
 
-template <bool SPLIT>
+// H16 (kernel set "f16"): the single plane holds fp16 values
+template <bool SPLIT, bool H16 = false>
 __global__ __launch_bounds__(256) void ln_fp_kernel(const float* __restrict__ x, const float* __restrict__ lnw, float eps,
                                                     int H, int r_pad, int normalize, u16* __restrict__ out_fp) {
   __shared__ __attribute__((aligned(16))) unsigned char stage[LN_MAX_CHUNKS * 8 * 4 * LN_FP_SLAB];  // H <= 1024
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void ln_fp_kernel(const float* __restrict__ x,
 #pragma unroll
     for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
       const float v[4] = {rows[j].v[k].x, rows[j].v[k].y, rows[j].v[k].z, rows[j].v[k].w};
-      split4<SPLIT>(v, hi[j][k], lo[j][k]);
+      split4x<SPLIT, H16>(v, hi[j][k], lo[j][k]);
     }
 #pragma unroll
   for (int plane = 0; plane < (SPLIT ? 2 : 1); ++plane) {

@@ -60,6 +60,27 @@ def parse_precision(precision: "str | Mapping[str, int]") -> tuple[int, list[int
     return _lib.OP_PRECISION_CUSTOM, terms
 _DTYPES = {torch.float32: _lib.OP_DTYPE_F32, torch.bfloat16: _lib.OP_DTYPE_BF16, torch.float16: _lib.OP_DTYPE_F16}
 
+DEFAULT_CALIBRATION_TOLERANCE = 1e-4  # max |logit difference| to the (hi, lo) bf16 kernels; the path's bar is 1e-3
+
+
+def resolve_calibration_tolerance(calibrate: "bool | float | None") -> float:
+    """``False`` / ``0`` -> 0.0 (no calibration); a float -> that tolerance; ``True`` / ``None`` -> ``OPEN_PROVENCE_CALIBRATE``
+    (``0`` / ``off`` disables, a number is the tolerance) or :data:`DEFAULT_CALIBRATION_TOLERANCE`."""
+
+    if calibrate is False:
+        return 0.0
+    if calibrate is not None and calibrate is not True:
+        return max(float(calibrate), 0.0)
+    env = os.environ.get("OPEN_PROVENCE_CALIBRATE", "").strip().lower()
+    if env in ("0", "off", "false", "no"):
+        return 0.0
+    if env and env not in ("1", "on", "true", "yes"):
+        try:
+            return max(float(env), 0.0)
+        except ValueError as exc:
+            raise ValueError(f"OPEN_PROVENCE_CALIBRATE must be 0 / off or a tolerance, got {env!r}") from exc
+    return DEFAULT_CALIBRATION_TOLERANCE
+
 
 def require_gpu(device: torch.device | str | int | None = None) -> torch.device:
     """Resolve a HIP device or fail loudly (the product has no CPU path)."""
@@ -139,6 +160,7 @@ class HipEncoder:
         self._workspace: torch.Tensor | None = None
         self._capture: torch.Tensor | None = None
         self._capture_result: torch.Tensor | None = None
+        self.calibration: dict | None = None  # report of the last calibrate() (load_state_dict runs it by default)
 
     # -- lifecycle -------------------------------------------------------------------------------
     def close(self) -> None:
@@ -168,16 +190,78 @@ class HipEncoder:
         )
         _lib.check(self.lib, self._handle, code, f"op_load_weight({name})")
 
-    def load_state_dict(self, state: Mapping[str, torch.Tensor]) -> None:
+    def load_state_dict(self, state: Mapping[str, torch.Tensor], *, calibrate: "bool | float | None" = None,
+                        kernel_set: "str | None" = None, calibration_rows: "Sequence[Sequence[int]] | None" = None) -> None:
         """Checkpoint keys as in the reference's ``model.safetensors`` (``ranking_model.*`` /
         ``pruning_head.*``; legacy checkpoints without the prefix are accepted, standalone.py:1452-1464).
-        Non-persistent buffers (``inv_freq``) and training-only tensors are skipped."""
+        Non-persistent buffers (``inv_freq``) and training-only tensors are skipped.
+
+        Then the arithmetic is chosen FROM THE LOADED WEIGHTS (the reference decides its dtype and attention
+        implementation at load time too, standalone.py:219-244, 1589-1615, 1631-1642): ``kernel_set`` (or
+        ``OPEN_PROVENCE_KERNEL_SET``) pins a kernel set by name; otherwise :meth:`calibrate` runs with tolerance
+        ``calibrate`` (a float; ``True`` / ``None`` = ``OPEN_PROVENCE_CALIBRATE`` or 1e-4; ``False`` / ``0`` = keep the
+        default selection, which is safe for any weights and priced for the worst case)."""
 
         for name, tensor in state.items():
             if "inv_freq" in name or name.endswith("pooling_weights.weight") or name.endswith("pooling_weights.bias"):
                 continue
             self.load_weight(name, tensor)
         _lib.check(self.lib, self._handle, self.lib.op_weights_ready(self._handle), "op_weights_ready")
+        self.__dict__["_f8_active"] = None
+        self.calibration = None
+        pinned = kernel_set or os.environ.get("OPEN_PROVENCE_KERNEL_SET")
+        if pinned:
+            self.select_kernel_set(pinned)
+            return
+        tolerance = resolve_calibration_tolerance(calibrate)
+        if tolerance > 0.0 and hasattr(self.lib, "op_calibrate"):
+            self.calibrate(tolerance, rows=calibration_rows)
+
+    def select_kernel_set(self, name: "str | None") -> None:
+        """Pin the kernel set by its :meth:`effective_policy` name (``None`` / ``"auto"``: the default selection).  A set with
+        fewer product terms than the checkpoint carries is an approximation: :meth:`calibrate` is what measures one."""
+
+        number = _lib.OP_KS_AUTO if name in (None, "auto") else _lib.KERNEL_SET_IDS.get(str(name))
+        if number is None:
+            raise ValueError(f"unknown kernel set {name!r}; expected one of {sorted(_lib.KERNEL_SET_IDS)} or 'auto'")
+        _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(number)), f"op_select_kernel_set({name})")
+        self.__dict__["_f8_active"] = None
+
+    def calibrate(self, tolerance: float = 1e-4, rows: "Sequence[Sequence[int]] | None" = None) -> dict:
+        """``op_calibrate``: one batch (``rows`` of token ids -- a sample of real inputs -- or the library's synthetic
+        batch) through the (hi, lo) bf16 kernels and through every kernel set cheaper than the default one; the
+        cheapest whose logits stay within ``tolerance`` of them (and finite) is what the forward runs on from now on.
+        Returns (and keeps as ``self.calibration``) the report: ``{"tolerance", "reference_set", "default_set",
+        "chosen_set", "candidates": {set name: max |logit difference|}, "rows", "tokens", "batch"}``."""
+
+        report = _lib.OpCalibration()
+        report.struct_bytes = ctypes.sizeof(_lib.OpCalibration)
+        if rows is not None:
+            ids_np, cu_np, _ = pack_rows(rows)
+            self.check_ids(ids_np)
+            ids_np = np.ascontiguousarray(ids_np, dtype=np.int32)
+            cu_np = np.ascontiguousarray(cu_np, dtype=np.int32)
+            args = (ids_np.ctypes.data_as(ctypes.c_void_p), cu_np.ctypes.data_as(ctypes.c_void_p), int(cu_np.shape[0]) - 1)
+        else:
+            args = (None, None, 0)
+        with torch.cuda.device(self.device):
+            code = self.lib.op_calibrate(self._handle, ctypes.c_float(float(tolerance)), *args, ctypes.byref(report))
+        _lib.check(self.lib, self._handle, code, "op_calibrate")
+        names = _lib.KERNEL_SET_NAMES
+        self.__dict__["_f8_active"] = None
+        self.calibration = {
+            "tolerance": float(report.tolerance),
+            "reference_set": names.get(int(report.reference_set), str(report.reference_set)),
+            "default_set": names.get(int(report.default_set), str(report.default_set)),
+            "chosen_set": names.get(int(report.chosen_set), str(report.chosen_set)),
+            "candidates": {names.get(int(report.candidate_set[i]), str(report.candidate_set[i])): float(report.candidate_err[i])
+                           for i in range(int(report.n_candidates))},
+            "default_err": float(report.default_err),
+            "rows": int(report.n_rows),
+            "tokens": int(report.n_tokens),
+            "batch": "caller rows" if rows is not None else "synthetic (uniform token ids)",
+        }
+        return self.calibration
 
     def effective_policy(self) -> dict:
         """Term masks actually evaluated (the requested policy minus weight-lo terms that are identically zero
@@ -190,8 +274,7 @@ class HipEncoder:
         kernel_set = ctypes.c_int(0)
         code = self.lib.op_effective_policy(self._handle, terms, ctypes.byref(kernel_set))
         _lib.check(self.lib, self._handle, code, "op_effective_policy")
-        names = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", 4: "f16-f8-w", 5: "bf16x3+wi-f16-f8-w", 6: "bf16-weights+wi-f16-f8",
-                 -1: "all-terms kernels, cleared lo operands"}
+        names = _lib.KERNEL_SET_NAMES
         return {
             "terms": {name: int(terms[i]) for i, name in enumerate(_lib.OP_FAMILIES)},
             "kernel_set": names.get(int(kernel_set.value), str(kernel_set.value)),
@@ -204,7 +287,7 @@ class HipEncoder:
 
         cached = self.__dict__.get("_f8_active")
         if cached is None:
-            cached = self.__dict__["_f8_active"] = self.effective_policy()["kernel_set"] in ("f16-f8", "f16-f8-w")
+            cached = self.__dict__["_f8_active"] = self.effective_policy()["kernel_set"] in _lib.FP16_PLANE_SETS
         return cached
 
     def fall_back_from_f8(self, reason: str = "") -> bool:

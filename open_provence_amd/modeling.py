@@ -208,7 +208,15 @@ class OpenProvenceModel:
         torch_dtype: Any | None = None,
         chunk_rows: int | None = None,
         pruning_hidden_state: str | None = None,
+        kernel_set: str | None = None,
+        calibrate: "bool | float | None" = None,
+        calibration_rows: "Sequence[Sequence[int]] | None" = None,
     ) -> None:
+        # kernel_set / calibrate / calibration_rows: how the arithmetic is chosen from the loaded weights
+        # (HipEncoder.load_state_dict; the reference's counterpart: standalone.py:219-244, 1589-1615)
+        self._kernel_set_request = kernel_set
+        self._calibrate_request = calibrate
+        self._calibration_rows = calibration_rows
         self.config = config
         self.max_length = int(config.max_length)
         self.num_labels = int(config.num_labels)
@@ -337,7 +345,9 @@ class OpenProvenceModel:
 
     def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = True) -> None:
         converted = self._convert_legacy_state_dict(state_dict)
-        self.encoder.load_state_dict(converted)
+        self.encoder.load_state_dict(converted, kernel_set=getattr(self, "_kernel_set_request", None),
+                                     calibrate=getattr(self, "_calibrate_request", None),
+                                     calibration_rows=getattr(self, "_calibration_rows", None))
         # The device library keeps only its re-packed copies; the original tensors are retained on the host (by
         # reference when they already live there) so that state_dict() / save_pretrained() work like the reference's.
         self._weights = {
@@ -444,6 +454,9 @@ class OpenProvenceModel:
             precision=kwargs.pop("precision", None),
             chunk_rows=kwargs.pop("chunk_rows", None),
             pruning_hidden_state=kwargs.pop("pruning_hidden_state", None),
+            kernel_set=kwargs.pop("kernel_set", None),
+            calibrate=kwargs.pop("calibrate", None),
+            calibration_rows=kwargs.pop("calibration_rows", None),
         )
         if max_length is not None:
             model.max_length = int(max_length)

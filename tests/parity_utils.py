@@ -10,7 +10,8 @@ import torch
 from helpers import dims_from_meta, load_golden, rows_from_fixture, state_from_fixture
 
 
-def run_fixture_on_gpu(name: str, precision="bf16x3", chunk_rows: int | None = None, capture: bool = True, flags=None, return_outputs: bool = False):
+def run_fixture_on_gpu(name: str, precision="bf16x3", chunk_rows: int | None = None, capture: bool = True, flags=None, return_outputs: bool = False,
+                       calibrate=None, kernel_set=None):
     """Returns dict with max-abs errors of the HIP path vs the reference outputs stored in the fixture."""
 
     from open_provence_amd.engine import HipEncoder
@@ -21,7 +22,7 @@ def run_fixture_on_gpu(name: str, precision="bf16x3", chunk_rows: int | None = N
     rows = rows_from_fixture(arrays)
     enc = HipEncoder(dims, device="cuda:0", precision=precision, chunk_rows=chunk_rows, flags=flags,
                      prune_pre_final_norm=bool(meta.get("prune_pre_final_norm", False)))
-    enc.load_state_dict(state)
+    enc.load_state_dict(state, calibrate=calibrate, kernel_set=kernel_set)
     policy = enc.effective_policy()
     if capture:
         with enc.capture_hidden():
@@ -43,6 +44,7 @@ def run_fixture_on_gpu(name: str, precision="bf16x3", chunk_rows: int | None = N
         "name": name,
         "precision": precision,
         "kernel_set": policy["kernel_set"],
+        "calibration": enc.calibration,
         "terms": policy["terms"],
         "finite": bool(np.isfinite(prune).all() and np.isfinite(rank).all()),
         "prune_max_err": float(np.abs(prune - ref_prune).max()),

@@ -57,7 +57,7 @@ def test_bf16_checkpoint_drops_weight_lo_terms_bit_identically(fixture):
     outs = []
     for flags in (NO_LAYER_FUSION, NO_POLICY_KERNELS):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
-        enc.load_state_dict(state)
+        enc.load_state_dict(state, calibrate=False)
         policy = enc.effective_policy()
         assert policy["terms"] == {"wqkv": 1, "qk": 3, "pv": 3, "attn_out": 1, "wi": 1, "mlp_out": 1}
         assert policy["kernel_set"] == ("bf16-weights" if flags == NO_LAYER_FUSION else "all-terms kernels, cleared lo operands")
@@ -90,7 +90,7 @@ def test_whole_layer_kernel_matches_two_kernel_path(fixture):
     # product); NO_F8: the same launch on (hi, lo) bf16 operands; NO_LAYER_FUSION: two kernels per layer
     for label, flags, kernel_set in (("f8", 0, "f16-f8"), ("layer", NO_F8, "bf16-weights"), ("two", NO_LAYER_FUSION, "bf16-weights")):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
-        enc.load_state_dict(state)
+        enc.load_state_dict(state, calibrate=False)
         assert enc.effective_policy()["kernel_set"] == kernel_set
         enc.profile_enable(True)
         prune, rank, _ = enc.forward_rows(rows)
@@ -130,7 +130,7 @@ def test_layer32_kernel_matches_the_default_kernel(fixture, precision):
     outs = {}
     for label, flags in (("m16", NO_F8), ("m32", LAYER_M32)):
         enc = HipEncoder(dims, device="cuda:0", precision=precision, flags=flags)
-        enc.load_state_dict(state)
+        enc.load_state_dict(state, calibrate=False)
         enc.profile_enable(True)
         prune, rank, _ = enc.forward_rows(rows)
         torch.cuda.synchronize()
@@ -170,7 +170,7 @@ def test_embedding_and_head_inside_the_first_and_last_kernels(fixture):
     for label, flags in (("fused", 0), ("separate", NO_HEAD_FUSION)):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x2", flags=flags,
                          prune_pre_final_norm=bool(meta.get("prune_pre_final_norm", False)))
-        enc.load_state_dict(state)
+        enc.load_state_dict(state, calibrate=False)
         enc.profile_enable(True)
         prune, rank, _ = enc.forward_rows(rows)
         torch.cuda.synchronize()
@@ -217,7 +217,7 @@ def test_panel_path_f16_f8_kernel_sets(fixture, weights):
     outs = {}
     for flags in (PANEL_F8, 0, PANEL_F8_WI, NO_F8):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags, prune_pre_final_norm=pre)
-        enc.load_state_dict(state)
+        enc.load_state_dict(state, calibrate=False)
         assert enc.effective_policy()["kernel_set"] == expected[(weights, flags)]
         enc.profile_enable(True)
         prune, rank, _ = enc.forward_rows(rows)
@@ -266,7 +266,7 @@ def test_tiny_scaled_weight_tensor_keeps_the_bf16_kernel_sets(weights):
         if weights == "bf16":
             state = {k: v.to(torch.bfloat16).to(torch.float32) if any(t in k for t in ("Wqkv", "Wo", "Wi")) else v for k, v in state.items()}
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
-        enc.load_state_dict(state)
+        enc.load_state_dict(state, calibrate=False)
         assert enc.effective_policy()["kernel_set"] == expected[weights], scale
         prune, rank, _ = enc.forward_rows(rows)
         torch.cuda.synchronize()
@@ -309,7 +309,7 @@ def test_activation_beyond_fp16_range_is_loud_on_the_f8_sets_and_fine_on_the_bf1
     outs = {}
     for flags in (0, NO_F8):
         enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flags)
-        enc.load_state_dict(state)
+        enc.load_state_dict(state, calibrate=False)
         outs[flags] = enc.effective_policy()["kernel_set"]
         prune, rank, _ = enc.forward_rows(rows)
         torch.cuda.synchronize()
@@ -348,13 +348,13 @@ def test_overflow_of_the_f8_sets_falls_back_to_the_bf16_sets_instead_of_failing(
         return prune.cpu().numpy(), rank.cpu().numpy()
 
     ref_enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=NO_F8)
-    ref_enc.load_state_dict(state)
+    ref_enc.load_state_dict(state, calibrate=False)
     ref_p, ref_r = run(ref_enc, False)
     ref_enc.close()
     assert np.isfinite(ref_p).all() and np.isfinite(ref_r).all()
 
     enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
-    enc.load_state_dict(state)
+    enc.load_state_dict(state, calibrate=False)
     assert enc.effective_policy()["kernel_set"] == "f16-f8-w" and enc.f8_active()
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
@@ -381,7 +381,7 @@ def test_overflow_of_the_f8_sets_falls_back_to_the_bf16_sets_instead_of_failing(
         if env_no_f8:
             os.environ["OPEN_PROVENCE_NO_F8"] = "1"
         try:
-            return OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state)
+            return OpenProvenceModel(cfg, device="cuda", tokenizer=CharTokenizer(), state_dict=state, calibrate=False)
         finally:
             os.environ.pop("OPEN_PROVENCE_NO_F8", None)
             if old is not None:

@@ -179,13 +179,39 @@ def test_en_gte_varlen_at_bench_size_matches_the_oracle(weights):
     assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
 
 
-def test_large_model_at_2048_matches_the_oracle():
-    """`bench.py --model large --seq-len 2048 --pairs 64` (BASELINE config 4): 25 layers, 64 x 2048 = 1024 row blocks."""
+@pytest.mark.parametrize("weights", ["fp32", "bf16"])
+def test_large_model_at_2048_matches_the_oracle(weights):
+    """`bench.py --model large --seq-len 2048 --pairs 64` (BASELINE config 4): 25 layers, 64 x 2048 = 1024 row blocks; both
+    checkpoint dtypes (tests/golden/bench_checksums.json stores `large|64x2048|bf16` too).  Pairs: first / last and the ones
+    on either side of the XCD-group boundaries (a pair = 16 row blocks = two groups of 8)."""
 
     from open_provence_amd.synthetic import synth_pair_batch
 
-    dims, state, enc = _panel_setup("large", "fp32")
+    dims, state, enc = _panel_setup("large", weights)
     rows = synth_pair_batch(dims, 64, 2048, seed=1234)
-    worst = _run_and_check(enc, dims, state, rows, [0, 63], PANEL_KINDS)
+    worst = _run_and_check(enc, dims, state, rows, [0, 1, 31, 32, 62, 63], PANEL_KINDS)
     enc.close()
     assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
+
+
+@pytest.mark.parametrize("init,weights,kernel_set", [("o1", "fp32", "f16-f8-w"), ("o1", "bf16", "f16-f8"), ("refinit", "fp32", "f16")])
+def test_xsmall_at_2048_matches_the_oracle_on_every_pair(init, weights, kernel_set):
+    """bench.py's `seq_len_2048` sub-record (north_star names seq_len 2048): xsmall dims, 64 pairs x 2048 tokens -- the
+    256-query attention blocks over 32 key tiles, rotary positions up to 2047 -- on the O(1) weights of `--init o1` (both
+    checkpoint dtypes; `xsmall|64x2048|*` in tests/golden/bench_checksums.json) and on the reference-initialised headline
+    weights with the calibrated kernel set.  All 64 pairs."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch, synth_state_dict
+
+    dims = named_dims("xsmall")
+    state = (refinit_state_dict if init == "refinit" else synth_state_dict)(dims, seed=7)
+    if weights == "bf16":
+        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(state)
+    assert enc.effective_policy()["kernel_set"] == kernel_set, enc.calibration
+    rows = synth_pair_batch(dims, 64, 2048, seed=1234)
+    worst = _run_and_check(enc, dims, state, rows, list(range(64)), {"fused_layer_attnout_mlp_qkv", "attn_global", "attn_local"})
+    enc.close()
+    assert worst < (3e-4 if init == "refinit" else 8e-4), worst
