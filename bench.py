@@ -68,6 +68,36 @@ def algorithmic_flops_per_pair(dims: EncoderDims, seq_len: int) -> float:
     return per_token * L + 2.0 * H * H + 2.0 * H * dims.num_labels
 
 
+def fragment_range_list(cu_host: np.ndarray) -> list[tuple[int, int]]:
+    """(start, end) token ranges of the FRAGMENT_TOKENS-token synthetic sentences of every packed row."""
+
+    segs: list[tuple[int, int]] = []
+    for i in range(len(cu_host) - 1):
+        a, b = int(cu_host[i]), int(cu_host[i + 1])
+        segs.extend((lo, min(lo + FRAGMENT_TOKENS, b)) for lo in range(a, b, FRAGMENT_TOKENS))
+    return segs
+
+
+def exchange_plan(rows_all: list, world: int, rank: int, num_labels: int, n_pipes: int = 1):
+    """The multi-GPU exchange of a step, as the product does it (modeling._collect_rows_sharded; reference for WHAT is gathered:
+    standalone.py:3075-3092): rows assigned to ranks by TOKEN count (ShardPlan), payload = one fp32 per FRAGMENT + ranking
+    logits.  -> (plan over fragment counts, this rank's rows, per launch sequence [(rows of this rank, plan of that half)]).
+    With ``n_pipes == 2`` every rank cuts the batch the same way (ShardPlan.split) and each half has its own plan / gather.
+    Pure host logic: tests/test_sharding.py drives it on a world-size-2 gloo group with a stand-in encoder."""
+
+    from open_provence_amd.sharding import ShardPlan
+
+    token_plan = ShardPlan([len(r) for r in rows_all], world, width=1, num_labels=num_labels)
+    frag_counts = [(len(r) + FRAGMENT_TOKENS - 1) // FRAGMENT_TOKENS for r in rows_all]
+    plan = ShardPlan(frag_counts, world, width=1, num_labels=num_labels, shards=token_plan.shards)
+    rows = [rows_all[i] for i in plan.local_rows(rank)]
+    halves = []
+    if n_pipes == 2:
+        for plan_j, rows_j in plan.split(2):
+            halves.append(([rows_all[rows_j[k]] for k in plan_j.local_rows(rank)], plan_j, list(rows_j)))
+    return plan, rows, halves
+
+
 def physical_cores() -> int:
     """Distinct (socket, core) pairs in /proc/cpuinfo (logical CPUs / SMT threads otherwise)."""
 
@@ -350,15 +380,10 @@ def main() -> None:
     else:
         rows_all = synth_pair_batch(dims, args.pairs * world, args.seq_len, seed=1234)
         if grouped:
-            from open_provence_amd.sharding import ShardPlan
-
             # the product's exchange (modeling._collect_rows_sharded): rows assigned by TOKEN count, payload = one fp32
             # per FRAGMENT (the mean keep-probability of a sentence, op_segment_means on the device) + ranking logits.
             # Synthetic sentences: 32 tokens each.
-            token_plan = ShardPlan([len(r) for r in rows_all], world, width=1, num_labels=dims.num_labels)
-            frag_counts = [(len(r) + FRAGMENT_TOKENS - 1) // FRAGMENT_TOKENS for r in rows_all]
-            plan = ShardPlan(frag_counts, world, width=1, num_labels=dims.num_labels, shards=token_plan.shards)
-            rows = [rows_all[i] for i in plan.local_rows(rank)]
+            plan, rows, _ = exchange_plan(rows_all, world, rank, dims.num_labels)
         else:
             rows = rows_all
         n_pairs_rank = len(rows)
@@ -383,19 +408,13 @@ def main() -> None:
     def fragment_ranges(cu_host: np.ndarray) -> torch.Tensor:
         """[S, 2] int32 token ranges of the 32-token sentences of every packed row (device)."""
 
-        segs = []
-        for i in range(len(cu_host) - 1):
-            a, b = int(cu_host[i]), int(cu_host[i + 1])
-            segs.extend((lo, min(lo + FRAGMENT_TOKENS, b)) for lo in range(a, b, FRAGMENT_TOKENS))
-        return torch.tensor(segs, dtype=torch.int32, device=device).reshape(-1, 2)
+        return torch.tensor(fragment_range_list(cu_host), dtype=torch.int32, device=device).reshape(-1, 2)
 
     seg_dev = fragment_ranges(cu_np) if plan is not None else None
     pipes = []
     if n_pipes == 2:
         if plan is not None:
-            halves = []
-            for plan_j, rows_j in plan.split(2):
-                halves.append(([rows_all[rows_j[k]] for k in plan_j.local_rows(rank)], plan_j))
+            halves = [(part_rows, plan_j) for part_rows, plan_j, _rows_j in exchange_plan(rows_all, world, rank, dims.num_labels, 2)[2]]
         else:
             half = len(rows) // 2
             halves = [(rows[:half], None), (rows[half:], None)]
@@ -614,6 +633,10 @@ def main() -> None:
             "policy": policy,  # term masks evaluated per contraction family + the kernel set running them
             "parallelism": f"dp{world} (pairs sharded by token count, on-device fragment means, one RCCL gather of 4 B per fragment + ranking logits)" if world > 1
             else ("single GPU, two independent half-batch launch sequences on CU-partitioned streams" if pipes else "single GPU"),
+            # what the ranks exchange inside the timed step.  Rounds 1-3 gathered 4 B per TOKEN; since round 4 the product's
+            # own exchange is timed (one fp32 per 32-token fragment): N > 1 figures are not comparable across that change
+            "exchange": (f"fragment_means/{FRAGMENT_TOKENS}: one RCCL gather of 4 B per {FRAGMENT_TOKENS}-token fragment + ranking logits "
+                         "(rounds 1-3: 4 B per token)") if grouped else None,
             "algorithmic_gflop_per_pair": flops_pair / 1e9,
             "outputs_finite": finite,
             "output_checksum": checksum,

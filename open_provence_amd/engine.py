@@ -305,6 +305,8 @@ class HipEncoder:
         if changed.value:
             import warnings
 
+            self.fallbacks = int(getattr(self, "fallbacks", 0)) + 1  # reported by process() (timing / performance_trace)
+
             warnings.warn(
                 "open_provence_amd: a forward on the fp16 + e4m3 kernel set returned non-finite values"
                 + (f" ({reason})" if reason else "")

@@ -435,7 +435,7 @@ class _OwnerHub:
             if with_ranges:
                 seg_parts.append(np.asarray(seg_flat, dtype=np.int32) + np.int32(tokens))
                 seg_counts.extend(counts)
-            requests.append((conn, len(cu_np) - 1, sum(counts) if with_ranges else n_tok))
+            requests.append((conn, len(cu_np) - 1, sum(counts) if with_ranges else n_tok, n_tok))
             tokens += n_tok
         ids = np.concatenate([payload[0] for _conn, payload in batch])
         cu = np.concatenate(cu_parts)
@@ -448,7 +448,7 @@ class _OwnerHub:
         rows = [ids[cu[i] : cu[i + 1]].tolist() for i in range(len(cu) - 1)]
         rank, keeps = model._predict_rows_local(rows, None)
         values = np.concatenate([np.asarray(k, dtype=np.float32)[: len(r)] for k, r in zip(keeps, rows)]) if rows else np.zeros(0, np.float32)
-        requests = [(conn, n_rows, tokens) for conn, n_rows, _vals in requests]
+        requests = [(conn, n_rows, n_tok, n_tok) for conn, n_rows, _vals, n_tok in requests]
         return ("done", requests, (rank.to("cpu", torch.float32).numpy().reshape(len(rows), -1), values, False))
 
     def _reply(self, model: Any, launched: tuple) -> None:
@@ -460,11 +460,13 @@ class _OwnerHub:
         try:
             rank, values, reduced = model._collect_packed(what) if kind == "handle" else what
         except Exception as exc:  # noqa: BLE001
-            for conn, _rows, _vals in requests:
+            for conn, _rows, _vals, _tok in requests:
                 conn.send(("error", self.request, f"{type(exc).__name__}: {exc}"))
             return
         row0 = val0 = 0
-        for conn, n_rows, n_vals in requests:
+        for conn, n_rows, n_vals, n_tok in requests:
+            if not reduced:  # the launch fell back to per-token values (_enqueue_packed dropped the ranges): cut by tokens
+                n_vals = n_tok
             conn.send(("out", self.request, (rank[row0 : row0 + n_rows].copy(), values[val0 : val0 + n_vals].copy(), reduced)))
             row0 += n_rows
             val0 += n_vals
@@ -501,6 +503,43 @@ def default_host_workers() -> int:
     return int(max(1, min(31, 2 * usable_cores() - 1)))
 
 
+_MAIN_HIDE_LOCK = threading.Lock()
+
+
+class _main_module_hidden:
+    """While active (and ``enabled``), ``multiprocessing``'s spawn finds nothing to re-import as the children's main module:
+    ``spawn.get_preparation_data`` reads ``__main__.__spec__.name`` / ``__main__.__file__`` when a process is STARTED."""
+
+    def __init__(self, enabled: bool) -> None:
+        self.enabled = enabled
+        self.saved: tuple | None = None
+
+    def __enter__(self) -> None:
+        if not self.enabled:
+            return
+        import sys
+
+        _MAIN_HIDE_LOCK.acquire()
+        main = sys.modules.get("__main__")
+        missing = object()
+        self.saved = (main, getattr(main, "__spec__", missing), getattr(main, "__file__", missing), missing)
+        if main is not None:
+            main.__spec__ = None
+            if hasattr(main, "__file__"):
+                del main.__file__
+
+    def __exit__(self, *_exc: Any) -> None:
+        if not self.enabled:
+            return
+        main, spec, file, missing = self.saved
+        if main is not None:
+            if spec is not missing:
+                main.__spec__ = spec
+            if file is not missing:
+                main.__file__ = file
+        _MAIN_HIDE_LOCK.release()
+
+
 class HostFrontEnd:
     """``workers`` host-stage replicas (no GPU, no model) behind ``model``, whose process owns every forward.
 
@@ -512,7 +551,13 @@ class HostFrontEnd:
     the model's tokenizer (Hugging Face tokenizers are) -- or pass ``tokenizer_factory``, a callable importable by name
     that builds the same tokenizer inside each replica."""
 
-    def __init__(self, model: Any, workers: int | None = None, *, tokenizer_factory: Callable[[], Any] | None = None) -> None:
+    def __init__(self, model: Any, workers: int | None = None, *, tokenizer_factory: Callable[[], Any] | None = None,
+                 import_main: bool = True) -> None:
+        """``import_main=False``: the workers do NOT import the caller's ``__main__`` module (multiprocessing's spawn does
+        by default, so that objects defined there unpickle -- and a script without an ``if __name__ == "__main__"`` guard runs
+        again in every worker).  What ``OpenProvenceModel.process`` uses when it starts a front-end by itself; callables
+        defined in ``__main__`` cannot be sent to such workers."""
+
         import pickle
 
         import torch.multiprocessing as mp
@@ -535,13 +580,14 @@ class HostFrontEnd:
             raise TypeError("HostFrontEnd sends the model's tokenizer to its worker processes and it cannot be pickled "
                             f"({type(exc).__name__}: {exc}); pass tokenizer_factory=<a module-level function that builds it>") from exc
         self._procs, conns = [], []
-        for rank in range(self.world):
-            mine, theirs = ctx.Pipe(duplex=True)
-            proc = ctx.Process(target=_serve_host_stages, args=(rank, self.world, theirs, spec), daemon=True)
-            proc.start()
-            theirs.close()
-            self._procs.append(proc)
-            conns.append(mine)
+        with _main_module_hidden(not import_main):
+            for rank in range(self.world):
+                mine, theirs = ctx.Pipe(duplex=True)
+                proc = ctx.Process(target=_serve_host_stages, args=(rank, self.world, theirs, spec), daemon=True)
+                proc.start()
+                theirs.close()
+                self._procs.append(proc)
+                conns.append(mine)
         for conn in conns:
             kind, _request, _payload = conn.recv()  # "ready": the replica has its tokenizer
             if kind != "ready":

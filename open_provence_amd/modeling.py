@@ -82,8 +82,14 @@ class ProcessPerformanceTrace:
     fragment_split_seconds: float = 0.0
     fragment_decode_seconds: float = 0.0
 
-    def as_dict(self) -> dict[str, float]:
-        return {name: float(getattr(self, name)) for name in self.__dataclass_fields__}
+    def as_dict(self) -> dict[str, Any]:
+        """The reference's ten stage timers (ref :377-404) + what the MI355X path adds when it has something to say
+        (``runtime``: the kernel set the forwards ran on, how often the range guard left an fp16-plane set, host-stage
+        replicas of the call) -- extra keys, the ten fields are always there."""
+
+        out: dict[str, Any] = {name: float(getattr(self, name)) for name in self.__dataclass_fields__}
+        out.update(getattr(self, "runtime", None) or {})
+        return out
 
 
 _NO_PROBS = np.zeros(0, dtype=np.float32)
@@ -734,7 +740,7 @@ class OpenProvenceModel:
         return self._enqueue_packed(*self._pack_launch(rows, segments))
 
     def _enqueue_packed(self, ids_np: np.ndarray, cu_np: np.ndarray, max_len: int, seg_flat: np.ndarray | None,
-                        seg_counts: list[int] | None) -> dict[str, Any]:
+                        seg_counts: list[int] | None, reuse_slot: int | None = None) -> dict[str, Any]:
         """Enqueue one forward over packed rows (:meth:`_pack_launch`); also what the range guard of the fp16 + e4m3
         kernel sets repeats, see :meth:`_guard_launch`."""
 
@@ -745,7 +751,13 @@ class OpenProvenceModel:
         if n_rows == 0:  # (more ranks than rows) nothing to enqueue here; the gather still runs on every rank
             return {"event": None, "pool": None, "total": 0, "rows": 0, "cu": cu_np, "seg_counts": [] if seg_counts is not None else None,
                     "alive": None, "shard": shard, "retry": None}
-        slot = self.__dict__["_staging_slot"] = (self.__dict__.get("_staging_slot", -1) + 1) % 2
+        if reuse_slot is not None:
+            # the synchronous repeat of a guarded launch re-uses THAT launch's staging slot (its values have been read) and
+            # leaves the rotation alone: with A on slot 0 and B still in flight on slot 1, a repeat of A that advanced the
+            # rotation would hand slot 1 to the next launch while B's results are uncollected there
+            slot = reuse_slot
+        else:
+            slot = self.__dict__["_staging_slot"] = (self.__dict__.get("_staging_slot", -1) + 1) % 2
         pool = self._staging(slot, total, n_rows)
         dev = self._runtime_device
         np.copyto(pool["ids_np"][:total], ids_np)
@@ -773,7 +785,7 @@ class OpenProvenceModel:
         event.record(torch.cuda.current_stream(dev))
         return {"event": event, "pool": pool, "total": total, "rows": n_rows, "cu": cu_np, "seg_counts": seg_counts,
                 "alive": (ids_dev, cu_dev, keep_dev, rank_dev, seg_dev, means_dev), "shard": shard, "retry": retry,
-                "f8": self.encoder.f8_active()}
+                "f8": self.encoder.f8_active(), "slot": slot}
 
     def _guard_launch(self, handle: dict[str, Any]) -> dict[str, Any]:
         """Range guard of the fp16 + e4m3 kernel sets for a pipelined launch (the launch has completed): when its
@@ -792,7 +804,7 @@ class OpenProvenceModel:
         if self.encoder.f8_active():
             return handle  # (nothing to fall back to: the caller reports the NaN)
         handle["alive"] = None
-        again = self._enqueue_packed(*handle["retry"])
+        again = self._enqueue_packed(*handle["retry"], reuse_slot=handle.get("slot"))
         again["shard"] = handle.get("shard")
         again["event"].synchronize()
         return again
@@ -1398,8 +1410,9 @@ class OpenProvenceModel:
                 # probability fails `> threshold`, standalone.py:3130) -- said once, not raised: a drop-in must not fail
                 # where the reference returns, and a raise on one rank of a process group would strand the others.
                 self.__dict__["_nan_warned"] = True
-                LOGGER.warning("the forward returned NaN for a (query, context) block on fp32-range kernels: the checkpoint "
-                               "holds non-finite weights or the inputs overflow fp32; results follow the reference (NaN scores)")
+                LOGGER.warning("the forward returned NaN for a (query, context) block on kernel set %r (every set with an fp16 operand "
+                               "plane has been left by now): the checkpoint holds non-finite weights or the inputs overflow fp32; results "
+                               "follow the reference (NaN scores)", self.encoder.effective_policy()["kernel_set"] if self._forward_is_native() else "replaced forward")
             states[(job["query_idx"], job["context_idx"])].raw_blocks.append(
                 (
                     job["block_idx"],
@@ -1527,10 +1540,15 @@ class OpenProvenceModel:
         # processes run the host stages, this process runs every forward (frontend.py).  The environment's counterpart of
         # the reference's DataLoader worker processes (standalone.py:3589) for callers that do not construct a front-end;
         # a request whose arguments cannot be pickled (a lambda as sentence_splitter) takes the in-process path below.
-        replicas = os.environ.get("OPEN_PROVENCE_HOST_REPLICAS", "")
-        if (replicas and replicas != "0" and not getattr(self, "_dist", None) and self.__dict__.get("_remote_forward") is None
+        # Round 5: without the variable too -- ``preprocess_workers=N`` / ``torch_dataloader_kwargs["num_workers"]`` ask for N such
+        # worker PROCESSES (what the reference's parameter means), and a request of >= 2000 contexts starts them by itself
+        # (the reference's auto rule, standalone.py:2588-2596), whenever the tokenizer and the splitter can be sent to a
+        # process that does not import the caller's __main__; threads otherwise.  OPEN_PROVENCE_HOST_REPLICAS=0 keeps
+        # everything in this process.
+        replicas, implicit = self._front_end_request(context, preprocess_workers, torch_dataloader_kwargs)
+        if (replicas and not getattr(self, "_dist", None) and self.__dict__.get("_remote_forward") is None
                 and not isinstance(context, str)):
-            routed = self._process_through_front_end(replicas, dict(
+            routed = self._process_through_front_end(replicas, implicit, dict(
                 question=question, context=context, title=title, first_line_as_title=first_line_as_title, batch_size=batch_size,
                 threshold=threshold, always_select_title=always_select_title, reorder=reorder, top_k=top_k,
                 sentence_splitter=sentence_splitter, language=language, use_best_reranker_score=use_best_reranker_score,
@@ -1564,9 +1582,44 @@ class OpenProvenceModel:
             if gc_was_enabled:
                 gc.enable()
 
-    def _process_through_front_end(self, replicas: str, call: dict[str, Any]) -> dict[str, Any] | None:
-        """``process()`` under OPEN_PROVENCE_HOST_REPLICAS: the request through a ``HostFrontEnd`` that lives on the model
-        (started on first use, restarted when the number changes).  None = take the in-process path (few contexts, or
+    IMPLICIT_FRONT_END_CONTEXTS = 2000  # the reference's auto rule starts workers from 2000 jobs on (standalone.py:2591-2592)
+    WORKER_REQUEST_MIN_CONTEXTS = 256   # preprocess_workers=N on a smaller request: threads (process start-up is seconds)
+
+    @staticmethod
+    def _count_contexts(ctx: Any) -> int:
+        return sum(len(c) if isinstance(c, (list, tuple)) else 1 for c in ctx) if isinstance(ctx, (list, tuple)) else 1
+
+    def _front_end_request(self, context: Any, preprocess_workers: int | None, loader_kwargs: Mapping[str, Any] | None) -> tuple[str, bool]:
+        """-> (replicas: "" = none, "auto" or a number; implicit: not asked for through OPEN_PROVENCE_HOST_REPLICAS)."""
+
+        env = os.environ.get("OPEN_PROVENCE_HOST_REPLICAS", "")
+        if env:
+            return ("" if env == "0" else env), False
+        if isinstance(context, str):
+            return "", True
+        asked = preprocess_workers
+        if asked is None and loader_kwargs and "num_workers" in loader_kwargs:
+            asked = int(loader_kwargs["num_workers"])
+        n_contexts = self._count_contexts(context)
+        if asked is not None:
+            return (str(int(asked)) if int(asked) > 0 and n_contexts >= self.WORKER_REQUEST_MIN_CONTEXTS else ""), True
+        if os.getenv("OPEN_PROVENCE_PREPROCESS_WORKERS"):
+            return "", True  # (that variable asks for worker THREADS, as before)
+        return ("auto" if n_contexts >= self.IMPLICIT_FRONT_END_CONTEXTS else ""), True
+
+    @staticmethod
+    def _lives_in_main(obj: Any) -> bool:
+        """A callable (or a mapping of them) defined in the caller's ``__main__``: a worker that does not import that module
+        cannot resolve it."""
+
+        values = obj.values() if isinstance(obj, Mapping) else [obj]
+        return any(callable(v) and getattr(v, "__module__", None) in ("__main__", "__mp_main__") for v in values)
+
+    def _process_through_front_end(self, replicas: str, implicit: bool, call: dict[str, Any]) -> dict[str, Any] | None:
+        """``process()`` through a ``HostFrontEnd`` that lives on the model (started on first use, restarted when the
+        number changes) -- asked for by OPEN_PROVENCE_HOST_REPLICAS, or ``implicit``: by ``preprocess_workers=`` / the
+        size of the request; implicit front-ends do not import the caller's ``__main__`` in their workers (a script without an
+        ``if __name__ == "__main__"`` guard would run again in each).  None = take the in-process path (few contexts, or
         arguments that cannot be sent to worker processes)."""
 
         import pickle
@@ -1577,10 +1630,12 @@ class OpenProvenceModel:
             workers = default_host_workers() if replicas == "auto" else int(replicas)
         except ValueError:
             return None
-        ctx = call["context"]
-        n_contexts = sum(len(c) if isinstance(c, (list, tuple)) else 1 for c in ctx) if isinstance(ctx, (list, tuple)) else 1
+        n_contexts = self._count_contexts(call["context"])
         if workers < 1 or n_contexts < 4 * workers:
             return None  # (a replica's fixed cost per request is not worth a handful of contexts)
+        if implicit and (self._lives_in_main(call.get("sentence_splitter")) or self._lives_in_main(call.get("debug_messages"))
+                         or not self._forward_is_native()):
+            return None  # (a replaced forward -- tests, experiments -- stays in the process that replaced it)
         try:
             pickle.dumps({k: v for k, v in call.items() if k not in ("question", "context")})
         except Exception:
@@ -1596,12 +1651,27 @@ class OpenProvenceModel:
             if self.__dict__.get("_front_end_unavailable"):
                 return None
             try:
-                front = self.__dict__["_host_front_end"] = HostFrontEnd(self, workers=workers)
-            except TypeError as exc:  # the tokenizer cannot be sent to worker processes
+                front = self.__dict__["_host_front_end"] = HostFrontEnd(self, workers=workers, import_main=not implicit)
+            except Exception as exc:  # the tokenizer cannot be sent to worker processes, or a worker failed to start
                 self.__dict__["_front_end_unavailable"] = True
-                LOGGER.warning("OPEN_PROVENCE_HOST_REPLICAS ignored: %s", exc)
+                self.__dict__["_host_front_end"] = None
+                LOGGER.warning("host front-end unavailable (%s: %s): process() runs in this process", type(exc).__name__, exc)
                 return None
-        return front.process(**call)
+        try:
+            return front.process(**call)
+        except (EOFError, BrokenPipeError, ConnectionError, OSError, RuntimeError) as exc:
+            if isinstance(exc, RuntimeError) and "worker process has gone" not in str(exc):
+                raise  # an error of the request itself (the replicas report those by message): the caller's to see
+            # a replica died: one request is not worth a process() that fails for good -- drop the front-end (its workers
+            # with it), remember not to restart it, and run this and every later request in-process
+            LOGGER.warning("host front-end lost a worker (%s: %s): closed, process() runs in this process from now on", type(exc).__name__, exc)
+            try:
+                front.close()
+            except Exception:
+                pass
+            self.__dict__["_host_front_end"] = None
+            self.__dict__["_front_end_unavailable"] = True
+            return None
 
     def _process_impl(
         self,
@@ -1863,6 +1933,15 @@ class OpenProvenceModel:
             total_seconds=perf_counter() - start_total,
             **timing,
         )
+        runtime: dict[str, Any] = {}
+        if self._forward_is_native() and getattr(self, "encoder", None) is not None:
+            runtime["kernel_set"] = self.encoder.effective_policy()["kernel_set"]
+            runtime["fallback_from_f8"] = int(getattr(self.encoder, "fallbacks", 0))
+        transport = (getattr(self, "_dist", None) or {}).get("transport")
+        if transport is not None and hasattr(transport, "conns"):  # the owner of a host-mode front-end
+            runtime["host_replicas"] = len(transport.conns)
+        if runtime:
+            object.__setattr__(trace, "runtime", runtime)  # (frozen dataclass: an attribute beside its ten fields)
         if debug_callback is not None:
             debug_callback(
                 "[OpenProvenceModel] Timing: "

@@ -105,6 +105,44 @@ def test_host_front_end_on_the_gpu_equals_the_plain_call(monkeypatch):
             assert routed[key] == want[key], key
 
 
+def test_process_starts_host_replicas_by_itself(monkeypatch):
+    """Round 5: no environment variable needed.  ``preprocess_workers=N`` on a request of >= 256 contexts, and ANY request of
+    >= 2000 contexts (the reference's auto rule, standalone.py:2588-2596), run their host stages on replicas that do not
+    import the caller's ``__main__``; the result equals the in-process call's field for field, ``timing`` says how it ran."""
+
+    from open_provence_amd import frontend
+
+    monkeypatch.delenv("OPEN_PROVENCE_HOST_REPLICAS", raising=False)
+    monkeypatch.setattr(frontend, "default_host_workers", lambda: 3)  # (the auto count of the box would start 31 processes)
+    model, _meta = _g3_model()
+    words = "the tower is tall boats carry fish and salt to north city harbour many years ago it was new".split()
+    contexts = [
+        " ".join(" ".join(words[(i * 5 + s * 3 + k) % len(words)] for k in range(4 + (i + s) % 5)).capitalize() + "." for s in range(1 + i % 6))
+        for i in range(2100)
+    ]
+    call = dict(question="which boats carry salt?", sentence_splitter=period_splitter, show_progress=False,
+                return_sentence_metrics=True, return_sentence_texts=True, threshold=0.4)
+    monkeypatch.setenv("OPEN_PROVENCE_HOST_REPLICAS", "0")
+    want_small, want_big = model.process(context=contexts[:300], **call), model.process(context=contexts, **call)
+    assert "host_replicas" not in want_big["timing"] and want_big["timing"]["kernel_set"]
+    monkeypatch.delenv("OPEN_PROVENCE_HOST_REPLICAS")
+    try:
+        got_small = model.process(context=contexts[:300], preprocess_workers=2, **call)   # asked for: two worker processes
+        assert got_small["timing"]["host_replicas"] == 2 and got_small["timing"]["fallback_from_f8"] == 0
+        assert model.process(context=contexts[:100], preprocess_workers=2, **call)["timing"].get("host_replicas") is None  # threads
+        got_big = model.process(context=contexts, **call)                                  # by size alone
+        assert got_big["timing"]["host_replicas"] == 3
+        assert got_big["performance_trace"].as_dict() == got_big["timing"]
+    finally:
+        front = model.__dict__.get("_host_front_end")
+        if front is not None:
+            front.close()
+    for got, want in ((got_small, want_small), (got_big, want_big)):
+        for key in want:
+            if key not in ("timing", "performance_trace"):
+                assert got[key] == want[key], key
+
+
 def test_padded_forward_boundary():
     from open_provence_amd.config import OpenProvenceConfig
     from open_provence_amd.modeling import OpenProvenceForTokenClassification, OpenProvenceModel

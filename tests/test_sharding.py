@@ -415,3 +415,69 @@ def test_a_failing_rank_does_not_strand_the_others_in_the_gather(tmp_path, world
             assert rep["outcome"].startswith("own:") and "on purpose" in rep["outcome"], rep
         else:
             assert rep["outcome"].startswith("peer:") and f"{bad}: ValueError" in rep["outcome"], rep
+
+
+# ---- bench.py --gpus N: the exchange a timed step performs (exchange_plan -> fragment means -> ShardPlan.gather) -----------
+def _bench_exchange_worker(rank, world, port, rows_all, n_pipes, out_path):
+    """What bench.py's step does between the forward and the end of the step, with a stand-in encoder (keep-probability of a
+    token = a function of its id; ranking logit of a row = a function of its ids): per-fragment means of THIS rank's rows,
+    one gather per launch sequence.  Rank 0 stores what arrived, in the order the plan restores."""
+
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan, rows, halves = bench.exchange_plan(rows_all, world, rank, 1, n_pipes)
+        parts = [(part_rows, part_plan, rows_j) for part_rows, part_plan, rows_j in halves] if n_pipes == 2 else [(rows, plan, list(range(len(rows_all))))]
+        collected = []
+        for part_rows, part_plan, rows_j in parts:
+            keep = np.array([(t % 97) / 97.0 for r in part_rows for t in r], dtype=np.float32)
+            cu = np.zeros(len(part_rows) + 1, dtype=np.int64)
+            for i, r in enumerate(part_rows):
+                cu[i + 1] = cu[i] + len(r)
+            means = torch.tensor([float(keep[a:b].mean()) for a, b in bench.fragment_range_list(cu)], dtype=torch.float32)
+            rank_logits = torch.tensor([[float(sum(r) % 1013)] for r in part_rows], dtype=torch.float32).reshape(len(part_rows), 1)
+            got = part_plan.gather(means, rank_logits, dst=0)
+            if rank == 0:
+                vals, rank_all = got
+                flat, pcu = vals.reshape(-1), part_plan.cu
+                collected.append({"rows": rows_j, "means": [flat[pcu[i] : pcu[i + 1]].clone() for i in range(len(rows_j))], "rank": rank_all.clone()})
+            else:
+                assert got is None
+        if rank == 0:
+            torch.save(collected, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_pipes", [(2, 1), (2, 2), (3, 2)])
+def test_bench_exchange_lands_in_row_order_for_unequal_rows(tmp_path, world, n_pipes):
+    """bench.py:exchange_plan (rows by token count -> plan over fragment counts -> split(2)) had only ever run on a one-rank
+    group; here world-size 2 / 3 on gloo with rows of very different lengths: every row's fragment means and ranking logit
+    arrive on rank 0 at the row's own position.  Reference for what is gathered: standalone.py:3075-3092."""
+
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+
+    rng = np.random.default_rng(11)
+    lengths = [512, 33, 1, 700, 64, 65, 31, 300, 128, 2, 450, 97, 512]
+    rows_all = [rng.integers(1, 5000, size=n).tolist() for n in lengths]
+    out_path = str(tmp_path / "exchange.pt")
+    mp.spawn(_bench_exchange_worker, args=(world, _free_port(), rows_all, n_pipes, out_path), nprocs=world, join=True)
+    collected = torch.load(out_path)
+    seen = []
+    for part in collected:
+        for k, row in enumerate(part["rows"]):
+            ids = np.array(rows_all[row])
+            keep = ((ids % 97) / 97.0).astype(np.float32)
+            want = [float(keep[a : a + bench.FRAGMENT_TOKENS].mean()) for a in range(0, len(ids), bench.FRAGMENT_TOKENS)]
+            assert part["means"][k].tolist() == pytest.approx(want, abs=0, rel=0) or np.array_equal(part["means"][k].numpy(), np.array(want, dtype=np.float32)), row
+            assert float(part["rank"][k, 0]) == float(sum(rows_all[row]) % 1013), row
+            seen.append(row)
+    assert sorted(seen) == list(range(len(rows_all)))  # every row exactly once across the launch sequences
