@@ -33,29 +33,40 @@ def test_bench_json_line_contract():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 1e-6
-    # the headline is the fp32-valued checkpoint on the fp16 + e4m3 kernel set (one launch sequence); the same command
-    # times the bf16-rounded weights as a sub-record, and reports the shader clock it held
-    assert line["config"]["checkpoint_dtype"] == "fp32" and line["config"]["policy"]["kernel_set"] == "f16-f8-w"
-    assert line["config"]["parallelism"] == "single GPU" and "one_pipeline" not in line
+    # Round 5: the headline is the fp32-valued checkpoint in the REFERENCE'S INITIALISATION (SURVEY.md 8d's recipe), on the
+    # kernel set the load-time calibration chose for it -- "f16", single-pass fp16 operands; the same command times the
+    # bf16-rounded weights and the O(1) worst-case weights (the headline of rounds 1-4: the all-terms sets) as sub-records
+    cfg = line["config"]
+    assert cfg["checkpoint_dtype"] == "fp32" and cfg["weights_init"] == "refinit" and cfg["policy"]["kernel_set"] == "f16"
+    cal = cfg["calibration"]
+    assert cal["chosen_set"] == "f16" and cal["default_set"] == "f16-f8-w" and cal["reference_set"] == "bf16x3"
+    assert cal["candidates"]["f16"] <= cal["tolerance"] < cal["candidates"]["bf16"]
+    assert "two independent" in cfg["parallelism"] and line["one_pipeline"]["value"] > 0
     other = line["bf16_checkpoint"]
-    assert other["value"] > 0 and other["policy"]["kernel_set"] == "f16-f8" and other["checkpoint_dtype"] == "bf16"
-    # the label says what ran (fp16 + e4m3 split operands), not "bf16"; every frac has the clock it was measured at beside
-    # it, taken in a SEPARATE probed pass whose own step time is on the record
-    assert "fp16" in line["dtype"] and "e4m3" in line["dtype"] and "fp16" in other["dtype"]
+    assert other["value"] > 0 and other["policy"]["kernel_set"] == "f16" and other["checkpoint_dtype"] == "bf16"
+    worst = line["worst_case_o1_weights"]
+    assert worst["fp32"]["policy"]["kernel_set"] == "f16-f8-w" and worst["bf16"]["policy"]["kernel_set"] == "f16-f8"
+    assert worst["fp32"]["calibration"]["chosen_set"] == "f16-f8-w" and worst["fp32"]["value"] > 0 and worst["fp32"]["roofline"]["frac"] > 0
+    # the label says what ran, not "bf16"; every frac has the clock it was measured at beside it, taken in a SEPARATE probed
+    # pass whose own step time is on the record
+    assert "fp16 single pass" in line["dtype"] and "e4m3" in worst["fp32"]["dtype"] and "fp16" in other["dtype"]
     assert 0.5 < line["shader_clock_ghz"]["value"] < 3.0 and line["shader_clock_ghz"]["ms_per_step_with_probe"] > 0
     assert 0.5 < roof["shader_clock_ghz"] < 3.0 and 0.5 < other["shader_clock_ghz"] < 3.0
     assert 0.5 < line["seq_len_2048"]["shader_clock_ghz"] < 3.0
-    for rec in (line["config"], other, line["seq_len_2048"]):
+    for rec in (cfg, other, line["seq_len_2048"], worst["fp32"], worst["bf16"]):
         assert {"prune_sum", "prune_abs_sum", "rank_sum"} <= set(rec["output_checksum"])
         # (8 pairs: no stored checksum for this workload; the default workloads compare with tests/golden/bench_checksums.json)
         assert rec["output_checksum"]["stored"].startswith("none")
     assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
-    # the panel path (base dims) as a sub-record, both checkpoint dtypes: default flags = the (hi, lo) bf16 kernel sets
+    # the panel path (base dims) as a sub-record, both checkpoint dtypes: calibrated (default), what op_weights_ready selects
+    # without calibration, and the calibration at 2e-4 (which takes the single-pass fp16 set at this depth)
     base = line["base_model"]
-    # (the Wi GEMM of an fp32-valued checkpoint takes the fp16 + e4m3 format by default: kernel set "bf16x3+wi-f16-f8-w")
-    assert base["model"] == "base" and base["fp32_checkpoint"]["kernel_set"] == "bf16x3+wi-f16-f8-w" and base["bf16_checkpoint"]["kernel_set"] == "bf16-weights"
-    assert base["fp32_checkpoint"]["value"] > 0 and base["bf16_checkpoint"]["value"] > 0
-    assert "bf16" in base["fp32_checkpoint"]["dtype"] and 0.5 < base["fp32_checkpoint"]["shader_clock_ghz"] < 3.0
+    assert base["model"] == "base" and base["weights_init"] == "refinit"
+    for wdt, uncal in (("fp32_checkpoint", "bf16x3+wi-f16-f8-w"), ("bf16_checkpoint", "bf16-weights")):
+        rec = base[wdt]
+        assert rec["value"] > 0 and rec["calibration"]["chosen_set"] == rec["kernel_set"] and 0.5 < rec["shader_clock_ghz"] < 3.0
+        assert rec["uncalibrated"]["kernel_set"] == uncal and rec["uncalibrated"]["calibration"] is None
+        assert rec["calibrate_2e-4"]["kernel_set"] == "f16" and rec["calibrate_2e-4"]["value"] > rec["uncalibrated"]["value"]
 
 
 @pytest.mark.gpu
@@ -67,7 +78,7 @@ def test_bench_two_launch_sequences_with_the_bf16_kernel_sets():
 
     proc = subprocess.run(
         [sys.executable, str(REPO_ROOT / "bench.py"), "--pairs", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-         "--no-long", "--no-base", "--no-other-dtype", "--weights", "bf16"],
+         "--no-long", "--no-base", "--no-other-dtype", "--no-worst-case", "--init", "o1", "--weights", "bf16"],
         capture_output=True, text=True, timeout=600, env={**os.environ, "OPEN_PROVENCE_NO_F8": "1"},
     )
     assert proc.returncode == 0, proc.stderr[-2000:]
@@ -84,7 +95,7 @@ def test_bench_multi_gpu_code_path_on_a_one_rank_group():
 
     proc = subprocess.run(
         [sys.executable, str(REPO_ROOT / "bench.py"), "--pairs", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-         "--no-long", "--no-base", "--exercise-gather"],
+         "--no-long", "--no-base", "--no-worst-case", "--exercise-gather"],
         capture_output=True, text=True, timeout=600,
     )
     assert proc.returncode == 0, proc.stderr[-2000:]

@@ -26,8 +26,8 @@ PANEL_F8_WI = 4096      # OP_FLAG_PANEL_F8_WI: that format in the Wi GEMM alone 
 @pytest.mark.parametrize("fixture", ["g1_xsmall", "g2_gte_varlen"])
 @pytest.mark.parametrize("precision", ["bf16x2", "bf16"])
 def test_curated_kernel_set_equals_cleared_operands(fixture, precision):
-    fast = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True, flags=NO_LAYER_FUSION)
-    slow = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True, flags=NO_POLICY_KERNELS)
+    fast = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True, flags=NO_LAYER_FUSION, calibrate=False)
+    slow = run_fixture_on_gpu(fixture, precision, capture=False, return_outputs=True, flags=NO_POLICY_KERNELS, calibrate=False)
     assert fast["kernel_set"] in ("bf16-weights", "bf16")
     assert slow["kernel_set"].startswith("all-terms")
     assert fast["terms"] == slow["terms"]
