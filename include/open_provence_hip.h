@@ -175,7 +175,14 @@ enum op_kernel_set {
   OP_KS_BF16X3_WI_F8 = 5,
   OP_KS_BF16_WEIGHTS_WI_F8 = 6,
   OP_KS_F16 = 7,
-  OP_KS_COUNT = 8
+  /* panel path (hidden 512 / 768) only: the attention side of a layer (q / k / v projection, attention, output projection)
+   * on set 7, its MLP (LayerNorm(mlp_norm), Wi GEMM + GeGLU, MLP output projection) in the fp16 + e4m3 format of set 4
+   * (F16_MLP_F8_W: the weights' lo part too) or of set 3 (F16_MLP_F8).  On weights of a trained checkpoint's scale the
+   * MLP's two contractions carry ~6 x the error of the other four families together (scripts/family_error_probe.py), and
+   * they are 75 % of the linear FLOPs: ~1.75 / ~1.4 MFMA units per product. */
+  OP_KS_F16_MLP_F8_W = 8,
+  OP_KS_F16_MLP_F8 = 9,
+  OP_KS_COUNT = 10
 };
 
 /* Pin the kernel set the forward runs on (OP_KS_AUTO: un-pin).  A set with fewer product terms than the loaded

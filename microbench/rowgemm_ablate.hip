@@ -221,11 +221,25 @@ int main() {
 #else
   constexpr int kF8 = 0;
 #endif
+  // -DABL_WAVES=8: the 8 waves x 16 rows form (two waves per SIMD; what the single-pass sets run); -DABL_H16: fp16 operands
+  // (kernel set "f16"; ABL_T = 0)
+#ifndef ABL_WAVES
+#define ABL_WAVES 4
+#endif
+#ifdef ABL_H16
+  constexpr bool kH16 = true;
+#else
+  constexpr bool kH16 = false;
+#endif
+#ifndef ABL_MF
+#define ABL_MF (ABL_WAVES == 8 ? 1 : 2)
+#endif
+  constexpr int kMF = ABL_MF, kOLO = ABL_T ? 7 : 0;
   auto launch = [&]() {
     if (ABL_LAYER == 2)
-      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, ABL_T, ABL_T, 7, 4, 2, ABL_T, ABL_T, kF8>), dim3(R / 128), dim3(256), 0, 0, p);
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_QKV, RP_MLP, ABL_T, ABL_T, kOLO, ABL_WAVES, kMF, ABL_T, ABL_T, kF8, kH16>), dim3(R / (ABL_WAVES * 16 * kMF)), dim3(ABL_WAVES * 64), 0, 0, p);
     else
-      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, ABL_T, 0, 0, 4, 2, ABL_T, ABL_T, kF8>), dim3(R / 128), dim3(256), 0, 0, p);
+      hipLaunchKernelGGL((rowgemm_kernel<KS, RE_NONE, RP_MLP, ABL_T, 0, 0, ABL_WAVES, kMF, ABL_T, ABL_T, kF8, kH16>), dim3(R / (ABL_WAVES * 16 * kMF)), dim3(ABL_WAVES * 64), 0, 0, p);
   };
 #endif
 #else

@@ -33,10 +33,11 @@ OP_POOL_CLS, OP_POOL_MEAN = 0, 1
 # enum op_kernel_set (op_effective_policy / op_select_kernel_set / op_calibrate)
 OP_KS_AUTO = -1
 KERNEL_SET_NAMES = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", 4: "f16-f8-w", 5: "bf16x3+wi-f16-f8-w",
-                    6: "bf16-weights+wi-f16-f8", 7: "f16", -1: "all-terms kernels, cleared lo operands"}
+                    6: "bf16-weights+wi-f16-f8", 7: "f16", 8: "f16+mlp-f16-f8-w", 9: "f16+mlp-f16-f8",
+                    -1: "all-terms kernels, cleared lo operands"}
 KERNEL_SET_IDS = {name: number for number, name in KERNEL_SET_NAMES.items() if number >= 0}
 # kernel sets with an fp16 operand plane: an activation beyond fp16's range comes out as NaN (range guard in engine.py)
-FP16_PLANE_SETS = ("f16-f8", "f16-f8-w", "bf16x3+wi-f16-f8-w", "bf16-weights+wi-f16-f8", "f16")
+FP16_PLANE_SETS = ("f16-f8", "f16-f8-w", "bf16x3+wi-f16-f8-w", "bf16-weights+wi-f16-f8", "f16", "f16+mlp-f16-f8-w", "f16+mlp-f16-f8")
 
 LIB_NAME = "libopenprovence_hip.so"
 

@@ -106,6 +106,8 @@ struct op_handle {
   int default_set = 0;             // the kernel set the default selection gives for this checkpoint (valid once resolved)
   bool f16_unfit = false;          // some weight TENSOR sits on fp16's subnormal grid: no kernel set with an fp16 weight plane
   bool wi_f8 = false;              // panel path, OP_FLAG_PANEL_F8_WI: the Wi GEMM (and its LayerNorm) in the fp16 + e4m3 format
+  bool mlp_f8 = false;             // panel path, kernel sets 8 / 9: pi = PI_F16 for the attention side, the whole MLP in the fp16 + e4m3 format
+  bool mlp_wlo = false;            // ... with the weights' lo part (set 8)
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
   int n_cus = 256;          // compute units of the device (hipDeviceProp multiProcessorCount)
@@ -637,7 +639,10 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       // ---- panel path (hidden % 256 == 0): LayerNorm -> fragment-packed planes, k-streamed panel GEMMs ----
       const dim3 ln_grid((unsigned)(r_pad / 16));
       const bool pf8 = o_f8;  // kernel sets 3 / 4: activations as fp16 pieces + e4m3 pieces (x 2^12) of their lo part
-      const bool wlo8 = h->pi == opl::PI_F16_F8_W || (h->wi_f8 && h->pi == opl::PI_ALL_TERMS);
+      // kernel sets 8 / 9: the attention side on the "f16" kernels (pi = PI_F16), the MLP -- LayerNorm(mlp_norm), Wi + GeGLU
+      // with h as fp16 + e4m3 pieces, MLP output projection -- on the fp16 + e4m3 kernels of sets 4 / 3
+      const bool mlp8 = f16 && h->mlp_f8;
+      const bool wlo8 = h->pi == opl::PI_F16_F8_W || (h->wi_f8 && h->pi == opl::PI_ALL_TERMS) || (mlp8 && h->mlp_wlo);
       // OP_FLAG_PANEL_F8_WI: the format in the Wi GEMM alone -- its LayerNorm writes fp16 + e4m3 pieces, its epilogue
       // writes h as the (hi, lo) bf16 pieces the MLP output projection's kernel reads
       auto layer_norm_fp = [&](const float* w, bool with_lo, bool clear, bool f8_here = false) -> int {
@@ -660,7 +665,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         if (clear) OP_TRY(clear_lo(L, ws.ln_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
         return OP_OK;
       };
-      auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles, bool f8_here = false) -> int {
+      auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles, bool f8_here = false, bool f8_full = false) -> int {
         OP_TRY(L.begin(kind));
         PanelParams q = pp;
         q.n_tiles = n_tiles;
@@ -669,6 +674,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         const unsigned groups = (per_xcd + q.row_group - 1) / q.row_group;
         const dim3 grid(8u * groups * (unsigned)q.row_group * (unsigned)n_tiles);  // XCD-aware block map: see panel_gemm_kernel
         const bool ok = f8_here ? opl::launch_panel_f8(st, q, 103, wlo8, grid)
+                        : f8_full ? opl::launch_panel_f8(st, q, epi, wlo8, grid)
                         : pf8   ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
                                 : (epi == 102 ? opl::launch_panel_qkv(st, q, h->pi, grid) : opl::launch_panel(st, q, epi, h->pi, grid));
         if (!ok) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
@@ -713,25 +719,25 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       pp.ld_out = H;
       OP_TRY(panel(PK_GEMM_ATTN_OUT, 100, pp, H / 256));
       const bool wi8 = h->wi_f8 && !pf8;
-      OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp && !wi8, wi8));
+      OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp && !wi8, wi8 || mlp8));
       pp.a_fp = ws.ln_hi;
       pp.a_lo8 = ws.ln_lo;
-      pp.wp = (pf8 || wi8) ? lw.wi_p16 : (f16 ? lw.wi_h16 : lw.wi_pk);
+      pp.wp = (pf8 || wi8 || mlp8) ? lw.wi_p16 : (f16 ? lw.wi_h16 : lw.wi_pk);
       pp.wp8 = lw.wi_p8;
       pp.w8_lo_off = (size_t)2 * I * H / 2;
       pp.o0 = ws.h_hi;
       pp.o0_lo8 = ws.h_lo;
       pp.ld_out = I;
-      OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128, wi8));
+      OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128, wi8, mlp8));
       OP_TRY(clear_h());
       pp.a_fp = ws.h_hi;
       pp.a_lo8 = ws.h_lo;
       pp.n_ksteps = I / 32;
-      pp.wp = pf8 ? lw.wo2_p16 : (f16 ? lw.wo2_h16 : lw.wo2_pk);
+      pp.wp = (pf8 || mlp8) ? lw.wo2_p16 : (f16 ? lw.wo2_h16 : lw.wo2_pk);
       pp.wp8 = lw.wo2_p8;
       pp.w8_lo_off = (size_t)H * I / 2;
       pp.ld_out = H;
-      OP_TRY(panel(PK_GEMM_MLP_OUT, 101, pp, H / 256));
+      OP_TRY(panel(PK_GEMM_MLP_OUT, 101, pp, H / 256, false, mlp8));
       continue;
     }
 
@@ -1289,6 +1295,7 @@ namespace {
 // op_kernel_set number of the handle's current selection (op_effective_policy)
 int public_set(const op_handle* h) {
   if (h->emulate) return -1;
+  if (h->pi == opl::PI_F16 && h->mlp_f8) return h->mlp_wlo ? OP_KS_F16_MLP_F8_W : OP_KS_F16_MLP_F8;
   if (h->pi == opl::PI_F16) return OP_KS_F16;
   return h->wi_f8 ? 5 + h->pi : h->pi;  // 5 / 6: sets 0 / 1 with the Wi GEMM in the fp16 + e4m3 format
 }
@@ -1308,6 +1315,8 @@ bool set_available(const op_handle* h, int set) {
     case OP_KS_BF16X3_WI_F8:
     case OP_KS_BF16_WEIGHTS_WI_F8: return h->panel_path && h->f8_packs && !h->f16_unfit;
     case OP_KS_F16: return h->h16_packs && !h->f16_unfit && row_layer_ok;
+    case OP_KS_F16_MLP_F8_W:
+    case OP_KS_F16_MLP_F8: return h->panel_path && h->h16_packs && h->f8_packs && !h->f16_unfit;
     default: return false;
   }
 }
@@ -1316,7 +1325,9 @@ bool set_available(const op_handle* h, int set) {
 // an approximation -- op_calibrate measures it before choosing it).
 void apply_set(op_handle* h, int set) {
   h->wi_f8 = set == OP_KS_BF16X3_WI_F8 || set == OP_KS_BF16_WEIGHTS_WI_F8;
-  h->pi = set == OP_KS_F16 ? opl::PI_F16 : (h->wi_f8 ? set - 5 : set);
+  h->mlp_f8 = set == OP_KS_F16_MLP_F8_W || set == OP_KS_F16_MLP_F8;
+  h->mlp_wlo = set == OP_KS_F16_MLP_F8_W;
+  h->pi = (set == OP_KS_F16 || h->mlp_f8) ? opl::PI_F16 : (h->wi_f8 ? set - 5 : set);
   h->eff = opl::kPolicies[h->pi];
   h->emulate = false;
 }
@@ -1340,6 +1351,7 @@ int resolve_policy(op_handle* h) {
   h->pi = 0;
   h->emulate = true;
   h->wi_f8 = false;
+  h->mlp_f8 = h->mlp_wlo = false;
   if (!(h->cfg.flags & OP_FLAG_NO_POLICY_KERNELS)) {
     for (int i = 0; i < opl::N_POLICIES; ++i)
       if (opl::kPolicies[i] == e) {
@@ -1385,7 +1397,9 @@ float set_cost(const op_handle* h, int set) {
   switch (set) {
     case OP_KS_F16: return 1.0f;
     case OP_KS_BF16: return 1.01f;  // same MFMA count as "f16", 8 instead of 11 significant bits: tried second
+    case OP_KS_F16_MLP_F8: return 1.375f;
     case OP_KS_F16_F8: return 1.5f;
+    case OP_KS_F16_MLP_F8_W: return 1.74f;
     case OP_KS_BF16_WEIGHTS_WI_F8: return 1.75f;
     case OP_KS_BF16_WEIGHTS: return 2.0f;
     case OP_KS_F16_F8_W: return h->panel_path ? 2.1f : 1.99f;
