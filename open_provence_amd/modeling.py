@@ -83,12 +83,13 @@ class ProcessPerformanceTrace:
     fragment_decode_seconds: float = 0.0
 
     def as_dict(self) -> dict[str, Any]:
-        """The reference's ten stage timers (ref :377-404) + what the MI355X path adds when it has something to say
-        (``runtime``: the kernel set the forwards ran on, how often the range guard left an fp16-plane set, host-stage
-        replicas of the call) -- extra keys, the ten fields are always there."""
+        """The reference's ten stage timers (ref :377-404) + the NUMERIC facts the MI355X path adds when it has something to
+        say: ``fallback_from_f8`` (how often the range guard left an fp16-plane kernel set on this model), ``host_replicas``
+        (host-stage worker processes of the call).  Callers do arithmetic over this dict (``float(v)``, sums over calls):
+        everything in it is a number; the kernel set's NAME and the calibration report are ``performance_trace.runtime``."""
 
         out: dict[str, Any] = {name: float(getattr(self, name)) for name in self.__dataclass_fields__}
-        out.update(getattr(self, "runtime", None) or {})
+        out.update({k: v for k, v in (getattr(self, "runtime", None) or {}).items() if isinstance(v, (int, float)) and not isinstance(v, bool)})
         return out
 
 
@@ -1936,6 +1937,7 @@ class OpenProvenceModel:
         runtime: dict[str, Any] = {}
         if self._forward_is_native() and getattr(self, "encoder", None) is not None:
             runtime["kernel_set"] = self.encoder.effective_policy()["kernel_set"]
+            runtime["calibration"] = self.encoder.calibration
             runtime["fallback_from_f8"] = int(getattr(self.encoder, "fallbacks", 0))
         transport = (getattr(self, "_dist", None) or {}).get("transport")
         if transport is not None and hasattr(transport, "conns"):  # the owner of a host-mode front-end

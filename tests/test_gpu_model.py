@@ -124,7 +124,8 @@ def test_process_starts_host_replicas_by_itself(monkeypatch):
                 return_sentence_metrics=True, return_sentence_texts=True, threshold=0.4)
     monkeypatch.setenv("OPEN_PROVENCE_HOST_REPLICAS", "0")
     want_small, want_big = model.process(context=contexts[:300], **call), model.process(context=contexts, **call)
-    assert "host_replicas" not in want_big["timing"] and want_big["timing"]["kernel_set"]
+    assert "host_replicas" not in want_big["timing"] and want_big["performance_trace"].runtime["kernel_set"] == "f16-f8-w"
+    assert all(isinstance(v, (int, float)) for v in want_big["timing"].values())  # callers sum / float() these
     monkeypatch.delenv("OPEN_PROVENCE_HOST_REPLICAS")
     try:
         got_small = model.process(context=contexts[:300], preprocess_workers=2, **call)   # asked for: two worker processes
