@@ -43,7 +43,7 @@ def build_e2e_tokenizer():
     if os.environ.get("E2E_TOKENIZER", "char") == "wordpiece":
         from helpers import build_wordpiece_tokenizer
 
-        return build_wordpiece_tokenizer(True)
+        return build_wordpiece_tokenizer(True, legacy_methods=os.environ.get("E2E_STOCK_TOKENIZER") != "1")
     return CharTokenizer()
 
 
@@ -60,7 +60,7 @@ def build_e2e_model():
     if os.environ.get("E2E_TOKENIZER", "char") == "wordpiece":
         from helpers import build_wordpiece_tokenizer
 
-        tok = build_wordpiece_tokenizer(True)
+        tok = build_wordpiece_tokenizer(True, legacy_methods=os.environ.get("E2E_STOCK_TOKENIZER") != "1")
     else:
         tok = CharTokenizer()
     model = OpenProvenceModel(cfg, device="cuda", tokenizer=tok, state_dict=synth_state_dict(dims, 7))
@@ -83,10 +83,15 @@ def main():
     ap.add_argument("--tokenizer", default="char", choices=["char", "wordpiece"],
                     help="char: the pure-Python tokenizer of the tests; wordpiece: a Hugging Face fast (Rust) tokenizer built offline")
     ap.add_argument("--workers", type=int, default=None, help="preprocess_workers (worker threads of the split / tokenize stage)")
+    ap.add_argument("--stock-tokenizer", action="store_true",
+                    help="wordpiece: the plain transformers PreTrainedTokenizerFast object (what a checkpoint's tokenizer files load as; "
+                    "it pickles, so process() can start host replicas by itself) instead of the test helper's local 4.x-style subclass")
     ap.add_argument("--chars-are-words", action="store_true", help="wordpiece: size the contexts in words (~tokens) instead of characters")
     args = ap.parse_args()
 
     os.environ["E2E_TOKENIZER"] = args.tokenizer
+    if args.stock_tokenizer:
+        os.environ["E2E_STOCK_TOKENIZER"] = "1"
     question, contexts = make_request(args.contexts, args.chars)
     front = None
     if args.front_end > 0:
