@@ -196,7 +196,7 @@ int op_select_kernel_set(op_handle* h, int kernel_set);
  * weights (it only drops terms that are identically zero) -- and therefore priced for the worst case: weights of O(1)
  * scale, where every dropped term costs >= 7e-3 on a logit.  A trained checkpoint's weights are ~0.02: there most of
  * the correction terms are below the parity bar by orders of magnitude.  op_calibrate runs one batch (ids_host /
- * cu_seqlens_host / n_seqs: the caller's sample of real inputs; NULL / NULL / 0: 24 rows x min(512, max positions) + 8
+ * cu_seqlens_host / n_seqs: the caller's sample of real inputs; NULL / NULL / 0: 24 rows x min(512, max positions) + 14
  * ragged rows of uniform token ids) through the (hi, lo) bf16 realisation of the requested policy (`reference_set`) and
  * through every available kernel set CHEAPER than the default one, cheapest first, and keeps the first whose
  * max |logit difference| (pruning and ranking logits) to the reference outputs is <= tolerance and finite; if none is,
