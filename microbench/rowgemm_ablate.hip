@@ -141,8 +141,8 @@ int main() {
     CHECK(hipMemcpy(d_pos, pos.data(), R * 4, hipMemcpyHostToDevice));
   }
 #ifdef OPK_TIMING
-  CHECK(hipMalloc(&p.dbg, (size_t)(R / 128) * 16 * 8));
-  CHECK(hipMemset(p.dbg, 0, (size_t)(R / 128) * 16 * 8));
+  CHECK(hipMalloc(&p.dbg, (size_t)(R / 64) * 16 * 8));  // (enough for 64-row blocks too)
+  CHECK(hipMemset(p.dbg, 0, (size_t)(R / 64) * 16 * 8));
 #endif
 #ifdef ABL_F8
   {
@@ -270,7 +270,11 @@ int main() {
     // cycle stamps of wave 0 of every block: 0 start, 1 after the attention-output projection, 2 after residual +
     // LayerNorm (MLP loop starts), 3 after the MLP, 4 after residual + LayerNorm, 5 end; [8] = cycles in the MLP
     // loop's end-of-stage wait + barrier
+#if defined(ABL_WAVES) && defined(ABL_MF)
+    const int blocks = R / (ABL_WAVES * 16 * ABL_MF);
+#else
     const int blocks = R / 128;
+#endif
     std::vector<unsigned long long> t((size_t)blocks * 16);
     CHECK(hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost));
     double seg[5] = {0, 0, 0, 0, 0}, wait = 0, wait2 = 0, wait1 = 0, total = 0, real = 0;
