@@ -530,6 +530,19 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
           (__attribute__((address_space(3))) void*)(&sW[stage][elem]), 16, 0, 0);
     }
   };
+  // Kernel set "f16" (round 5): the q / k / v^T loop of the whole-layer kernel takes TWO chunks per LDS stage and barrier
+  // (pair_iteration below); chunk `chunk` copied to element offset `elem_off` of stage `stage`
+  constexpr bool QKV2 = PRO == RP_MLP && EPI == RE_QKV && !F8 && H16 && 2 * STAGE <= STAGE_ALLOC;
+  auto stage_chunk_at = [&](int chunk, int stage, int elem_off) {
+    const u16* src = p.wp + (size_t)chunk * CHUNK_SRC;
+#pragma unroll
+    for (int u = 0; u < WAVE_PIECES; ++u) {
+      const int elem = (wave + WAVES * u) * 512;                // position inside the chunk's single plane
+      const int src_elem = (elem / 1024) * 2048 + elem % 1024;  // the source keeps both planes per k-step
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + src_elem + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(&sW[stage][elem_off + elem]), 16, 0, 0);
+    }
+  };
   // F8 kernel sets, q / k / v^T projection: the chunks are streamed in PAIRS (qkv_pairs below), a stage holds chunks
   // 2t and 2t+1 back to back.  Instruction u of a wave copies piece u % GS of its group u / GS (GS consecutive pieces
   // through one pointer / M0 and the DMA's immediate offset); the chunk a group belongs to is a wave-uniform integer
@@ -1654,6 +1667,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
       } else {
         if constexpr (QKV_PAIRS) stage_pair(0, 0);
         else stage_chunk(0, 0);
+        if constexpr (QKV2) stage_chunk_at(1, 0, STAGE);  // the first PAIR of chunks
         if (ROPE_PRELOAD) rope_preload();
         if constexpr (LN_V2) {
           layer_ln(no_, std::integral_constant<bool, A_LO>{}, 1);
@@ -2242,6 +2256,107 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
   const std::true_type yes{};
   const std::false_type no{};
   const int n_sw = (EPI == RE_QKV) ? p.n_swapped : p.n_chunks;
+
+  // ---- (round 5, kernel set "f16") the q / k / v^T loop of the whole-layer kernel with TWO chunks per LDS stage and barrier.
+  // One chunk per barrier: 24 barriers of eight waves per block, each with its counted wait and a refill of the fragment-read
+  // pipeline, around 256 pipe cycles of MFMAs per wave.  A stage now holds the chunk pair (2t, 2t+1) -- one RoPE head or one
+  // v^T head --, the pair's two chunks run back to back with the deferred epilogue of the chunk before each riding on it,
+  // and the eight waves meet once per pair.  Same operations in the same order per chunk: bit-identical values.
+  if constexpr (QKV2) {
+    static_assert(PLANES == 1, "chunk pairs: single-plane weights");
+    auto set_rope = [&](auto j_tag) {
+      constexpr int j = decltype(j_tag)::value;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        rope_c[mf] = rope_cc[mf][j];
+        rope_s[mf] = rope_ss[mf][j];
+      }
+    };
+    auto stores_of = [](bool sw_chunk, int parity) constexpr {
+      return sw_chunk ? (parity == 1 ? MF * (2 + ((O0_LO && O1_LO) ? 2 : 0)) : 0) : 2 * (1 + (O2_LO ? 1 : 0));
+    };
+    auto recipe = [&]() {
+      constexpr int N_MFMA = KS * 2 * MF;
+#pragma unroll
+      for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      }
+    };
+    auto pair_iteration = [&](int c0, auto stage_tag, auto first_tag, auto sw_tag, auto swp_tag) {
+      constexpr int S = decltype(stage_tag)::value;
+      constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr bool SW = decltype(sw_tag)::value;    // this pair: q / k chunks (weights as the MFMA row operand) or v chunks
+      constexpr bool SWP = decltype(swp_tag)::value;  // the chunk in front of the pair
+      if (SWP && !FIRST) set_rope(odd);
+      const int cn = c0 + 2 < p.n_chunks ? c0 + 2 : c0;  // (the last pair harmlessly re-copies itself: no DMA under a branch)
+      stage_chunk_at(cn, S ^ 1, 0);
+      stage_chunk_at(cn + 1, S ^ 1, STAGE);
+      __builtin_amdgcn_sched_barrier(0);  // RoPE values ahead of the DMA, the epilogues' stores behind it (counted wait below)
+      if (!FIRST) epilogue(c0 - 1, odd, swp_tag, acc_prev);
+      f32x4 acc[2][MF];
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      rowgemm_chunk_mfma<KS, MF, T2, SW, 0, true, 1, H16>(lds_stage[S], a_hi, a_lo, acc);
+      if (!FIRST) epilogue_store(c0 - 1, odd, swp_tag);
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = acc[nf][mf];
+      if (!FIRST) recipe();
+      __builtin_amdgcn_sched_barrier(0);
+      // second chunk of the pair, the first one's epilogue riding on it
+      if (SW) set_rope(even);
+      epilogue(c0, even, sw_tag, acc_prev);
+      f32x4 acc2[2][MF];
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc2[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      rowgemm_chunk_mfma<KS, MF, T2, SW, STAGE * 2, true, 1, H16>(lds_stage[S], a_hi, a_lo, acc2);
+      epilogue_store(c0, even, sw_tag);
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc_prev[nf][mf] = acc2[nf][mf];
+      recipe();
+      // this wave's share of the next pair has landed (vmcnt retires in order: everything but the stores issued behind the
+      // DMA), then all waves meet
+      constexpr int N_STORES = (FIRST ? 0 : stores_of(SWP, 1)) + stores_of(SW, 0);
+#ifdef OPK_TIMING
+      const unsigned long long opk_w0 = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
+#ifdef OPK_TIMING
+      const unsigned long long opk_w1 = __builtin_readcyclecounter();
+      opk_wait1 += opk_w1 - opk_w0;
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef OPK_TIMING
+      opk_wait2 += __builtin_readcyclecounter() - opk_w1;
+#endif
+    };
+    pair_iteration(0, even, yes, yes, yes);  // (chunks 0 and 1 were requested in front of the LayerNorm and have landed)
+    int stage_bit = 1;
+    for (int c0 = 2; c0 < n_sw; c0 += 2, stage_bit ^= 1) {
+      if (stage_bit) pair_iteration(c0, odd, no, yes, yes);
+      else pair_iteration(c0, even, no, yes, yes);
+    }
+    if (stage_bit) pair_iteration(n_sw, odd, no, no, yes);  // first v pair; finishes the last k chunk
+    else pair_iteration(n_sw, even, no, no, yes);
+    stage_bit ^= 1;
+    for (int c0 = n_sw + 2; c0 < p.n_chunks; c0 += 2, stage_bit ^= 1) {
+      if (stage_bit) pair_iteration(c0, odd, no, no, no);
+      else pair_iteration(c0, even, no, no, no);
+    }
+    epilogue(p.n_chunks - 1, odd, no, acc_prev);
+    epilogue_store(p.n_chunks - 1, odd, no);
+    OPK_STAMP(5);
+    OPK_DUMP();
+    return;
+  }
   iteration(0, even, yes, yes, yes);
   iteration(1, odd, no, yes, yes);
   for (int c0 = 2; c0 < n_sw; c0 += 2) {
