@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-long --no-base "$@" > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --steps ${PROF_STEPS:-30} --warmup ${PROF_WARMUP:-10} --no-cpu-baseline --no-long --no-base "$@" > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-long --no-base "$@" > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-long --no-base "$@" > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-long --no-base "$@" > $OUT/pmc_mfma.log 2>&1
