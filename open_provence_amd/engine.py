@@ -208,6 +208,7 @@ class HipEncoder:
             self.load_weight(name, tensor)
         _lib.check(self.lib, self._handle, self.lib.op_weights_ready(self._handle), "op_weights_ready")
         self.__dict__["_f8_active"] = None
+        self.__dict__["_audit_pending"] = False
         self.calibration = None
         pinned = kernel_set or os.environ.get("OPEN_PROVENCE_KERNEL_SET")
         if pinned:
@@ -226,6 +227,7 @@ class HipEncoder:
             raise ValueError(f"unknown kernel set {name!r}; expected one of {sorted(_lib.KERNEL_SET_IDS)} or 'auto'")
         _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(number)), f"op_select_kernel_set({name})")
         self.__dict__["_f8_active"] = None
+        self.__dict__["_audit_pending"] = False  # (a pinned set is the caller's decision: nothing to audit)
 
     def calibrate(self, tolerance: float = 1e-4, rows: "Sequence[Sequence[int]] | None" = None) -> dict:
         """``op_calibrate``: one batch (``rows`` of token ids -- a sample of real inputs -- or the library's synthetic
@@ -261,6 +263,10 @@ class HipEncoder:
             "tokens": int(report.n_tokens),
             "batch": "caller rows" if rows is not None else "synthetic (uniform token ids)",
         }
+        # a set chosen on SYNTHETIC token ids is audited on the first real batch (_audit_first_batch); the caller's own rows
+        # are real inputs already.  OPEN_PROVENCE_AUDIT=0 switches the audit off.
+        self.__dict__["_audit_pending"] = (rows is None and self.calibration["chosen_set"] != self.calibration["default_set"]
+                                           and os.environ.get("OPEN_PROVENCE_AUDIT", "1").strip().lower() not in ("0", "off", "false", "no"))
         return self.calibration
 
     def effective_policy(self) -> dict:
@@ -399,7 +405,48 @@ class HipEncoder:
             self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, int(max_seqlen),
                                  prune.data_ptr(), rank.data_ptr(), keep_prob.data_ptr() if keep_prob is not None else None,
                                  ws, stream)
+            if self.__dict__.get("_audit_pending") and total >= 64 and self._capture is None:
+                self._audit_first_batch(ids, cu_seqlens, cu_host, n_seqs, total, int(max_seqlen), prune, rank, keep_prob, ws, stream)
         return prune, rank
+
+    def _audit_first_batch(self, ids, cu_seqlens, cu_host, n_seqs, total, max_seqlen, prune, rank, keep_prob, ws, stream) -> None:
+        """The calibration ran on synthetic token ids; the FIRST real batch a calibrated model sees is its audit: the same
+        batch once more through the reference kernel set of the calibration, max |logit difference| against what the chosen
+        set just returned.  Within ``audit_factor`` (3) x the calibration tolerance -- 3e-4, still 3 x inside the path's bar;
+        the forward fuzz puts the worst row of other inputs at <= 2.7 x a calibration batch's maximum -- the choice stands
+        (one synchronisation, two extra forwards, once per load).  Beyond it, or non-finite: the model goes back to the
+        default selection of ``op_weights_ready`` for good, warns, and THIS batch is recomputed there before it is returned."""
+
+        self.__dict__["_audit_pending"] = False
+        cal = self.calibration or {}
+        chosen, reference = cal.get("chosen_set"), cal.get("reference_set")
+        if not chosen or chosen == cal.get("default_set") or reference not in _lib.KERNEL_SET_IDS:
+            return
+        p_ref, r_ref = torch.empty_like(prune), torch.empty_like(rank)
+        self.select_kernel_set(reference)
+        try:
+            self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, max_seqlen,
+                                 p_ref.data_ptr(), r_ref.data_ptr(), None, ws, stream)
+        finally:
+            self.select_kernel_set(chosen)
+        err = float(torch.maximum((prune - p_ref).abs().max(), (rank - r_ref).abs().max()).item())  # (synchronises)
+        bound = float(cal.get("tolerance", DEFAULT_CALIBRATION_TOLERANCE)) * float(getattr(self, "audit_factor", 3.0))
+        passed = err == err and err <= bound  # (NaN fails)
+        cal["audit"] = {"tokens": int(total), "rows": int(n_seqs), "max_abs_err": err, "bound": bound, "passed": bool(passed)}
+        if passed:
+            return
+        import warnings
+
+        self.select_kernel_set("auto")
+        cal["chosen_set"] = self.effective_policy()["kernel_set"]
+        warnings.warn(
+            f"open_provence_amd: the first real batch disagrees with the load-time calibration: kernel set {chosen!r} is {err:.2e} from "
+            f"the {reference!r} kernels on it (bound {bound:.1e}); this model runs on {cal['chosen_set']!r} from now on.  "
+            "Pass calibration_rows= (a sample of real token ids) to calibrate on representative inputs.",
+            RuntimeWarning, stacklevel=4,
+        )
+        self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, max_seqlen,
+                             prune.data_ptr(), rank.data_ptr(), keep_prob.data_ptr() if keep_prob is not None else None, ws, stream)
 
     def _check_packed_inputs(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, keep_prob: torch.Tensor | None) -> tuple[int, int]:
         """Shared argument checks of forward_packed / forward_packed_on -> (total_tokens, n_seqs)."""

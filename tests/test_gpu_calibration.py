@@ -241,3 +241,53 @@ def test_an_activation_beyond_fp16_range_leaves_the_f16_set_too():
     p, r = run(enc, False)
     assert np.array_equal(p, ref_p) and np.array_equal(r, ref_r)
     enc.close()
+
+
+def test_first_real_batch_audits_the_calibrated_set():
+    """The calibration batch is synthetic; the first batch a calibrated model sees goes through the reference kernels as well.
+    Within 3 x the tolerance the choice stands; beyond it the model returns to the default selection for good and that very
+    batch is recomputed there (bit-identical to an uncalibrated model's outputs)."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.packing import pack_rows
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch
+
+    dims = named_dims("xsmall", num_layers=4)
+    state = refinit_state_dict(dims, seed=7)
+    rows = synth_pair_batch(dims, 6, [200, 64, 130, 31, 257, 40], seed=9)
+    rows[5] = rows[5][:3]  # a three-token row too
+    ids_np, cu_np, max_len = pack_rows(rows)
+
+    def run(enc):
+        ids, cu = torch.from_numpy(ids_np).to(enc.device), torch.from_numpy(cu_np).to(enc.device)
+        keep = torch.empty(int(cu_np[-1]), dtype=torch.float32, device=enc.device)
+        prune, rank = enc.forward_packed(ids, cu, cu_np, max_len, keep_prob=keep)
+        torch.cuda.synchronize()
+        return prune.cpu().numpy(), rank.cpu().numpy(), keep.cpu().numpy()
+
+    plain = HipEncoder(dims, device="cuda:0")
+    plain.load_state_dict(state, calibrate=False)
+    want_default = run(plain)
+    plain.close()
+
+    enc = HipEncoder(dims, device="cuda:0")
+    enc.load_state_dict(state)
+    assert enc.calibration["chosen_set"] == "f16" and "audit" not in enc.calibration
+    first = run(enc)
+    audit = enc.calibration["audit"]
+    assert audit["passed"] and audit["tokens"] == int(cu_np[-1]) and audit["max_abs_err"] <= audit["bound"] == pytest.approx(3e-4)
+    assert enc.effective_policy()["kernel_set"] == "f16"
+    again = run(enc)  # no second audit; the audited batch's outputs were the chosen set's own
+    assert all(np.array_equal(a, b) for a, b in zip(first, again))
+    enc.close()
+
+    enc = HipEncoder(dims, device="cuda:0")
+    enc.audit_factor = 1e-6  # nothing passes: the audit must send the model back to the default selection
+    enc.load_state_dict(state)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = run(enc)
+        assert any("first real batch" in str(w.message) for w in caught)
+    assert not enc.calibration["audit"]["passed"] and enc.effective_policy()["kernel_set"] == "f16-f8-w" == enc.calibration["chosen_set"]
+    assert all(np.array_equal(a, b) for a, b in zip(got, want_default))
+    enc.close()
