@@ -190,8 +190,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
     }
   };
 
+  // FSM (round 5; the single-pass instantiations, where the softmax's vector instructions -- not the MFMAs -- bound the
+  // kernel: ~150 of them per 64-key tile and wave beside 32 MFMAs): two of the five vector instructions per score leave.
+  //   * The score accumulators start at -m_run instead of 0, so S^T arrives as s - m and goes straight into v_exp (no
+  //     subtraction); the reference still moves lazily, and only a tile in which it moves pays the subtraction.
+  //   * The row sums come from the matrix pipe: one more MFMA per k-step against a fragment of ones accumulates
+  //     sum_k p[k][q] -- of the ROUNDED p the numerator is made of -- for every lane of a query column (no adds, no shuffles).
+  constexpr bool FSM = H16;  // (not the bf16 single-pass set: it stays bit-identical to the all-terms kernels with cleared lo operands)
   float m_run[2] = {-1e30f, -1e30f};
   float l_run[2] = {0.f, 0.f};
+  f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // FSM: row sums (all four rows of a lane hold the same sum)
+  const bf16x8 ones_frag = as_frag(H16 ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u)
+                                       : make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
   f32x4 oacc[4][2];
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -212,10 +222,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
         (kbase + TILE_KEYS - 1 < len) && (kbase + TILE_KEYS - 1 - qbase <= win) && (qbase + 31 - kbase <= win);
     if (!outside) {
       f32x4 sacc[2 * KT][2];
+      // FSM: the accumulators start at minus the softmax reference of their query (0 while it has none: sentinel -1e30)
+      float m_base[2];
+#pragma unroll
+      for (int qf = 0; qf < 2; ++qf) m_base[qf] = (FSM && m_run[qf] > -1e29f) ? m_run[qf] : 0.f;
 #pragma unroll
       for (int m = 0; m < 2 * KT; ++m)
 #pragma unroll
-        for (int qf = 0; qf < 2; ++qf) sacc[m][qf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qf = 0; qf < 2; ++qf) sacc[m][qf] = f32x4{-m_base[qf], -m_base[qf], -m_base[qf], -m_base[qf]};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -266,6 +280,47 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
           for (int r = 0; r < 4; ++r) tile_max = fmaxf(tile_max, sacc[m][qf][r]);
         tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 16, 64));
         tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
+        if constexpr (FSM) {
+          // sacc holds s - m_base.  The reference moves when the tile's maximum exceeds it by more than 2^6 (as below), or
+          // when this query has no reference yet and the tile has a visible key for it (a masked tile leaves -3e30).
+          const bool fresh = m_run[qf] <= -1e29f;
+          const bool moved = fresh ? (tile_max > -1e29f) : (tile_max > 6.0f);
+          if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // wave-uniform, rare after a query's first tile
+            const float delta = moved ? tile_max : 0.f;
+            const float alpha = __builtin_amdgcn_exp2f(fresh ? 0.f : -delta);  // (a fresh query's sums are zero: any finite factor)
+            m_run[qf] = moved ? m_base[qf] + delta : m_run[qf];
+            lacc[qf][0] *= alpha;
+            lacc[qf][1] *= alpha;
+            lacc[qf][2] *= alpha;
+            lacc[qf][3] *= alpha;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              oacc[n][qf][0] *= alpha;
+              oacc[n][qf][1] *= alpha;
+              oacc[n][qf][2] *= alpha;
+              oacc[n][qf][3] *= alpha;
+            }
+#pragma unroll
+            for (int m = 0; m < 2 * KT; ++m)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sacc[m][qf][r] -= delta;
+          }
+#pragma unroll
+          for (int m = 0; m < 2 * KT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[m][qf][r] = __builtin_amdgcn_exp2f(sacc[m][qf][r]);  // <= 2^6; masked: 2^-3e30 = 0
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            const float v0[4] = {sacc[2 * t][qf][0], sacc[2 * t][qf][1], sacc[2 * t][qf][2], sacc[2 * t][qf][3]};
+            const float v1[4] = {sacc[2 * t + 1][qf][0], sacc[2 * t + 1][qf][1], sacc[2 * t + 1][qf][2], sacc[2 * t + 1][qf][3]};
+            uint2 h0, l0, h1, l1;
+            split4x<false, H16>(v0, h0, l0);
+            split4x<false, H16>(v1, h1, l1);
+            ph[t][qf] = as_frag(make_uint4(h0.x, h0.y, h1.x, h1.y));
+            pl[t][qf] = ph[t][qf];
+          }
+          continue;
+        }
         // Lazy reference: the exponent reference m_run only moves when this tile's maximum exceeds it by more
         // than 2^6 (p stays <= 64, harmless in fp32 and in the hi/lo split), and the 16 accumulator rescales run
         // only in the tiles where some query of the wave moved -- a wave-uniform branch, rare after the first tile.
@@ -312,6 +367,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
       // O^T += V^T P^T
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
+        if constexpr (FSM) {  // the row sums of this k-step: ones x P^T
+#pragma unroll
+          for (int qf = 0; qf < 2; ++qf) lacc[qf] = mfma16x<H16>(ones_frag, ph[t][qf], lacc[qf]);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           const bf16x8 vh = lds_frag(st + (K_PIECES + (t * PV) * 4 + n) * 512);
@@ -357,6 +416,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
     for (int qf = 0; qf < 2; ++qf) {
       float l_tot = l_run[qf] + __shfl_xor(l_run[qf], 16, 64);
       l_tot += __shfl_xor(l_tot, 32, 64);
+      if constexpr (FSM) l_tot = lacc[qf][0];  // summed over all 32 keys of every k-step by the MFMA: complete in every lane
       const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
       // oacc[n][qf][r]: d = 32(n>>1) + 8g + 4(n&1) + r  ->  lane owns d = 8g..8g+7 of k-step (n>>1) of this head
       if constexpr (OF8) {
