@@ -423,12 +423,17 @@ class HipEncoder:
         if not chosen or chosen == cal.get("default_set") or reference not in _lib.KERNEL_SET_IDS:
             return
         p_ref, r_ref = torch.empty_like(prune), torch.empty_like(rank)
+        profiling = bool(self.__dict__.get("_profiling"))
+        if profiling:  # the audit's launches are not the caller's workload: keep them out of a per-kernel profile
+            self.lib.op_profile_enable(self._handle, 0)
         self.select_kernel_set(reference)
         try:
             self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, max_seqlen,
                                  p_ref.data_ptr(), r_ref.data_ptr(), None, ws, stream)
         finally:
             self.select_kernel_set(chosen)
+            if profiling:
+                self.lib.op_profile_enable(self._handle, 1)
         err = float(torch.maximum((prune - p_ref).abs().max(), (rank - r_ref).abs().max()).item())  # (synchronises)
         bound = float(cal.get("tolerance", DEFAULT_CALIBRATION_TOLERANCE)) * float(getattr(self, "audit_factor", 3.0))
         passed = err == err and err <= bound  # (NaN fails)
@@ -617,6 +622,7 @@ class HipEncoder:
 
     def profile_enable(self, enabled: bool) -> None:
         _lib.check(self.lib, self._handle, self.lib.op_profile_enable(self._handle, 1 if enabled else 0), "profile")
+        self.__dict__["_profiling"] = bool(enabled)
 
     def profile_reset(self) -> None:
         _lib.check(self.lib, self._handle, self.lib.op_profile_reset(self._handle), "profile_reset")
