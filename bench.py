@@ -145,6 +145,8 @@ ARITHMETIC_OF_KERNEL_SET = {
     "f16": "fp16 single pass (11 significant bits per operand), fp32 accumulate",
     "f16+mlp-f16-f8-w": "attention side: fp16 single pass; MLP: fp16 hi + e4m3 lo split operands (weights: fp16 + two e4m3 planes); fp32 accumulate",
     "f16+mlp-f16-f8": "attention side: fp16 single pass; MLP: fp16 hi + e4m3 lo split activations x fp16 weights; fp32 accumulate",
+    "f16-f8-w+attn-f16": "weight GEMMs: fp16 hi + e4m3 lo split operands (weights: fp16 + two e4m3 planes); q x k, p x v: fp16 single pass; fp32 accumulate",
+    "f16-f8+attn-f16": "weight GEMMs: fp16 hi + e4m3 lo split activations x fp16 weights; q x k, p x v: fp16 single pass; fp32 accumulate",
 }
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 6 /* 6: op_select_kernel_set, op_calibrate, kernel set 7 ("f16": single-pass fp16 operands); 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
+#define OP_ABI_VERSION 7 /* 7: kernel sets 10 / 11 (fp16 attention inside the fp16 + e4m3 sets), op_calibration holds 16 candidates; 6: op_select_kernel_set, op_calibrate, kernel set 7 ("f16": single-pass fp16 operands); 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
@@ -182,7 +182,14 @@ enum op_kernel_set {
    * they are 75 % of the linear FLOPs: ~1.75 / ~1.4 MFMA units per product. */
   OP_KS_F16_MLP_F8_W = 8,
   OP_KS_F16_MLP_F8 = 9,
-  OP_KS_COUNT = 10
+  /* panel path only: sets 4 / 3 with the ATTENTION itself (q x k, p x v) single pass on fp16 operands -- the q / k / v
+   * projection writes single-plane fp16 q, k, v^T, attention runs set 7's kernels and writes o as fp16 + e4m3 pieces; the
+   * four weight GEMMs keep every term of sets 4 / 3.  Attention is 18 - 21 % of large 64 x 2048 / en-gte varlen on sets
+   * 4 / 3 (three MFMA passes per product), and q x k / p x v are the two families whose single-pass error is smallest
+   * (scripts/family_error_probe.py). */
+  OP_KS_F16_F8_W_ATTN_F16 = 10,
+  OP_KS_F16_F8_ATTN_F16 = 11,
+  OP_KS_COUNT = 12
 };
 
 /* Pin the kernel set the forward runs on (OP_KS_AUTO: un-pin).  A set with fewer product terms than the loaded
@@ -211,8 +218,8 @@ typedef struct op_calibration {
   int32_t default_set;   /* what op_weights_ready selects for this checkpoint */
   int32_t chosen_set;    /* what the forward runs on from now on */
   int32_t n_candidates;
-  int32_t candidate_set[8];
-  float candidate_err[8]; /* max |difference| to the reference outputs; +inf: non-finite outputs */
+  int32_t candidate_set[16];
+  float candidate_err[16]; /* max |difference| to the reference outputs; +inf: non-finite outputs */
   int32_t n_rows, n_tokens; /* the calibration batch */
   float default_err;        /* the default set's own difference to the reference outputs on that batch.  It is not held to
                              * the tolerance (it is the set the parity tests stand on), but when it is NOT FINITE -- an

@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 
 OP_MAX_LAYERS = 128
-OP_ABI_VERSION = 6
+OP_ABI_VERSION = 7
 
 OP_OK = 0
 OP_DTYPE_F32, OP_DTYPE_BF16, OP_DTYPE_F16 = 0, 1, 2
@@ -34,10 +34,12 @@ OP_POOL_CLS, OP_POOL_MEAN = 0, 1
 OP_KS_AUTO = -1
 KERNEL_SET_NAMES = {0: "bf16x3", 1: "bf16-weights", 2: "bf16", 3: "f16-f8", 4: "f16-f8-w", 5: "bf16x3+wi-f16-f8-w",
                     6: "bf16-weights+wi-f16-f8", 7: "f16", 8: "f16+mlp-f16-f8-w", 9: "f16+mlp-f16-f8",
+                    10: "f16-f8-w+attn-f16", 11: "f16-f8+attn-f16",
                     -1: "all-terms kernels, cleared lo operands"}
 KERNEL_SET_IDS = {name: number for number, name in KERNEL_SET_NAMES.items() if number >= 0}
 # kernel sets with an fp16 operand plane: an activation beyond fp16's range comes out as NaN (range guard in engine.py)
-FP16_PLANE_SETS = ("f16-f8", "f16-f8-w", "bf16x3+wi-f16-f8-w", "bf16-weights+wi-f16-f8", "f16", "f16+mlp-f16-f8-w", "f16+mlp-f16-f8")
+FP16_PLANE_SETS = ("f16-f8", "f16-f8-w", "bf16x3+wi-f16-f8-w", "bf16-weights+wi-f16-f8", "f16", "f16+mlp-f16-f8-w", "f16+mlp-f16-f8",
+                   "f16-f8-w+attn-f16", "f16-f8+attn-f16")
 
 LIB_NAME = "libopenprovence_hip.so"
 
@@ -103,8 +105,8 @@ class OpCalibration(ctypes.Structure):
         ("default_set", ctypes.c_int32),
         ("chosen_set", ctypes.c_int32),
         ("n_candidates", ctypes.c_int32),
-        ("candidate_set", ctypes.c_int32 * 8),
-        ("candidate_err", ctypes.c_float * 8),
+        ("candidate_set", ctypes.c_int32 * 16),
+        ("candidate_err", ctypes.c_float * 16),
         ("n_rows", ctypes.c_int32),
         ("n_tokens", ctypes.c_int32),
         ("default_err", ctypes.c_float),

@@ -108,6 +108,7 @@ struct op_handle {
   bool wi_f8 = false;              // panel path, OP_FLAG_PANEL_F8_WI: the Wi GEMM (and its LayerNorm) in the fp16 + e4m3 format
   bool mlp_f8 = false;             // panel path, kernel sets 8 / 9: pi = PI_F16 for the attention side, the whole MLP in the fp16 + e4m3 format
   bool mlp_wlo = false;            // ... with the weights' lo part (set 8)
+  bool attn_f16 = false;           // panel path, kernel sets 10 / 11: pi = PI_F16_F8_W / PI_F16_F8 with the attention on set 7's fp16 kernels
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
   int n_cus = 256;          // compute units of the device (hipDeviceProp multiProcessorCount)
@@ -347,6 +348,8 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   // rows >= `rows` are never produced by the attention kernel: keep its output finite there
   const bool o_f8 = (h->pi == opl::PI_F16_F8 || h->pi == opl::PI_F16_F8_W) && !h->emulate;  // o = fp16 pieces (ws.o_hi) + e4m3 pieces (ws.o_lo)
   const bool f16 = h->pi == opl::PI_F16 && !h->emulate;  // kernel set "f16": set 2's layouts, fp16 values, the fp16 weight packs
+  // kernel sets 10 / 11 (panel path): q / k / v^T as single-plane fp16, attention on set 7's kernels with o in sets 3 / 4's format
+  const bool attn16 = o_f8 && h->attn_f16 && h->panel_path;
   if (fp_layout && o_f8) {
     const size_t n16 = (size_t)((r_pad - rows) / 16);
     if (n16) OP_HIP(h, hipMemsetAsync(ws.o_hi + (size_t)(rows / 16) * (H / 32) * 512, 0, n16 * (H / 32) * 512 * sizeof(u16), st));
@@ -416,7 +419,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       const unsigned item_span = 8u * opk::ATT_ITEM_GROUP;
       const dim3 grid((ap.xcd_group ? ((unsigned)ap.n_items + item_span - 1) / item_span * item_span : (unsigned)ap.n_items) *
                       (unsigned)h->nh);
-      if (!opl::launch_attn(st, ap, is_global ? plan.waves_g : 4, is_global ? 2 : 1, h->pi, zero_p_lo, grid))
+      if (!opl::launch_attn(st, ap, is_global ? plan.waves_g : 4, is_global ? 2 : 1, h->pi, zero_p_lo && !attn16, grid, attn16))
         return fail(h, OP_ERR_UNSUPPORTED, "internal: no attention kernel for this configuration");
     } else {
       const dim3 grid((unsigned)q_tiles, (unsigned)h->nh, (unsigned)ns);
@@ -675,7 +678,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         const dim3 grid(8u * groups * (unsigned)q.row_group * (unsigned)n_tiles);  // XCD-aware block map: see panel_gemm_kernel
         const bool ok = f8_here ? opl::launch_panel_f8(st, q, 103, wlo8, grid)
                         : f8_full ? opl::launch_panel_f8(st, q, epi, wlo8, grid)
-                        : pf8   ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
+                        : pf8   ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, attn16, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
                                 : (epi == 102 ? opl::launch_panel_qkv(st, q, h->pi, grid) : opl::launch_panel(st, q, epi, h->pi, grid));
         if (!ok) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
         return L.end();
@@ -708,7 +711,9 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
         pp.o0 = ws.vt_hi;
         OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
       }
-      OP_TRY(clear_qkv());
+      if (!attn16) {  // (sets 10 / 11 neither write nor read a lo plane of q / k / v^T)
+        OP_TRY(clear_qkv());
+      }
       OP_TRY(attention(is_global));
       pp.a_fp = ws.o_hi;
       pp.a_lo8 = ws.o_lo;
@@ -1297,6 +1302,8 @@ int public_set(const op_handle* h) {
   if (h->emulate) return -1;
   if (h->pi == opl::PI_F16 && h->mlp_f8) return h->mlp_wlo ? OP_KS_F16_MLP_F8_W : OP_KS_F16_MLP_F8;
   if (h->pi == opl::PI_F16) return OP_KS_F16;
+  if (h->attn_f16 && h->pi == opl::PI_F16_F8_W) return OP_KS_F16_F8_W_ATTN_F16;
+  if (h->attn_f16 && h->pi == opl::PI_F16_F8) return OP_KS_F16_F8_ATTN_F16;
   return h->wi_f8 ? 5 + h->pi : h->pi;  // 5 / 6: sets 0 / 1 with the Wi GEMM in the fp16 + e4m3 format
 }
 
@@ -1317,6 +1324,8 @@ bool set_available(const op_handle* h, int set) {
     case OP_KS_F16: return h->h16_packs && !h->f16_unfit && row_layer_ok;
     case OP_KS_F16_MLP_F8_W:
     case OP_KS_F16_MLP_F8: return h->panel_path && h->h16_packs && h->f8_packs && !h->f16_unfit;
+    case OP_KS_F16_F8_W_ATTN_F16:
+    case OP_KS_F16_F8_ATTN_F16: return h->panel_path && h->f8_packs && !h->f16_unfit;
     default: return false;
   }
 }
@@ -1327,8 +1336,11 @@ void apply_set(op_handle* h, int set) {
   h->wi_f8 = set == OP_KS_BF16X3_WI_F8 || set == OP_KS_BF16_WEIGHTS_WI_F8;
   h->mlp_f8 = set == OP_KS_F16_MLP_F8_W || set == OP_KS_F16_MLP_F8;
   h->mlp_wlo = set == OP_KS_F16_MLP_F8_W;
+  h->attn_f16 = set == OP_KS_F16_F8_W_ATTN_F16 || set == OP_KS_F16_F8_ATTN_F16;
   h->pi = (set == OP_KS_F16 || h->mlp_f8) ? opl::PI_F16 : (h->wi_f8 ? set - 5 : set);
+  if (h->attn_f16) h->pi = set == OP_KS_F16_F8_W_ATTN_F16 ? opl::PI_F16_F8_W : opl::PI_F16_F8;
   h->eff = opl::kPolicies[h->pi];
+  if (h->attn_f16) h->eff.qk = h->eff.pv = 0;
   h->emulate = false;
 }
 
@@ -1352,6 +1364,7 @@ int resolve_policy(op_handle* h) {
   h->emulate = true;
   h->wi_f8 = false;
   h->mlp_f8 = h->mlp_wlo = false;
+  h->attn_f16 = false;
   if (!(h->cfg.flags & OP_FLAG_NO_POLICY_KERNELS)) {
     for (int i = 0; i < opl::N_POLICIES; ++i)
       if (opl::kPolicies[i] == e) {
@@ -1398,9 +1411,11 @@ float set_cost(const op_handle* h, int set) {
     case OP_KS_F16: return 1.0f;
     case OP_KS_BF16: return 1.01f;  // same MFMA count as "f16", 8 instead of 11 significant bits: tried second
     case OP_KS_F16_MLP_F8: return 1.375f;
+    case OP_KS_F16_F8_ATTN_F16: return 1.45f;
     case OP_KS_F16_F8: return 1.5f;
     case OP_KS_F16_MLP_F8_W: return 1.74f;
     case OP_KS_BF16_WEIGHTS_WI_F8: return 1.75f;
+    case OP_KS_F16_F8_W_ATTN_F16: return 1.9f;
     case OP_KS_BF16_WEIGHTS: return 2.0f;
     case OP_KS_F16_F8_W: return h->panel_path ? 2.1f : 1.99f;
     case OP_KS_BF16X3_WI_F8: return 2.5f;
@@ -1520,7 +1535,7 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
   for (int set = 0; set < OP_KS_COUNT; ++set)
     if (set != default_set && set_available(h, set) && set_cost(h, set) < set_cost(h, default_set)) cand.push_back(set);
   std::sort(cand.begin(), cand.end(), [&](int a, int b) { return set_cost(h, a) < set_cost(h, b); });
-  if (cand.size() > 8) cand.resize(8);
+  if (cand.size() > 16) cand.resize(16);
   if (cand.empty()) return finish();
 
   std::vector<int32_t> ids, cu;

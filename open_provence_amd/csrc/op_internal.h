@@ -78,12 +78,16 @@ bool has_layer32(int pi);
 bool launch_layer32(hipStream_t st, const opk::Layer32Params& p, int pi, bool with_qkv, unsigned grid);
 // waves x kt: (8, 2) and (4, 2) full attention / long and short sequences, (4, 1) sliding window.
 // zero_p_lo (pi == 0 only): the policy has no lo(p) x hi(v) term.
-bool launch_attn(hipStream_t st, const opk::AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid);
+// f16_in_f8_out (kernel sets 10 / 11; pi = PI_F16_F8 / PI_F16_F8_W): the fp16 single-pass kernels of PI_F16 on fp16 q / k / v^T,
+// o written as fp16 + e4m3 pieces for the attention output projection of the fp16 + e4m3 format.
+bool launch_attn(hipStream_t st, const opk::AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid,
+                 bool f16_in_f8_out = false);
 bool launch_panel(hipStream_t st, const opk::PanelParams& p, int epi, int pi, dim3 grid);
 // q, k and v^T panels of one layer in one launch (p.n_tiles = 3 H / 256, p.n_qk_tiles = 2 H / 256, p.o2 = v^T)
 bool launch_panel_qkv(hipStream_t st, const opk::PanelParams& p, int pi, dim3 grid);
 // the panel GEMMs in the fp16 + e4m3 format (kernel sets 3 / 4; wlo: the weights carry their lo part = set 4)
 bool launch_panel_f8(hipStream_t st, const opk::PanelParams& p, int epi, bool wlo, dim3 grid);
-bool launch_panel_f8_qkv(hipStream_t st, const opk::PanelParams& p, bool wlo, dim3 grid);
+// o16 (kernel sets 10 / 11): q, k, v^T as single-plane fp16 for launch_attn(.., f16_in_f8_out = true)
+bool launch_panel_f8_qkv(hipStream_t st, const opk::PanelParams& p, bool wlo, bool o16, dim3 grid);
 
 }  // namespace opl

@@ -30,7 +30,16 @@ bool launch_pi(hipStream_t st, const AttnFpParams& p, int waves, int kt, dim3 gr
 
 }  // namespace
 
-bool launch_attn(hipStream_t st, const AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid) {
+bool launch_attn(hipStream_t st, const AttnFpParams& p, int waves, int kt, int pi, bool zero_p_lo, dim3 grid, bool f16_in_f8_out) {
+  if (f16_in_f8_out) {
+    if (zero_p_lo || (pi != PI_F16_F8 && pi != PI_F16_F8_W)) return false;
+    if (waves == 8 && kt == 2) hipLaunchKernelGGL((attn_fp_kernel<0, 0, false, 8, 2, false, true, 2, true>), grid, dim3(512), 0, st, p);
+    else if (waves == 4 && kt == 2) hipLaunchKernelGGL((attn_fp_kernel<0, 0, false, 4, 2, false, true, 2, true>), grid, dim3(256), 0, st, p);
+    else if (waves == 4 && kt == 1)
+      hipLaunchKernelGGL((attn_fp_kernel<0, 0, false, 4, 1, false, true, OPK_ATTN_LOCAL_STAGES, true>), grid, dim3(256), 0, st, p);
+    else return false;
+    return true;
+  }
   if (zero_p_lo) {  // all-terms instantiation with lo(p) cleared
     if (pi != 0) return false;
     if (waves == 8 && kt == 2) hipLaunchKernelGGL((attn_fp_kernel<3, 3, true, 8, 2, true>), grid, dim3(512), 0, st, p);

@@ -78,7 +78,12 @@ bool launch_panel_f8(hipStream_t st, const PanelParams& p, int epi, bool wlo, di
   return wlo ? launch_f8_t<true>(st, p, epi, grid) : launch_f8_t<false>(st, p, epi, grid);
 }
 
-bool launch_panel_f8_qkv(hipStream_t st, const PanelParams& p, bool wlo, dim3 grid) {
+bool launch_panel_f8_qkv(hipStream_t st, const PanelParams& p, bool wlo, bool o16, dim3 grid) {
+  if (o16) {  // kernel sets 10 / 11: single-plane fp16 q, k, v^T for the fp16 attention kernels
+    if (wlo) hipLaunchKernelGGL((panel_f8_qkv_kernel<true, 0, 0, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((panel_f8_qkv_kernel<false, 0, 0, true>), grid, dim3(256), 0, st, p);
+    return true;
+  }
   // q, k and v^T keep their (hi, lo) bf16 pieces: the attention kernels read them
   if (wlo) hipLaunchKernelGGL((panel_f8_qkv_kernel<true, 3, 1>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((panel_f8_qkv_kernel<false, 3, 1>), grid, dim3(256), 0, st, p);

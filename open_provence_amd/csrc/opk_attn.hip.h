@@ -72,7 +72,7 @@ constexpr int ATT_ITEM_GROUP = 4;
 template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false, bool OF8 = false, int NST = 2, bool H16 = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) {
   if constexpr (OF8) set_saturating_conversions();
-  static_assert(!H16 || (TQK == 0 && TPV == 0 && !O_LO && !OF8 && !ZP), "fp16 operands: single pass only");
+  static_assert(!H16 || (TQK == 0 && TPV == 0 && !O_LO && !ZP), "fp16 operands: single pass only");
   constexpr int ATT_FP_BQ = WAVES * 32;
   constexpr int TILE_KEYS = 32 * KT;
   constexpr bool Q_LO = (TQK & T_LEFT_LO) != 0, K_LO = (TQK & T_RIGHT_LO) != 0;

@@ -397,10 +397,12 @@ __global__ __launch_bounds__(256, 2) void panel_qkv_kernel(PanelParams p) {
 // ----------------------------------------------------------------------------------------------
 constexpr int panel_f8_stage_elems(bool wlo) { return (16 + (wlo ? 16 : 8)) * 512; }
 
-template <int EPI, bool WLO, int OLO, int NST>
+// O16 (kernel sets 10 / 11, q / k / v^T only): the outputs are single-plane fp16 -- what attn_fp_kernel<.., H16> reads.
+template <int EPI, bool WLO, int OLO, int NST, bool O16 = false>
 __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_block, int wtile_index, int tile, u16* __restrict__ o0,
                                                u16 (&sW)[NST][panel_f8_stage_elems(WLO)]) {
   static_assert(NST == 2 || NST == 3, "two or three slab stages");
+  static_assert(!O16 || (OLO == 0 && (EPI == PE_QK || EPI == PE_V)), "fp16 outputs: single-plane q / k / v^T");
   constexpr int NF = 16;
   constexpr bool O0_LO = (OLO & 1) != 0, O1_LO = (OLO & 2) != 0;
   constexpr int STAGE = panel_f8_stage_elems(WLO);
@@ -673,8 +675,8 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
             hi_half[4 * u + r] = rope_hi(x1, x2, c4[u][r], s4[u][r]) * qscale;
           }
         bf16x8 h0, l0, h1, l1;
-        pack8<(O0_LO || O1_LO)>(lo_half, h0, l0);
-        pack8<(O0_LO || O1_LO)>(hi_half, h1, l1);
+        pack8x<(O0_LO || O1_LO), O16>(lo_half, h0, l0);
+        pack8x<(O0_LO || O1_LO), O16>(hi_half, h1, l1);
         u16* dst = out + ((rb * kb_out + (size_t)((tq * 4 + hh) * 2)) * 2) * 512 + lane * 8;
         store_stream16(dst, as_u4(h0));
         store_stream16(dst + 1024, as_u4(h1));
@@ -692,7 +694,7 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
       const float v[8] = {acc[nf][0][0], acc[nf][0][1], acc[nf][0][2], acc[nf][0][3],
                           acc[nf][1][0], acc[nf][1][1], acc[nf][1][2], acc[nf][1][3]};
       bf16x8 hi, lo;
-      pack8<O0_LO>(v, hi, lo);
+      pack8x<O0_LO, O16>(v, hi, lo);
       u16* dst = o0 + (((head * (size_t)(p.r_pad >> 5) + tb) * 2) * 4 + (size_t)(nf & 3)) * 512 + lane * 8;
       store_stream16(dst, as_u4(hi));
       if (O0_LO) store_stream16(dst + 2048, as_u4(lo));
@@ -714,14 +716,14 @@ __global__ __launch_bounds__(256, 2) void panel_f8_gemm_kernel(PanelParams p) {
   panel_f8_block<EPI, WLO, OLO, NST>(p, row_block, tile, tile, p.o0, sW);
 }
 
-template <bool WLO, int OLO_QK, int OLO_V>
+template <bool WLO, int OLO_QK, int OLO_V, bool O16 = false>
 __global__ __launch_bounds__(256, 2) void panel_f8_qkv_kernel(PanelParams p) {
   constexpr int NST = panel_f8_stages(WLO);
   __shared__ __attribute__((aligned(16))) u16 sW[NST][panel_f8_stage_elems(WLO)];
   int row_block, tile;
   if (!panel_block_map(p, row_block, tile)) return;
-  if (tile < p.n_qk_tiles) panel_f8_block<PE_QK, WLO, OLO_QK, NST>(p, row_block, tile, tile, p.o0, sW);
-  else panel_f8_block<PE_V, WLO, OLO_V, NST>(p, row_block, tile, tile - p.n_qk_tiles, p.o2, sW);
+  if (tile < p.n_qk_tiles) panel_f8_block<PE_QK, WLO, OLO_QK, NST, O16>(p, row_block, tile, tile, p.o0, sW);
+  else panel_f8_block<PE_V, WLO, OLO_V, NST, O16>(p, row_block, tile, tile - p.n_qk_tiles, p.o2, sW);
 }
 
 }  // namespace opk

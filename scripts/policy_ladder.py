@@ -53,7 +53,7 @@ def main() -> None:
     # every kernel set the handle can run, pinned by name on ONE set of fp32-valued weights (op_select_kernel_set), the
     # all-terms (hi, lo) bf16 set first = the reference of the on-device column
     configs = [("pinned", name) for name in ("bf16x3", "bf16x3+wi-f16-f8-w", "f16-f8-w", "bf16-weights", "bf16-weights+wi-f16-f8",
-                                             "f16-f8", "f16+mlp-f16-f8-w", "f16+mlp-f16-f8", "bf16", "f16")] + [("calibrated", None)]
+                                             "f16-f8-w+attn-f16", "f16-f8", "f16-f8+attn-f16", "f16+mlp-f16-f8-w", "f16+mlp-f16-f8", "bf16", "f16")] + [("calibrated", None)]
     base = None
     for label, name in configs:
         enc = HipEncoder(dims, device=dev, precision="bf16x3", flags=0)

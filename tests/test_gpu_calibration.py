@@ -156,6 +156,68 @@ def test_panel_path_calibrates_and_stays_inside_its_tolerance():
     assert outs["calibrated"][2] == "f16+mlp-f16-f8-w", outs["calibrated"][3]
 
 
+@pytest.mark.parametrize("weights", ["fp32", "bf16"])
+def test_deep_panel_models_take_the_attention_to_fp16_inside_the_f8_sets(weights):
+    """en-gte dims at full depth (22 layers, hidden 768) on reference-initialised weights: the attention-side GEMMs need the
+    correction terms of sets 4 / 3 there (sets 8 / 9 are beyond 1e-4), the attention itself does not -- q x k and p x v are the
+    two families with the smallest single-pass error.  fp32-valued weights calibrate to set 10 ("f16-f8-w+attn-f16": q / k /
+    v^T written as single-plane fp16, attention on the fp16 kernels, o as fp16 + e4m3 pieces); bf16-rounded weights keep
+    "f16-f8" when set 11 is beyond the tolerance on the calibration batch.  Pinned, both sets stay within 1e-3 of the oracle
+    and within 1.5e-4 of the all-terms kernels on ragged rows; they are not available on the row path."""
+
+    from open_provence_amd import _lib
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, pad_rows, refinit_state_dict, synth_pair_batch
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = named_dims("en-gte")
+    state = refinit_state_dict(dims, seed=7)
+    if weights == "bf16":
+        state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
+    full = synth_pair_batch(dims, 6, SEQ_LEN, seed=99)
+    rows = [full[i][:n] for i, n in enumerate((SEQ_LEN, 17, 130, 333, 64, 257))]
+    pinned = "f16-f8-w+attn-f16" if weights == "fp32" else "f16-f8+attn-f16"
+    outs = {}
+    for label, kwargs in (("reference", {"kernel_set": "bf16x3"}), ("calibrated", {}), ("pinned", {"kernel_set": pinned})):
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+        enc.load_state_dict(state, **kwargs)
+        enc.profile_enable(True)
+        prune, rank, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        kinds = set(enc.profile_read())
+        assert {"gemm_qkv_rope", "attn_global", "attn_local", "gemm_attn_out"} <= kinds, kinds
+        outs[label] = (prune.cpu().numpy(), rank.cpu().numpy(), enc.effective_policy(), enc.calibration)
+        enc.close()
+    ref_p, ref_r = outs["reference"][:2]
+    cal = outs["calibrated"][3]
+    assert pinned in cal["candidates"], cal  # it was tried
+    if weights == "fp32":
+        assert outs["calibrated"][2]["kernel_set"] == "f16-f8-w+attn-f16", cal
+        assert cal["candidates"]["f16-f8-w+attn-f16"] <= 1e-4 < cal["candidates"]["f16+mlp-f16-f8-w"], cal
+    else:
+        assert outs["calibrated"][2]["kernel_set"] in ("f16-f8", "f16-f8+attn-f16"), cal
+    assert outs["pinned"][2]["kernel_set"] == pinned
+    assert outs["pinned"][2]["terms"]["qk"] == 0 and outs["pinned"][2]["terms"]["pv"] == 0 and outs["pinned"][2]["terms"]["wi"] != 0
+    ids, mask = pad_rows(rows)
+    with torch.no_grad():
+        ref = oracle_forward(state, dims, ids, mask)
+    m = mask.bool().numpy()
+    for label in ("calibrated", "pinned"):
+        p, r = outs[label][:2]
+        assert np.isfinite(p).all() and np.isfinite(r).all()
+        assert np.abs(p - ref_p).max() <= 1.5e-4 and np.abs(r - ref_r).max() <= 1.5e-4, (label, float(np.abs(p - ref_p).max()))
+        assert np.abs(p - ref.pruning_logits.numpy()[m]).max() < 1e-3 and np.abs(r - ref.ranking_logits.numpy()).max() < 1e-3, label
+    assert not np.array_equal(outs["pinned"][0], ref_p)  # a different arithmetic did run
+
+    # the row path (hidden 256) has no such set
+    small = named_dims("xsmall", num_layers=2, vocab_size=2048)
+    enc = HipEncoder(small, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(refinit_state_dict(small, seed=3), calibrate=False)
+    with pytest.raises(_lib.HipLibraryError):
+        enc.select_kernel_set(pinned)
+    enc.close()
+
+
 def test_pin_unpin_and_environment():
     from open_provence_amd import _lib
     from open_provence_amd.engine import HipEncoder
