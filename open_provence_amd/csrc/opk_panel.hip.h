@@ -646,6 +646,9 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
                        make_uint4(lo8[4 * pr], lo8[4 * pr + 1], lo8[4 * pr + 2], lo8[4 * pr + 3]));
     }
   } else if (EPI == PE_QK) {
+    // O16: q / k become fp16 operands -- beyond fp16's range they turn into Inf (and the outputs into NaN: the range guard of
+    // the Python layer repeats the batch on the (hi, lo) bf16 sets) instead of a silently clamped 65504
+    if constexpr (O16) set_overflowing_conversions();
     const int per = p.hidden / 256;
     const bool is_q = tile < per;
     const int tq = is_q ? tile : tile - per;
@@ -687,6 +690,7 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
       }
     }
   } else {  // PE_V
+    if constexpr (O16) set_overflowing_conversions();
     const size_t tb = (size_t)(m0 >> 5);
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {

@@ -305,6 +305,48 @@ def test_an_activation_beyond_fp16_range_leaves_the_f16_set_too():
     enc.close()
 
 
+def test_a_query_beyond_fp16_range_is_loud_on_the_fp16_attention_sets():
+    """Sets 10 / 11 write q, k, v^T as fp16: a q beyond 65504 (here the q rows of one layer's Wqkv x 2e6) becomes Inf there --
+    non-finite outputs, not a clamped operand -- while set 4 (q as (hi, lo) bf16) computes it; the guarded forward repeats the
+    batch on the (hi, lo) bf16 kernels and the model stays there."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.packing import pack_rows
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch
+
+    dims = named_dims("base", num_layers=3, vocab_size=4096)
+    state = refinit_state_dict(dims, seed=5)
+    key = "ranking_model.model.layers.1.attn.Wqkv.weight"
+    assert key in state
+    w = state[key].clone()
+    w[: dims.hidden_size] *= 2.0e6
+    state[key] = w
+    rows = [r[:n] for r, n in zip(synth_pair_batch(dims, 4, 256, seed=11), (256, 40, 130, 17))]
+    ids_np, cu_np, max_len = pack_rows(rows)
+
+    def run(enc, checked):
+        ids, cu = torch.from_numpy(ids_np).to(enc.device), torch.from_numpy(cu_np).to(enc.device)
+        prune, rank = (enc.forward_packed_checked if checked else enc.forward_packed)(ids, cu, cu_np, max_len)
+        torch.cuda.synchronize()
+        return prune.cpu().numpy(), rank.cpu().numpy()
+
+    outs = {}
+    for name in ("bf16x3", "f16-f8-w", "f16-f8-w+attn-f16"):
+        enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+        enc.load_state_dict(state, kernel_set=name)
+        outs[name] = run(enc, False)
+        if name == "f16-f8-w+attn-f16":
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                outs["guarded"] = run(enc, True)
+                assert caught
+            assert enc.effective_policy()["kernel_set"] == "bf16x3" and not enc.f8_active()
+        enc.close()
+    assert np.isfinite(outs["bf16x3"][0]).all() and np.isfinite(outs["f16-f8-w"][0]).all()
+    assert not np.isfinite(outs["f16-f8-w+attn-f16"][0]).all()  # loud
+    assert np.array_equal(outs["guarded"][0], outs["bf16x3"][0]) and np.array_equal(outs["guarded"][1], outs["bf16x3"][1])
+
+
 def test_first_real_batch_audits_the_calibrated_set():
     """The calibration batch is synthetic; the first batch a calibrated model sees goes through the reference kernels as well.
     Within 3 x the tolerance the choice stands; beyond it the model returns to the default selection for good and that very
