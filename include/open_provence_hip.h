@@ -158,7 +158,9 @@ size_t op_workspace_bytes(const op_handle* h, int n_seqs, int total_tokens, int 
  * (hidden 512 / 768: with OP_FLAG_PANEL_F8) unless OP_FLAG_NO_F8 is set, set 3 needs every GEMM
  * weight to be exactly an fp16 value, and neither is taken for a checkpoint with a weight TENSOR
  * scaled into fp16's subnormal range (checked at load time).  Their fp16 operand plane has fp16's
- * range: an MLP activation beyond it turns the outputs into NaN (on purpose: not clamped). */
+ * range: an MLP activation beyond it turns the outputs into NaN (on purpose: not clamped; on the panel path through a
+ * range flag the kernels raise in the workspace and the head kernels turn into NaN logits -- under MODE.FP16_OVFL = 1 a
+ * conversion clamps and the fp16 MFMA takes a NaN operand for a finite number). */
 int op_effective_policy(op_handle* h, uint8_t* terms_out, int* kernel_set);
 
 /* Kernel sets (the numbering of op_effective_policy).  MFMA pipe time per algorithmic product in 16-bit units:

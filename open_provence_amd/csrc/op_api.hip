@@ -241,6 +241,7 @@ struct Workspace {
   u16 *h_hi, *h_lo;
   int32_t *row_seq, *row_pos, *row_tok, *roff, *qboff, *qboff_l;
   float* cls;
+  int* range_flag;  // panel path, fp16 + e4m3 format: "an fp16 operand was out of range" (PanelParams::range_flag)
   size_t bytes;
 };
 
@@ -282,6 +283,7 @@ void carve(const op_handle* h, char* base, int cap_rows_pad, int n_seqs, Workspa
   ws.qboff = (int32_t*)take(((size_t)n_seqs + 1) * 4);
   ws.qboff_l = (int32_t*)take(((size_t)n_seqs + 1) * 4);
   ws.cls = (float*)take(std::max<size_t>((size_t)n_seqs, 1) * H * 4);
+  ws.range_flag = (int*)take(sizeof(int));
   ws.bytes = off;
 }
 
@@ -350,6 +352,11 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
   const bool f16 = h->pi == opl::PI_F16 && !h->emulate;  // kernel set "f16": set 2's layouts, fp16 values, the fp16 weight packs
   // kernel sets 10 / 11 (panel path): q / k / v^T as single-plane fp16, attention on set 7's kernels with o in sets 3 / 4's format
   const bool attn16 = o_f8 && h->attn_f16 && h->panel_path;
+  // Panel path, fp16 + e4m3 kernels (sets 3 / 4 / 8 - 11): they convert under MODE.FP16_OVFL = 1 (an h beyond fp16's range is
+  // clamped) and their fp16 MFMAs take a NaN operand for a finite number, so an out-of-range activation cannot travel to the
+  // outputs as Inf / NaN by itself: the kernels raise ws.range_flag and rank_head_kernel writes NaN ranking logits.
+  const bool range_flagged = h->panel_path && !h->emulate && (o_f8 || (f16 && h->mlp_f8));
+  if (range_flagged) OP_HIP(h, hipMemsetAsync(ws.range_flag, 0, sizeof(int), st));
   if (fp_layout && o_f8) {
     const size_t n16 = (size_t)((r_pad - rows) / 16);
     if (n16) OP_HIP(h, hipMemsetAsync(ws.o_hi + (size_t)(rows / 16) * (H / 32) * 512, 0, n16 * (H / 32) * 512 * sizeof(u16), st));
@@ -416,6 +423,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       // (same-box A/B: sliding-window attention -5 %, whole forward +0.7 %; with the (hi, lo) bf16 whole-layer kernel
       // it measured -1 % in round 2 and stays off there unless OP_FLAG_ATTN_XCD_GROUP asks for it)
       ap.xcd_group = (h->panel_path || o_f8 || (h->cfg.flags & OP_FLAG_ATTN_XCD_GROUP)) ? 1 : 0;
+      ap.range_flag = range_flagged ? ws.range_flag : nullptr;
       const unsigned item_span = 8u * opk::ATT_ITEM_GROUP;
       const dim3 grid((ap.xcd_group ? ((unsigned)ap.n_items + item_span - 1) / item_span * item_span : (unsigned)ap.n_items) *
                       (unsigned)h->nh);
@@ -689,6 +697,7 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
       memset(&pp, 0, sizeof(pp));
       pp.r_pad = r_pad;
       pp.hidden = H;
+      pp.range_flag = range_flagged ? ws.range_flag : nullptr;
       pp.row_pos = ws.row_pos;
       pp.rope_cos = h->rope_cos[is_global ? 1 : 0];
       pp.rope_sin = h->rope_sin[is_global ? 1 : 0];
@@ -838,12 +847,14 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     hipLaunchKernelGGL(final_ln_prune_kernel, dim3(row_blocks), dim3(256), 0, st, ws.x, h->final_norm, h->cfg.norm_eps, H,
                        r_pad, ws.row_tok, ws.row_seq, ws.row_pos, h->prune_w, h->prune_b, prune_out, keep_prob,
                        h->cfg.prune_pre_final_norm ? 1 : 0, mean_pool, ws.cls,
-                       h->capture ? h->capture + (size_t)h->N * total_tokens * H : nullptr);
+                       h->capture ? h->capture + (size_t)h->N * total_tokens * H : nullptr,
+                       range_flagged ? ws.range_flag : nullptr);
     OP_TRY(L.end());
   }
   OP_TRY(L.begin(PK_RANK_HEAD));
   hipLaunchKernelGGL(rank_head_kernel, dim3((unsigned)ns), dim3(256), 0, st, ws.cls, ws.x, cu_dev, s0, ws.roff, mean_pool,
-                     H, h->nl, h->dense_t, h->head_norm, h->cfg.norm_eps, h->cls_w, h->cls_b, rank_out);
+                     H, h->nl, h->dense_t, h->head_norm, h->cfg.norm_eps, h->cls_w, h->cls_b, rank_out,
+                     range_flagged ? ws.range_flag : nullptr);
   OP_TRY(L.end());
   return OP_OK;
 }

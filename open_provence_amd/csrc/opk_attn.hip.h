@@ -34,6 +34,7 @@ struct AttnFpParams {
   int n_items;  // work items (sequence, query block) per head
   int n_heads;
   int xcd_group;  // 0: item-major grid (n_items x n_heads blocks); 1: XCD-grouped map below
+  int* range_flag;  // OF8 + H16 (kernel sets 10 / 11): raised when an output is not finite (see PanelParams::range_flag); may be NULL
 };
 
 // Block -> (work item, head), XCD-aware.  Neighbouring query blocks of a sequence read the same K / V^T rows (a
@@ -71,7 +72,7 @@ constexpr int ATT_ITEM_GROUP = 4;
 // v_mfma_f32_16x16x32_f16.  p <= 2^6 by the lazy reference; a p below 2^-24 is flushed (it is summed into l_run in fp32).
 template <int TQK, int TPV, bool O_LO, int WAVES, int KT, bool ZP = false, bool OF8 = false, int NST = 2, bool H16 = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) {
-  if constexpr (OF8) set_saturating_conversions();
+  if constexpr (OF8 && !H16) set_saturating_conversions();  // (H16: only in front of the output conversions, below)
   static_assert(!H16 || (TQK == 0 && TPV == 0 && !O_LO && !ZP), "fp16 operands: single pass only");
   constexpr int ATT_FP_BQ = WAVES * 32;
   constexpr int TILE_KEYS = 32 * KT;
@@ -411,7 +412,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped prefetches of the last tiles)
   }
 
+  if constexpr (OF8 && H16) set_saturating_conversions();  // the e4m3 lo plane of o clamps; p (<= 2^6) was converted with IEEE overflow
   if (active) {
+    bool o_bad = false;  // OF8 + H16: an output beyond fp16's range or not finite
 #pragma unroll
     for (int qf = 0; qf < 2; ++qf) {
       float l_tot = l_run[qf] + __shfl_xor(l_run[qf], 16, 64);
@@ -427,6 +430,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
                                oacc[2 * half][qf][3] * inv};
           const float v1[4] = {oacc[2 * half + 1][qf][0] * inv, oacc[2 * half + 1][qf][1] * inv,
                                oacc[2 * half + 1][qf][2] * inv, oacc[2 * half + 1][qf][3] * inv};
+          if constexpr (H16) {
+            // Kernel sets 10 / 11: q / k / v^T are fp16 and hold Inf where an activation went beyond fp16's range; the scores and
+            // o are NaN then -- but the consumer of o multiplies under MODE.FP16_OVFL = 1, where v_mfma_f32_16x16x32_f16 takes a
+            // NaN operand for a finite number and a +Inf - Inf inside the dot product likewise (microbench/mode_probe.hip): the
+            // forward would be computed from a swallowed operand.  Raise the range flag instead (rank_head_kernel -> NaN).
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o_bad |= !(fabsf(v0[r]) <= 65504.f) | !(fabsf(v1[r]) <= 65504.f);
+          }
           uint2 h0, h1;
           split4_f8(v0, h0, lo8[2 * half]);
           split4_f8(v1, h1, lo8[2 * half + 1]);
@@ -448,6 +459,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fp_kernel(AttnFpParams p) 
         store_stream16(dst, make_uint4(h0.x, h0.y, h1.x, h1.y));
         if (O_LO) store_stream16(dst + 512, make_uint4(l0.x, l0.y, l1.x, l1.y));
       }
+    }
+    if constexpr (OF8 && H16) {
+      if (o_bad && p.range_flag != nullptr) atomicOr(p.range_flag, 1);
     }
   }
 }

@@ -130,6 +130,10 @@ struct PanelParams {
   const u16* wp8;
   size_t w8_lo_off;
   u16* o0_lo8;
+  // fp16 + e4m3 kernels: raised (atomicOr 1) when a value written as an fp16 operand is beyond fp16's range or not finite --
+  // those kernels convert under MODE.FP16_OVFL = 1 (clamp) and their MFMAs swallow a NaN operand; rank_head_kernel turns the
+  // flag into NaN outputs.  May be NULL.
+  int* range_flag;
 };
 
 // T = term mask (left = the fragment-packed activation, right = the weight panel); OLO bit 0: o0 (q / v^T / h) gets a
@@ -623,6 +627,7 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
       }
       return;
     }
+    bool out_of_range = false;  // an h beyond fp16's range (the conversion below clamps it) or not finite
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
       const size_t rb = (size_t)((m0 >> 4) + mf);
@@ -634,6 +639,7 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
         for (int r = 0; r < 4; ++r) {
           va[r] = gelu_erf(acc[2 * s][mf][r]) * acc[8 + 2 * s][mf][r];
           vb[r] = gelu_erf(acc[2 * s + 1][mf][r]) * acc[8 + 2 * s + 1][mf][r];
+          out_of_range |= !(fabsf(va[r]) <= 65504.f) | !(fabsf(vb[r]) <= 65504.f);
         }
         uint2 h0, h1;
         split4_f8(va, h0, lo8[2 * s]);
@@ -645,10 +651,19 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
         store_stream16(p.o0_lo8 + (rb * (kb_out >> 1) + (size_t)(tile * 2 + pr)) * 512 + lane * 8,
                        make_uint4(lo8[4 * pr], lo8[4 * pr + 1], lo8[4 * pr + 2], lo8[4 * pr + 3]));
     }
+    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0 && lane == 0 && p.range_flag != nullptr) atomicOr(p.range_flag, 1);
   } else if (EPI == PE_QK) {
     // O16: q / k become fp16 operands -- beyond fp16's range they turn into Inf (and the outputs into NaN: the range guard of
     // the Python layer repeats the batch on the (hi, lo) bf16 sets) instead of a silently clamped 65504
-    if constexpr (O16) set_overflowing_conversions();
+    if constexpr (O16) {
+      set_overflowing_conversions();
+      // (the mode write is an asm statement and a conversion has no dependency on it: the accumulators pass through empty asm
+      // statements behind it -- volatile asm keeps its order, and every conversion below depends on one of these values)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) asm volatile("" : "+v"(acc[nf][mf]));
+    }
     const int per = p.hidden / 256;
     const bool is_q = tile < per;
     const int tq = is_q ? tile : tile - per;
@@ -690,7 +705,13 @@ __device__ __forceinline__ void panel_f8_block(const PanelParams& p, int row_blo
       }
     }
   } else {  // PE_V
-    if constexpr (O16) set_overflowing_conversions();
+    if constexpr (O16) {
+      set_overflowing_conversions();
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) asm volatile("" : "+v"(acc[nf][mf]));
+    }
     const size_t tb = (size_t)(m0 >> 5);
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void final_ln_prune_kernel(float* __restrict__
                                                              const float* __restrict__ pw, const float* __restrict__ pb,
                                                              float* __restrict__ prune_out, float* __restrict__ keep_prob,
                                                              int pre_norm, int keep_all_rows, float* __restrict__ cls,
-                                                             float* __restrict__ capture) {
+                                                             float* __restrict__ capture, const int* __restrict__ range_flag) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= r_pad) return;
@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void final_ln_prune_kernel(float* __restrict__
   d0 = wave_sum(d0);
   d1 = wave_sum(d1);
   if (lane == 0) {
-    const float l0 = d0 + pb[0], l1 = d1 + pb[1];
+    // range_flag: see rank_head_kernel -- the pruning logits of a flagged chunk leave as NaN too
+    const float poison = (range_flag != nullptr && *range_flag != 0) ? __builtin_nanf("") : 0.f;
+    const float l0 = d0 + pb[0] + poison, l1 = d1 + pb[1] + poison;
     prune_out[(size_t)tok * 2 + 0] = l0;
     prune_out[(size_t)tok * 2 + 1] = l1;
     if (keep_prob) keep_prob[tok] = 1.0f / (1.0f + expf(l0 - l1));
@@ -268,7 +270,12 @@ __global__ __launch_bounds__(256) void rank_head_kernel(const float* __restrict_
                                                         const float* __restrict__ dense_t,
                                                         const float* __restrict__ head_norm, float eps,
                                                         const float* __restrict__ cls_w, const float* __restrict__ cls_b,
-                                                        float* __restrict__ rank_out) {
+                                                        float* __restrict__ rank_out, const int* __restrict__ range_flag) {
+  // range_flag (may be NULL): raised by a kernel of the fp16 + e4m3 format that met an activation beyond fp16's range (or a
+  // non-finite one) where the format cannot say so itself -- under MODE.FP16_OVFL = 1 conversions clamp and the fp16 MFMA
+  // takes a NaN operand for a finite number (microbench/mode_probe.hip).  The ranking logits of the chunk then leave as NaN:
+  // the same signal as an Inf that travelled through the residual stream, which the callers' range guard acts on.
+  const bool poisoned = range_flag != nullptr && *range_flag != 0;
   __shared__ float pooled[1024];
   __shared__ float z[1024];
   __shared__ float red[4];
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void rank_head_kernel(const float* __restrict_
     float part = 0.f;
     for (int n = tid; n < H; n += 256) part += (z[n] - mean) * rstd * head_norm[n] * cls_w[(size_t)c * H + n];
     const float tot = block_sum_256(part, red);
-    if (tid == 0) rank_out[(size_t)(s0 + s) * nl + c] = tot + cls_b[c];
+    if (tid == 0) rank_out[(size_t)(s0 + s) * nl + c] = poisoned ? __builtin_nanf("") : tot + cls_b[c];
   }
 }
 

@@ -243,5 +243,10 @@ def named_dims(name: str, **overrides: int) -> EncoderDims:
         cls_token_id=1,
         sep_token_id=2,
     )
+    if "num_layers" in overrides:  # the EncoderDims name of the HF key
+        overrides["num_hidden_layers"] = overrides.pop("num_layers")
+    unknown = sorted(set(overrides) - set(cfg))
+    if unknown:  # (an ignored override runs a different model than the caller asked for)
+        raise TypeError(f"named_dims: unknown override(s) {unknown}; known: {sorted(cfg)}")
     cfg.update(overrides)
     return EncoderDims.from_base_model_config(cfg, num_labels=1)

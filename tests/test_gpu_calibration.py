@@ -109,7 +109,7 @@ def test_o1_weights_keep_the_default_kernel_sets(model, weights, default_set):
     from open_provence_amd.engine import HipEncoder
     from open_provence_amd.synthetic import named_dims, synth_state_dict
 
-    dims = named_dims(model, **({"num_layers": 4} if model == "base" else {}))
+    dims = named_dims(model)
     state = synth_state_dict(dims, seed=7)
     if weights == "bf16":
         state = _bf16_rounded(state)
@@ -117,7 +117,7 @@ def test_o1_weights_keep_the_default_kernel_sets(model, weights, default_set):
     enc.load_state_dict(state)
     cal = enc.calibration
     assert cal["default_set"] == default_set == cal["chosen_set"] == enc.effective_policy()["kernel_set"], cal
-    # xsmall: orders of magnitude (10 layers; >= 1.8e-2); base cut to 4 layers here: its Wi-only variants sit at 3.5-5e-4
+    # xsmall: orders of magnitude (10 layers; >= 1.8e-2); base (19 layers): its Wi-only variants sit at 3.5-5e-4
     assert cal["candidates"] and all(err > (100 if model == "xsmall" else 2) * cal["tolerance"] for err in cal["candidates"].values()), cal
     enc.close()
 
@@ -306,9 +306,10 @@ def test_an_activation_beyond_fp16_range_leaves_the_f16_set_too():
 
 
 def test_a_query_beyond_fp16_range_is_loud_on_the_fp16_attention_sets():
-    """Sets 10 / 11 write q, k, v^T as fp16: a q beyond 65504 (here the q rows of one layer's Wqkv x 2e6) becomes Inf there --
-    non-finite outputs, not a clamped operand -- while set 4 (q as (hi, lo) bf16) computes it; the guarded forward repeats the
-    batch on the (hi, lo) bf16 kernels and the model stays there."""
+    """Sets 10 / 11 write q, k, v^T as fp16: a q beyond 65504 (here the q rows of one layer's Wqkv x 1.2e6) becomes Inf there,
+    the attention output NaN -- which the fp16 MFMAs of the attention output projection (MODE.FP16_OVFL = 1) would take for a
+    finite number: the attention kernel raises the range flag and the heads write NaN logits -- while set 4 (q as (hi, lo)
+    bf16) computes it; the guarded forward repeats the batch on the (hi, lo) bf16 kernels and the model stays there."""
 
     from open_provence_amd.engine import HipEncoder
     from open_provence_amd.packing import pack_rows
@@ -319,7 +320,7 @@ def test_a_query_beyond_fp16_range_is_loud_on_the_fp16_attention_sets():
     key = "ranking_model.model.layers.1.attn.Wqkv.weight"
     assert key in state
     w = state[key].clone()
-    w[: dims.hidden_size] *= 2.0e6
+    w[: dims.hidden_size] *= 1.2e6  # (the weights themselves stay inside fp16: 0.04 x 1.2e6 < 65504)
     state[key] = w
     rows = [r[:n] for r, n in zip(synth_pair_batch(dims, 4, 256, seed=11), (256, 40, 130, 17))]
     ids_np, cu_np, max_len = pack_rows(rows)
@@ -343,8 +344,51 @@ def test_a_query_beyond_fp16_range_is_loud_on_the_fp16_attention_sets():
             assert enc.effective_policy()["kernel_set"] == "bf16x3" and not enc.f8_active()
         enc.close()
     assert np.isfinite(outs["bf16x3"][0]).all() and np.isfinite(outs["f16-f8-w"][0]).all()
-    assert not np.isfinite(outs["f16-f8-w+attn-f16"][0]).all()  # loud
+    assert not np.isfinite(outs["f16-f8-w+attn-f16"][0]).any() and not np.isfinite(outs["f16-f8-w+attn-f16"][1]).any()  # loud: the range flag
     assert np.array_equal(outs["guarded"][0], outs["bf16x3"][0]) and np.array_equal(outs["guarded"][1], outs["bf16x3"][1])
+
+
+@pytest.mark.parametrize("kernel_set", ["f16-f8-w", "f16+mlp-f16-f8-w", "f16-f8-w+attn-f16"])
+def test_an_mlp_activation_beyond_fp16_range_is_loud_on_the_panel_path(kernel_set):
+    """Panel path (hidden 512): the fp16 + e4m3 GEMM kernels convert under MODE.FP16_OVFL = 1 -- an h of 1e6 would be clamped to
+    65504 -- and their fp16 MFMAs take a NaN operand for a finite number (microbench/mode_probe.hip), so an out-of-range
+    activation cannot reach the outputs as Inf / NaN by itself (before the range flag: finite logits off by 3.75).  The Wi + GeGLU
+    epilogue raises the workspace's range flag and the heads write NaN logits: loud, and the guarded forward repeats the batch
+    on the (hi, lo) bf16 kernels and stays there."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.packing import pack_rows
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch
+
+    dims = named_dims("base", num_layers=3, vocab_size=4096)
+    state = refinit_state_dict(dims, seed=5)
+    key = "ranking_model.model.layers.1.mlp.Wi.weight"
+    state[key] = state[key] * 3000.0  # h ~ 1e6 in that layer; the next LayerNorm normalises the huge MLP output
+    rows = [r[:n] for r, n in zip(synth_pair_batch(dims, 4, 256, seed=11), (256, 40, 130, 17))]
+    ids_np, cu_np, max_len = pack_rows(rows)
+
+    def run(enc, checked):
+        ids, cu = torch.from_numpy(ids_np).to(enc.device), torch.from_numpy(cu_np).to(enc.device)
+        prune, rank = (enc.forward_packed_checked if checked else enc.forward_packed)(ids, cu, cu_np, max_len)
+        torch.cuda.synchronize()
+        return prune.cpu().numpy(), rank.cpu().numpy()
+
+    ref_enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    ref_enc.load_state_dict(state, kernel_set="bf16x3")
+    ref_p, ref_r = run(ref_enc, False)
+    ref_enc.close()
+    assert np.isfinite(ref_p).all() and np.isfinite(ref_r).all()
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(state, kernel_set=kernel_set)
+    raw_p, raw_r = run(enc, False)
+    assert not np.isfinite(raw_p).any() and not np.isfinite(raw_r).any()  # every logit of the flagged chunk
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        p, r = run(enc, True)
+        assert caught
+    assert enc.effective_policy()["kernel_set"] == "bf16x3" and not enc.f8_active()
+    assert np.array_equal(p, ref_p) and np.array_equal(r, ref_r)
+    enc.close()
 
 
 def test_first_real_batch_audits_the_calibrated_set():
@@ -356,7 +400,7 @@ def test_first_real_batch_audits_the_calibrated_set():
     from open_provence_amd.packing import pack_rows
     from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch
 
-    dims = named_dims("xsmall", num_layers=4)
+    dims = named_dims("xsmall")
     state = refinit_state_dict(dims, seed=7)
     rows = synth_pair_batch(dims, 6, [200, 64, 130, 31, 257, 40], seed=9)
     rows[5] = rows[5][:3]  # a three-token row too
