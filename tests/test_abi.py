@@ -91,3 +91,16 @@ def test_product_kernel_headers_carry_no_ablation_switches(tmp_path):
         applied = subprocess.run(["patch", "-p1", "-s"], stdin=fh, cwd=tmp_path, capture_output=True, text=True)
     assert applied.returncode == 0, applied.stdout + applied.stderr
     assert "OPK_ABL_NO_DMA" in (dst / "csrc" / "opk_rowgemm_mlp_loop.inc").read_text()  # (the kernel body is cut by phase into .inc files)
+
+
+def test_named_dims_overrides_are_checked():
+    """An override that named_dims does not know must not be dropped silently (``num_layers=3`` once ran the full-depth model);
+    ``num_layers`` is accepted as the EncoderDims name of ``num_hidden_layers``."""
+
+    from open_provence_amd.synthetic import named_dims
+
+    assert named_dims("base").num_layers == 19
+    assert named_dims("base", num_layers=3).num_layers == 3 == named_dims("base", num_hidden_layers=3).num_layers
+    assert named_dims("xsmall", vocab_size=2048).vocab_size == 2048
+    with pytest.raises(TypeError):
+        named_dims("base", layers=3)
