@@ -313,91 +313,137 @@ struct AttnPlan {
   int items_l;  // ... of a sliding-window layer (128-query blocks)
 };
 
-int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t* ids_dev, const int32_t* cu_dev, int s0,
-                  int ns, int rows, int max_len, int total_tokens, const AttnPlan& plan, float* prune_out, float* rank_out,
-                  float* keep_prob) {
-  const int H = h->H, I = h->I;
-  // Row path: exactly the computed rows, rounded to the 128-row block -- no slack rows: a 131072-row batch is 1024
-  // blocks = two full rounds of 2 blocks per CU; two extra (empty) blocks would cost a third round.  The tiled path
-  // keeps 64 slack rows for its attention kernel's tile over-read.
-  const bool fp_layout = h->row_path || h->panel_path;  // fragment-packed activations, attn_fp_kernel
-  const int r_pad = fp_layout ? align_up(rows, ROW_BM) : align_up(rows + 64, 256);
-  const int m_tiles = r_pad / GEMM_BM;
-  const unsigned row_blocks = (unsigned)((r_pad + 3) / 4);
-  hipStream_t st = L.stream;
+// One chunk of sequences through the whole encoder: the launch sequence of a forward.  The arguments and what every path
+// derives from them are members; prologue() (row map, padding rows, embeddings), one *_layer() per path and layer, heads().
+struct ChunkPass {
+  op_handle* h;
+  Launcher& L;
+  const Workspace& ws;
+  const int32_t* ids_dev;
+  const int32_t* cu_dev;
+  int s0, ns, rows, max_len, total_tokens;
+  const AttnPlan& plan;
+  float *prune_out, *rank_out, *keep_prob;
 
-  // Evaluated policy E, instantiated kernel set V (V has every term of E).  Where V multiplies by a lo operand that
-  // E does not have, that operand is cleared: weights at load time (op_load_weight), activations right here.
-  const Policy E = h->eff, V = opl::kPolicies[h->pi];
-  auto extra = [](int v, int e, int bit) { return (v & bit) != 0 && (e & bit) == 0; };
-  const bool clr_q = extra(V.qk, E.qk, 1), clr_k = extra(V.qk, E.qk, 2), clr_v = extra(V.pv, E.pv, 2);
-  const bool clr_o = extra(V.attn_out, E.attn_out, 1), clr_h = extra(V.mlp_out, E.mlp_out, 1);
-  const bool clr_ln_attn = extra(V.wqkv, E.wqkv, 1), clr_ln_mlp = extra(V.wi, E.wi, 1);
-  const bool zero_p_lo = extra(V.pv, E.pv, 1);
-  // tiled path: two kernel sets only (single pass / all terms)
-  const bool split = (E.wqkv | E.qk | E.pv | E.attn_out | E.wi | E.mlp_out) != 0;
+  int H, I;
+  bool fp_layout;  // fragment-packed activations, attn_fp_kernel
+  int r_pad, m_tiles;
+  unsigned row_blocks;
+  hipStream_t st;
+  Policy E, V;  // evaluated policy, instantiated kernel set (V has every term of E)
+  bool clr_q, clr_k, clr_v, clr_o, clr_h, clr_ln_attn, clr_ln_mlp, zero_p_lo, split;
+  bool o_f8, f16, attn16, range_flagged, embed_in_qkv0;
+  size_t plane_bytes;  // one row-major plane (tiled path)
+  int q_tiles;
+  bool small_blocks;
+  unsigned row_grid;
+  const char* no_kernel = "internal: no row-stationary kernel for hidden %d";
+  bool layer_fused, head_in_last_layer;
+  bool head_done = false;
 
-  OP_TRY(L.begin(PK_ROWMAP));
-  hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, ROW_ALIGN, ROW_ALIGN, ws.roff);
-  if (fp_layout) {
-    hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, plan.waves_g * 32, 1, ws.qboff);
-    hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, 128, 1, ws.qboff_l);
+  ChunkPass(op_handle* h_, Launcher& L_, const Workspace& ws_, const int32_t* ids_dev_, const int32_t* cu_dev_, int s0_, int ns_, int rows_,
+            int max_len_, int total_tokens_, const AttnPlan& plan_, float* prune_out_, float* rank_out_, float* keep_prob_)
+      : h(h_), L(L_), ws(ws_), ids_dev(ids_dev_), cu_dev(cu_dev_), s0(s0_), ns(ns_), rows(rows_), max_len(max_len_),
+        total_tokens(total_tokens_), plan(plan_), prune_out(prune_out_), rank_out(rank_out_), keep_prob(keep_prob_) {
+    H = h->H;
+    I = h->I;
+    // Row path: exactly the computed rows, rounded to the 128-row block -- no slack rows: a 131072-row batch is 1024
+    // blocks = two full rounds of 2 blocks per CU; two extra (empty) blocks would cost a third round.  The tiled path
+    // keeps 64 slack rows for its attention kernel's tile over-read.
+    fp_layout = h->row_path || h->panel_path;
+    r_pad = fp_layout ? align_up(rows, ROW_BM) : align_up(rows + 64, 256);
+    m_tiles = r_pad / GEMM_BM;
+    row_blocks = (unsigned)((r_pad + 3) / 4);
+    st = L.stream;
+    // Evaluated policy E, instantiated kernel set V (V has every term of E).  Where V multiplies by a lo operand that
+    // E does not have, that operand is cleared: weights at load time (op_load_weight), activations in the launch sequence.
+    E = h->eff;
+    V = opl::kPolicies[h->pi];
+    auto extra = [](int v, int e, int bit) { return (v & bit) != 0 && (e & bit) == 0; };
+    clr_q = extra(V.qk, E.qk, 1);
+    clr_k = extra(V.qk, E.qk, 2);
+    clr_v = extra(V.pv, E.pv, 2);
+    clr_o = extra(V.attn_out, E.attn_out, 1);
+    clr_h = extra(V.mlp_out, E.mlp_out, 1);
+    clr_ln_attn = extra(V.wqkv, E.wqkv, 1);
+    clr_ln_mlp = extra(V.wi, E.wi, 1);
+    zero_p_lo = extra(V.pv, E.pv, 1);
+    // tiled path: two kernel sets only (single pass / all terms)
+    split = (E.wqkv | E.qk | E.pv | E.attn_out | E.wi | E.mlp_out) != 0;
+    o_f8 = (h->pi == opl::PI_F16_F8 || h->pi == opl::PI_F16_F8_W) && !h->emulate;  // o = fp16 pieces (ws.o_hi) + e4m3 pieces (ws.o_lo)
+    f16 = h->pi == opl::PI_F16 && !h->emulate;  // kernel set "f16": set 2's layouts, fp16 values, the fp16 weight packs
+    // kernel sets 10 / 11 (panel path): q / k / v^T as single-plane fp16, attention on set 7's kernels with o in sets 3 / 4's format
+    attn16 = o_f8 && h->attn_f16 && h->panel_path;
+    // Panel path, fp16 + e4m3 kernels (sets 3 / 4 / 8 - 11): they convert under MODE.FP16_OVFL = 1 (an h beyond fp16's range is
+    // clamped) and their fp16 MFMAs take a NaN operand for a finite number, so an out-of-range activation cannot travel to the
+    // outputs as Inf / NaN by itself: the kernels raise ws.range_flag and the head kernels write NaN logits.
+    range_flagged = h->panel_path && !h->emulate && (o_f8 || (f16 && h->mlp_f8));
+    // Row path without hidden-state capture: the layer-0 q / k / v kernel gathers and normalises the embeddings itself
+    // (RowGemmParams::emb_table) -- no embedding launch, the residual rows are written once and not read back.
+    embed_in_qkv0 = h->row_path && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
+    plane_bytes = (size_t)r_pad * H * sizeof(u16);
+    q_tiles = (max_len + ATT_BQ - 1) / ATT_BQ;
+    // 4 waves x 32 rows = 128-row blocks, two per CU.  Small batches (at most one such block per CU) use 4 waves x
+    // 16 rows = 64-row blocks instead: twice the blocks, so a latency-bound request spreads over twice the CUs.
+    small_blocks = (r_pad / ROW_BM) <= h->n_cus && !(h->cfg.flags & OP_FLAG_NO_SMALL_BLOCKS);
+    row_grid = (unsigned)(r_pad / (small_blocks ? 64 : ROW_BM));
+    // Kernel sets whose GEMM weights are single-plane run a whole layer (attention output projection, MLP, next q/k/v
+    // projection) as ONE kernel with h kept on chip; the all-terms set keeps the two fused kernels per layer.
+    layer_fused = h->row_path && !h->emulate && opl::has_row_layer_fused(h->pi) && !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION);
+    head_in_last_layer = layer_fused && h->cfg.pooling != OP_POOL_MEAN && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
   }
-  hipLaunchKernelGGL(row_map_kernel, dim3((unsigned)((r_pad + 255) / 256)), dim3(256), 0, st, cu_dev, s0, ns, ws.roff,
-                     r_pad, ws.row_seq, ws.row_pos, ws.row_tok);
-  OP_TRY(L.end());
 
-  // rows >= `rows` are never produced by the attention kernel: keep its output finite there
-  const bool o_f8 = (h->pi == opl::PI_F16_F8 || h->pi == opl::PI_F16_F8_W) && !h->emulate;  // o = fp16 pieces (ws.o_hi) + e4m3 pieces (ws.o_lo)
-  const bool f16 = h->pi == opl::PI_F16 && !h->emulate;  // kernel set "f16": set 2's layouts, fp16 values, the fp16 weight packs
-  // kernel sets 10 / 11 (panel path): q / k / v^T as single-plane fp16, attention on set 7's kernels with o in sets 3 / 4's format
-  const bool attn16 = o_f8 && h->attn_f16 && h->panel_path;
-  // Panel path, fp16 + e4m3 kernels (sets 3 / 4 / 8 - 11): they convert under MODE.FP16_OVFL = 1 (an h beyond fp16's range is
-  // clamped) and their fp16 MFMAs take a NaN operand for a finite number, so an out-of-range activation cannot travel to the
-  // outputs as Inf / NaN by itself: the kernels raise ws.range_flag and rank_head_kernel writes NaN ranking logits.
-  const bool range_flagged = h->panel_path && !h->emulate && (o_f8 || (f16 && h->mlp_f8));
-  if (range_flagged) OP_HIP(h, hipMemsetAsync(ws.range_flag, 0, sizeof(int), st));
-  if (fp_layout && o_f8) {
-    const size_t n16 = (size_t)((r_pad - rows) / 16);
-    if (n16) OP_HIP(h, hipMemsetAsync(ws.o_hi + (size_t)(rows / 16) * (H / 32) * 512, 0, n16 * (H / 32) * 512 * sizeof(u16), st));
-    if (n16) OP_HIP(h, hipMemsetAsync(ws.o_lo + (size_t)(rows / 16) * h->nh * 512, 0, n16 * h->nh * 512 * sizeof(u16), st));
-  } else if (fp_layout) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
-    const size_t tail_off = (size_t)(rows / 16) * (H / 32) * 2 * 512;
-    const size_t tail_bytes = (size_t)((r_pad - rows) / 16) * (H / 32) * 2 * 512 * sizeof(u16);
-    if (tail_bytes) OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));  // (a zero-byte node fails stream capture)
-  } else {
-    const size_t tail_off = (size_t)rows * H;
-    const size_t tail_bytes = (size_t)(r_pad - rows) * H * sizeof(u16);
-    if (tail_bytes) OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
-    if (tail_bytes && split) OP_HIP(h, hipMemsetAsync(ws.o_lo + tail_off, 0, tail_bytes, st));
-  }
-
-  // Row path without hidden-state capture: the layer-0 q / k / v kernel gathers and normalises the embeddings itself
-  // (RowGemmParams::emb_table) -- no embedding launch, the residual rows are written once and not read back.
-  const bool embed_in_qkv0 = h->row_path && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
-  if (!embed_in_qkv0) {
-    OP_TRY(L.begin(PK_EMBED_LN));
-    if (split)
-      hipLaunchKernelGGL((embed_ln_kernel<true>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
-                         h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
-    else
-      hipLaunchKernelGGL((embed_ln_kernel<false>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
-                         h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
+  // row map, the range flag, padding rows of the attention output, embeddings
+  int prologue() {
+    OP_TRY(L.begin(PK_ROWMAP));
+    hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, ROW_ALIGN, ROW_ALIGN, ws.roff);
+    if (fp_layout) {
+      hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, plan.waves_g * 32, 1, ws.qboff);
+      hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, cu_dev, s0, ns, 128, 1, ws.qboff_l);
+    }
+    hipLaunchKernelGGL(row_map_kernel, dim3((unsigned)((r_pad + 255) / 256)), dim3(256), 0, st, cu_dev, s0, ns, ws.roff,
+                       r_pad, ws.row_seq, ws.row_pos, ws.row_tok);
     OP_TRY(L.end());
+
+    // rows >= `rows` are never produced by the attention kernel: keep its output finite there
+    if (range_flagged) OP_HIP(h, hipMemsetAsync(ws.range_flag, 0, sizeof(int), st));
+    if (fp_layout && o_f8) {
+      const size_t n16 = (size_t)((r_pad - rows) / 16);
+      if (n16) OP_HIP(h, hipMemsetAsync(ws.o_hi + (size_t)(rows / 16) * (H / 32) * 512, 0, n16 * (H / 32) * 512 * sizeof(u16), st));
+      if (n16) OP_HIP(h, hipMemsetAsync(ws.o_lo + (size_t)(rows / 16) * h->nh * 512, 0, n16 * h->nh * 512 * sizeof(u16), st));
+    } else if (fp_layout) {  // fragment-packed o: pieces of 16 rows, hi/lo interleaved, o_hi + o_lo are one buffer
+      const size_t tail_off = (size_t)(rows / 16) * (H / 32) * 2 * 512;
+      const size_t tail_bytes = (size_t)((r_pad - rows) / 16) * (H / 32) * 2 * 512 * sizeof(u16);
+      if (tail_bytes) OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));  // (a zero-byte node fails stream capture)
+    } else {
+      const size_t tail_off = (size_t)rows * H;
+      const size_t tail_bytes = (size_t)(r_pad - rows) * H * sizeof(u16);
+      if (tail_bytes) OP_HIP(h, hipMemsetAsync(ws.o_hi + tail_off, 0, tail_bytes, st));
+      if (tail_bytes && split) OP_HIP(h, hipMemsetAsync(ws.o_lo + tail_off, 0, tail_bytes, st));
+    }
+
+    if (!embed_in_qkv0) {
+      OP_TRY(L.begin(PK_EMBED_LN));
+      if (split)
+        hipLaunchKernelGGL((embed_ln_kernel<true>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
+                           h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
+      else
+        hipLaunchKernelGGL((embed_ln_kernel<false>), dim3(row_blocks), dim3(256), 0, st, ids_dev, ws.row_tok, h->emb,
+                           h->emb_norm, h->cfg.norm_eps, H, r_pad, h->V, ws.x, ws.ln_hi, ws.ln_lo);
+      OP_TRY(L.end());
+    }
+    return OP_OK;
   }
 
-  auto capture = [&](int index) -> int {
+  int capture(int index) {
     if (!h->capture) return OP_OK;
     OP_TRY(L.begin(PK_CAPTURE));
     hipLaunchKernelGGL(capture_rows_kernel, dim3(row_blocks), dim3(256), 0, st, ws.x, ws.row_tok, H, r_pad,
                        h->capture + (size_t)index * total_tokens * H);
     return L.end();
-  };
+  }
 
-  const size_t plane_bytes = (size_t)r_pad * H * sizeof(u16);  // one row-major plane (tiled path)
-  const int q_tiles = (max_len + ATT_BQ - 1) / ATT_BQ;
-
-  auto attention = [&](bool is_global) -> int {
+  int attention(bool is_global) {
     OP_TRY(L.begin(is_global ? PK_ATTN_GLOBAL : PK_ATTN_LOCAL));
     const int window = is_global ? -1 : h->cfg.local_attention / 2;
     if (fp_layout) {
@@ -456,21 +502,21 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     if (fp_layout && clr_o) OP_TRY(clear_lo(L, ws.o_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
     if (!fp_layout && split && !(E.attn_out & 1)) OP_HIP(h, hipMemsetAsync(ws.o_lo, 0, plane_bytes, st));
     return OP_OK;
-  };
+  }
   // fragment-packed q / k / v^T just written by a q/k/v projection: clear what the policy does not carry
-  auto clear_qkv = [&]() -> int {
+  int clear_qkv() {
     if (clr_q) OP_TRY(clear_lo(L, ws.q_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
     if (clr_k) OP_TRY(clear_lo(L, ws.k_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
     if (clr_v) OP_TRY(clear_lo(L, ws.vt_hi, 2048, (size_t)h->nh * (r_pad / 32)));
     return OP_OK;
-  };
-  auto clear_h = [&]() -> int {
+  }
+  int clear_h() {
     if (clr_h) OP_TRY(clear_lo(L, ws.h_hi, 512, (size_t)(r_pad / 16) * (I / 32)));
     return OP_OK;
-  };
+  }
 
   // parameters of a q/k/v projection of layer `li` (row-stationary kernels)
-  auto qkv_params = [&](int li) {
+  RowGemmParams qkv_params(int li) {
     const LayerWeights& lw = h->layers[li];
     const bool is_global = h->cfg.layer_is_global[li] != 0;
     RowGemmParams rp;
@@ -493,268 +539,263 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     rp.ld_out = H;
     rp.zero_a_lo = clr_ln_attn ? 1 : 0;
     return rp;
-  };
-  // 4 waves x 32 rows = 128-row blocks, two per CU.  Small batches (at most one such block per CU) use 4 waves x
-  // 16 rows = 64-row blocks instead: twice the blocks, so a latency-bound request spreads over twice the CUs.
-  const bool small_blocks = (r_pad / ROW_BM) <= h->n_cus && !(h->cfg.flags & OP_FLAG_NO_SMALL_BLOCKS);
-  const unsigned row_grid = (unsigned)(r_pad / (small_blocks ? 64 : ROW_BM));
-  const char* no_kernel = "internal: no row-stationary kernel for hidden %d";
-  // Kernel sets whose GEMM weights are single-plane run a whole layer (attention output projection, MLP, next q/k/v
-  // projection) as ONE kernel with h kept on chip; the all-terms set keeps the two fused kernels per layer.
-  const bool layer_fused = h->row_path && !h->emulate && opl::has_row_layer_fused(h->pi) && !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION);
-  const bool head_in_last_layer = layer_fused && h->cfg.pooling != OP_POOL_MEAN && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
-  bool head_done = false;
+  }
 
-  for (int li = 0; li < h->N; ++li) {
+  // one layer on the row path: (layer 0: q / k / v) -> attention -> the whole-layer kernel, or the two fused kernels of set 0
+  int row_layer(int li) {
     const LayerWeights& lw = h->layers[li];
     const bool is_global = h->cfg.layer_is_global[li] != 0;
-    OP_TRY(capture(li));
-
-    if (h->row_path) {
-      // ---- row-stationary path (hidden <= 256): three launches per layer ------------------------------
-      if (li == 0) {  // layer 0 has no attn_norm: split x0 directly
-        RowGemmParams rp = qkv_params(0);
-        if (embed_in_qkv0) {
-          rp.emb_table = h->emb;
-          rp.emb_ids = ids_dev;
-          rp.emb_vocab = h->V;
-          rp.row_tok = ws.row_tok;
-          rp.ln_w = h->emb_norm;
-          rp.x_io = ws.x;
-        }
-        OP_TRY(L.begin(PK_ROW_QKV));
-        if (!opl::launch_row_qkv0(st, rp, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
-        OP_TRY(L.end());
-        OP_TRY(clear_qkv());
-      }  // else: q/k/v of this layer were produced by the fused kernel that closed layer li-1
-      OP_TRY(attention(is_global));
-
-      if (layer_fused) {
-        // x += o Wo^T ; x += GeGLU(LN(x) Wi^T) Wo^T ; q, k, v^T of the NEXT layer -- one kernel, h stays on chip
-        const bool with_qkv = li + 1 < h->N;
-        if ((h->cfg.flags & OP_FLAG_LAYER_M32) && lw.wo_p32 && opl::has_layer32(h->pi) && I % 64 == 0) {
-          // hidden = 256, on request: the same launch on the 32x32x16 MFMA shape (opk_layer32.hip.h) -- 6 % fewer
-          // cycles, but that shape draws more power per flop and the chip clocks lower under it
-          Layer32Params lp;
-          memset(&lp, 0, sizeof(lp));
-          const LayerWeights& nx = h->layers[with_qkv ? li + 1 : li];
-          lp.o_fp = ws.o_hi;
-          lp.x_io = ws.x;
-          lp.ln_mlp = lw.mlp_norm;
-          lp.ln_next = with_qkv ? nx.attn_norm : nullptr;
-          lp.eps = h->cfg.norm_eps;
-          lp.wo_p = lw.wo_p32;
-          lp.wi_p = lw.wi_p32;
-          lp.wo2_p = lw.wo2_p32;
-          lp.wqkv_p = nx.wqkv_p32;
-          lp.n_pairs = I / 32;
-          lp.q_fp = ws.q_hi;
-          lp.k_fp = ws.k_hi;
-          lp.vt_fp = ws.vt_hi;
-          lp.r_pad = r_pad;
-          lp.row_pos = ws.row_pos;
-          const int gl = h->cfg.layer_is_global[with_qkv ? li + 1 : li] ? 1 : 0;
-          lp.rope_cos = h->rope_cos[gl];
-          lp.rope_sin = h->rope_sin[gl];
-          lp.max_pos = h->max_pos;
-          OP_TRY(L.begin(PK_FUSED_LAYER));
-          if (!opl::launch_layer32(st, lp, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM))) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
-          OP_TRY(L.end());
-          continue;
-        }
-        RowGemmParams rl = qkv_params(with_qkv ? li + 1 : li);
-        rl.a1_fp = ws.o_hi;
-        rl.w1p = f16 ? lw.wo_h16 : lw.wo_ks;
-        rl.k1_steps = H / 32;
-        rl.x_io = ws.x;
-        rl.ln_w_mlp = lw.mlp_norm;
-        rl.wi_pk = f16 ? lw.wi_h16 : lw.wi_pk;
-        rl.wo2_ks = f16 ? lw.wo2_h16 : lw.wo2_pk;
-        rl.n_pairs = I / 32;
-        if (o_f8) {  // the "f16 + fp8" packs of the same weights
-          rl.a1_lo8 = ws.o_lo;
-          rl.w1p = lw.wo_f16;
-          rl.w1p8 = lw.wo_f8;
-          rl.wi_pk = lw.wi_f8;
-          rl.wo2_ks = lw.wo2_f16;
-          rl.wp = h->layers[with_qkv ? li + 1 : li].wqkv_f8;
-        }
-        if (!with_qkv && head_in_last_layer) {
-          // the last layer's rows go straight through final_norm + the pruning head (no write-back of x, no
-          // final_ln_prune launch); mean pooling and hidden-state capture need all normalised rows and keep the kernel
-          rl.fin_ln = h->final_norm;
-          rl.fin_pw = h->prune_w;
-          rl.fin_pb = h->prune_b;
-          rl.row_tok = ws.row_tok;
-          rl.row_seq = ws.row_seq;
-          rl.fin_prune = prune_out;
-          rl.fin_keep = keep_prob;
-          rl.fin_cls = ws.cls;
-          rl.fin_pre_norm = h->cfg.prune_pre_final_norm ? 1 : 0;
-          head_done = true;
-        }
-        OP_TRY(L.begin(PK_FUSED_LAYER));
-        if (!opl::launch_row_layer_fused(st, rl, H / 32, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM),
-                                         (h->cfg.flags & OP_FLAG_LAYER_8X16) != 0 || (opl::kPolicies[h->pi].wi & 1) == 0))
-          return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
-        OP_TRY(L.end());
-        continue;
+    // ---- row-stationary path (hidden <= 256): three launches per layer ------------------------------
+    if (li == 0) {  // layer 0 has no attn_norm: split x0 directly
+      RowGemmParams rp = qkv_params(0);
+      if (embed_in_qkv0) {
+        rp.emb_table = h->emb;
+        rp.emb_ids = ids_dev;
+        rp.emb_vocab = h->V;
+        rp.row_tok = ws.row_tok;
+        rp.ln_w = h->emb_norm;
+        rp.x_io = ws.x;
       }
-
-      // x += o Wo^T ; h = GeGLU(LN(x) Wi^T)   -- one kernel, the hidden state stays in registers in between
-      RowGemmParams rp;
-      memset(&rp, 0, sizeof(rp));
-      rp.eps = h->cfg.norm_eps;
-      rp.hidden = H;
-      rp.r_pad = r_pad;
-      rp.ln_w = lw.mlp_norm;
-      rp.wp = lw.wi_pk;
-      rp.n_chunks = 2 * I / ROW_CHUNK;
-      rp.o0_hi = ws.h_hi;  // fragment-packed h (h_hi + h_lo are one buffer)
-      rp.ld_out = I;
-      rp.a1_fp = ws.o_hi;
-      rp.w1p = lw.wo_ks;
-      rp.k1_steps = H / 32;
-      rp.x_io = ws.x;
-      rp.zero_a_lo = clr_ln_mlp ? 1 : 0;
-      OP_TRY(L.begin(PK_FUSED_ATTN_OUT_WI));
-      if (!opl::launch_row_geglu_fused(st, rp, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+      OP_TRY(L.begin(PK_ROW_QKV));
+      if (!opl::launch_row_qkv0(st, rp, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
       OP_TRY(L.end());
-      OP_TRY(clear_h());
+      OP_TRY(clear_qkv());
+    }  // else: q/k/v of this layer were produced by the fused kernel that closed layer li-1
+    OP_TRY(attention(is_global));
 
-      if (li + 1 < h->N) {
-        // x += h Wo^T ; q, k, v^T of the NEXT layer = RoPE / transpose of LN(x) Wqkv^T
-        RowGemmParams rq = qkv_params(li + 1);
-        rq.a1_fp = ws.h_hi;
-        rq.w1p = lw.wo2_pk;
-        rq.k1_steps = I / 32;
-        rq.x_io = ws.x;
-        OP_TRY(L.begin(PK_FUSED_MLP_OUT_QKV));
-        if (!opl::launch_row_qkv_fused(st, rq, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+    if (layer_fused) {
+      // x += o Wo^T ; x += GeGLU(LN(x) Wi^T) Wo^T ; q, k, v^T of the NEXT layer -- one kernel, h stays on chip
+      const bool with_qkv = li + 1 < h->N;
+      if ((h->cfg.flags & OP_FLAG_LAYER_M32) && lw.wo_p32 && opl::has_layer32(h->pi) && I % 64 == 0) {
+        // hidden = 256, on request: the same launch on the 32x32x16 MFMA shape (opk_layer32.hip.h) -- 6 % fewer
+        // cycles, but that shape draws more power per flop and the chip clocks lower under it
+        Layer32Params lp;
+        memset(&lp, 0, sizeof(lp));
+        const LayerWeights& nx = h->layers[with_qkv ? li + 1 : li];
+        lp.o_fp = ws.o_hi;
+        lp.x_io = ws.x;
+        lp.ln_mlp = lw.mlp_norm;
+        lp.ln_next = with_qkv ? nx.attn_norm : nullptr;
+        lp.eps = h->cfg.norm_eps;
+        lp.wo_p = lw.wo_p32;
+        lp.wi_p = lw.wi_p32;
+        lp.wo2_p = lw.wo2_p32;
+        lp.wqkv_p = nx.wqkv_p32;
+        lp.n_pairs = I / 32;
+        lp.q_fp = ws.q_hi;
+        lp.k_fp = ws.k_hi;
+        lp.vt_fp = ws.vt_hi;
+        lp.r_pad = r_pad;
+        lp.row_pos = ws.row_pos;
+        const int gl = h->cfg.layer_is_global[with_qkv ? li + 1 : li] ? 1 : 0;
+        lp.rope_cos = h->rope_cos[gl];
+        lp.rope_sin = h->rope_sin[gl];
+        lp.max_pos = h->max_pos;
+        OP_TRY(L.begin(PK_FUSED_LAYER));
+        if (!opl::launch_layer32(st, lp, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM))) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
         OP_TRY(L.end());
-        OP_TRY(clear_qkv());
-      } else {
-        KStreamParams kp;
-        kp.a_fp = ws.h_hi;
-        kp.wp = lw.wo2_pk;
-        kp.n_ksteps = I / 32;
-        kp.x = ws.x;
-        OP_TRY(L.begin(PK_KSTREAM_MLP_OUT));
-        if (!opl::launch_kstream(st, kp, H / 16, h->pi, (unsigned)(r_pad / ROW_BM))) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
-        OP_TRY(L.end());
-      }
-      continue;
-    }
-
-    if (h->panel_path) {
-      // ---- panel path (hidden % 256 == 0): LayerNorm -> fragment-packed planes, k-streamed panel GEMMs ----
-      const dim3 ln_grid((unsigned)(r_pad / 16));
-      const bool pf8 = o_f8;  // kernel sets 3 / 4: activations as fp16 pieces + e4m3 pieces (x 2^12) of their lo part
-      // kernel sets 8 / 9: the attention side on the "f16" kernels (pi = PI_F16), the MLP -- LayerNorm(mlp_norm), Wi + GeGLU
-      // with h as fp16 + e4m3 pieces, MLP output projection -- on the fp16 + e4m3 kernels of sets 4 / 3
-      const bool mlp8 = f16 && h->mlp_f8;
-      const bool wlo8 = h->pi == opl::PI_F16_F8_W || (h->wi_f8 && h->pi == opl::PI_ALL_TERMS) || (mlp8 && h->mlp_wlo);
-      // OP_FLAG_PANEL_F8_WI: the format in the Wi GEMM alone -- its LayerNorm writes fp16 + e4m3 pieces, its epilogue
-      // writes h as the (hi, lo) bf16 pieces the MLP output projection's kernel reads
-      auto layer_norm_fp = [&](const float* w, bool with_lo, bool clear, bool f8_here = false) -> int {
-        OP_TRY(L.begin(PK_LN));
-        if (pf8 || f8_here) {
-          hipLaunchKernelGGL(ln_fp8_kernel, ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad, w ? 1 : 0, ws.ln_hi,
-                             ws.ln_lo);
-          return L.end();
-        }
-        if (with_lo)
-          hipLaunchKernelGGL((ln_fp_kernel<true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
-                             w ? 1 : 0, ws.ln_hi);
-        else if (f16)
-          hipLaunchKernelGGL((ln_fp_kernel<false, true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
-                             w ? 1 : 0, ws.ln_hi);
-        else
-          hipLaunchKernelGGL((ln_fp_kernel<false>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
-                             w ? 1 : 0, ws.ln_hi);
-        OP_TRY(L.end());
-        if (clear) OP_TRY(clear_lo(L, ws.ln_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
         return OP_OK;
-      };
-      auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles, bool f8_here = false, bool f8_full = false) -> int {
-        OP_TRY(L.begin(kind));
-        PanelParams q = pp;
-        q.n_tiles = n_tiles;
-        q.row_group = 8;  // sweep 1 / 2 / 4 / 8 / 16 on base and en-gte: flat within 2 %, 8 best on the Wi GEMM (-5 %)
-        const unsigned per_xcd = ((unsigned)(r_pad / ROW_BM) + 7) / 8;  // row blocks each XCD owns
-        const unsigned groups = (per_xcd + q.row_group - 1) / q.row_group;
-        const dim3 grid(8u * groups * (unsigned)q.row_group * (unsigned)n_tiles);  // XCD-aware block map: see panel_gemm_kernel
-        const bool ok = f8_here ? opl::launch_panel_f8(st, q, 103, wlo8, grid)
-                        : f8_full ? opl::launch_panel_f8(st, q, epi, wlo8, grid)
-                        : pf8   ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, attn16, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
-                                : (epi == 102 ? opl::launch_panel_qkv(st, q, h->pi, grid) : opl::launch_panel(st, q, epi, h->pi, grid));
-        if (!ok) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
-        return L.end();
-      };
-      // layer 0: attn_norm is Identity -> plain split
-      OP_TRY(layer_norm_fp(li != 0 ? lw.attn_norm : nullptr, (V.wqkv & 1) != 0, clr_ln_attn));
-      PanelParams pp;
-      memset(&pp, 0, sizeof(pp));
-      pp.r_pad = r_pad;
-      pp.hidden = H;
-      pp.range_flag = range_flagged ? ws.range_flag : nullptr;
-      pp.row_pos = ws.row_pos;
-      pp.rope_cos = h->rope_cos[is_global ? 1 : 0];
-      pp.rope_sin = h->rope_sin[is_global ? 1 : 0];
-      pp.max_pos = h->max_pos;
-      pp.a_fp = ws.ln_hi;
-      pp.a_lo8 = ws.ln_lo;
-      pp.n_ksteps = H / 32;
-      pp.wp = pf8 ? lw.wqkv_p16 : (f16 ? lw.wqkv_h16 : lw.wqkv_pk);
-      pp.wp8 = lw.wqkv_p8;
-      pp.w8_lo_off = (size_t)3 * H * H / 2;  // u16 elements: the tensor's e4m3(w) slabs, then those of lo(w)
-      pp.o0 = ws.q_hi;
-      pp.o1 = ws.k_hi;
-      if (pf8 || !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION)) {  // q, k, v^T in one launch
-        pp.o2 = ws.vt_hi;
-        pp.n_qk_tiles = 2 * H / 256;
-        OP_TRY(panel(PK_GEMM_QKV_ROPE, 102, pp, 3 * H / 256));
-      } else {
-        OP_TRY(panel(PK_GEMM_QK_ROPE, PE_QK, pp, 2 * H / 256));
-        pp.wp = (f16 ? lw.wqkv_h16 : lw.wqkv_pk) + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
-        pp.o0 = ws.vt_hi;
-        OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
       }
-      if (!attn16) {  // (sets 10 / 11 neither write nor read a lo plane of q / k / v^T)
-        OP_TRY(clear_qkv());
+      RowGemmParams rl = qkv_params(with_qkv ? li + 1 : li);
+      rl.a1_fp = ws.o_hi;
+      rl.w1p = f16 ? lw.wo_h16 : lw.wo_ks;
+      rl.k1_steps = H / 32;
+      rl.x_io = ws.x;
+      rl.ln_w_mlp = lw.mlp_norm;
+      rl.wi_pk = f16 ? lw.wi_h16 : lw.wi_pk;
+      rl.wo2_ks = f16 ? lw.wo2_h16 : lw.wo2_pk;
+      rl.n_pairs = I / 32;
+      if (o_f8) {  // the "f16 + fp8" packs of the same weights
+        rl.a1_lo8 = ws.o_lo;
+        rl.w1p = lw.wo_f16;
+        rl.w1p8 = lw.wo_f8;
+        rl.wi_pk = lw.wi_f8;
+        rl.wo2_ks = lw.wo2_f16;
+        rl.wp = h->layers[with_qkv ? li + 1 : li].wqkv_f8;
       }
-      OP_TRY(attention(is_global));
-      pp.a_fp = ws.o_hi;
-      pp.a_lo8 = ws.o_lo;
-      pp.wp = pf8 ? lw.wo_p16 : (f16 ? lw.wo_h16 : lw.wo_ks);
-      pp.wp8 = lw.wo_p8;
-      pp.w8_lo_off = (size_t)H * H / 2;
-      pp.x = ws.x;
-      pp.ld_out = H;
-      OP_TRY(panel(PK_GEMM_ATTN_OUT, 100, pp, H / 256));
-      const bool wi8 = h->wi_f8 && !pf8;
-      OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp && !wi8, wi8 || mlp8));
-      pp.a_fp = ws.ln_hi;
-      pp.a_lo8 = ws.ln_lo;
-      pp.wp = (pf8 || wi8 || mlp8) ? lw.wi_p16 : (f16 ? lw.wi_h16 : lw.wi_pk);
-      pp.wp8 = lw.wi_p8;
-      pp.w8_lo_off = (size_t)2 * I * H / 2;
-      pp.o0 = ws.h_hi;
-      pp.o0_lo8 = ws.h_lo;
-      pp.ld_out = I;
-      OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128, wi8, mlp8));
-      OP_TRY(clear_h());
-      pp.a_fp = ws.h_hi;
-      pp.a_lo8 = ws.h_lo;
-      pp.n_ksteps = I / 32;
-      pp.wp = (pf8 || mlp8) ? lw.wo2_p16 : (f16 ? lw.wo2_h16 : lw.wo2_pk);
-      pp.wp8 = lw.wo2_p8;
-      pp.w8_lo_off = (size_t)H * I / 2;
-      pp.ld_out = H;
-      OP_TRY(panel(PK_GEMM_MLP_OUT, 101, pp, H / 256, false, mlp8));
-      continue;
+      if (!with_qkv && head_in_last_layer) {
+        // the last layer's rows go straight through final_norm + the pruning head (no write-back of x, no
+        // final_ln_prune launch); mean pooling and hidden-state capture need all normalised rows and keep the kernel
+        rl.fin_ln = h->final_norm;
+        rl.fin_pw = h->prune_w;
+        rl.fin_pb = h->prune_b;
+        rl.row_tok = ws.row_tok;
+        rl.row_seq = ws.row_seq;
+        rl.fin_prune = prune_out;
+        rl.fin_keep = keep_prob;
+        rl.fin_cls = ws.cls;
+        rl.fin_pre_norm = h->cfg.prune_pre_final_norm ? 1 : 0;
+        head_done = true;
+      }
+      OP_TRY(L.begin(PK_FUSED_LAYER));
+      if (!opl::launch_row_layer_fused(st, rl, H / 32, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM),
+                                       (h->cfg.flags & OP_FLAG_LAYER_8X16) != 0 || (opl::kPolicies[h->pi].wi & 1) == 0))
+        return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+      OP_TRY(L.end());
+      return OP_OK;
     }
 
+    // x += o Wo^T ; h = GeGLU(LN(x) Wi^T)   -- one kernel, the hidden state stays in registers in between
+    RowGemmParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.eps = h->cfg.norm_eps;
+    rp.hidden = H;
+    rp.r_pad = r_pad;
+    rp.ln_w = lw.mlp_norm;
+    rp.wp = lw.wi_pk;
+    rp.n_chunks = 2 * I / ROW_CHUNK;
+    rp.o0_hi = ws.h_hi;  // fragment-packed h (h_hi + h_lo are one buffer)
+    rp.ld_out = I;
+    rp.a1_fp = ws.o_hi;
+    rp.w1p = lw.wo_ks;
+    rp.k1_steps = H / 32;
+    rp.x_io = ws.x;
+    rp.zero_a_lo = clr_ln_mlp ? 1 : 0;
+    OP_TRY(L.begin(PK_FUSED_ATTN_OUT_WI));
+    if (!opl::launch_row_geglu_fused(st, rp, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+    OP_TRY(L.end());
+    OP_TRY(clear_h());
+
+    if (li + 1 < h->N) {
+      // x += h Wo^T ; q, k, v^T of the NEXT layer = RoPE / transpose of LN(x) Wqkv^T
+      RowGemmParams rq = qkv_params(li + 1);
+      rq.a1_fp = ws.h_hi;
+      rq.w1p = lw.wo2_pk;
+      rq.k1_steps = I / 32;
+      rq.x_io = ws.x;
+      OP_TRY(L.begin(PK_FUSED_MLP_OUT_QKV));
+      if (!opl::launch_row_qkv_fused(st, rq, H / 32, small_blocks, h->pi, row_grid)) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+      OP_TRY(L.end());
+      OP_TRY(clear_qkv());
+    } else {
+      KStreamParams kp;
+      kp.a_fp = ws.h_hi;
+      kp.wp = lw.wo2_pk;
+      kp.n_ksteps = I / 32;
+      kp.x = ws.x;
+      OP_TRY(L.begin(PK_KSTREAM_MLP_OUT));
+      if (!opl::launch_kstream(st, kp, H / 16, h->pi, (unsigned)(r_pad / ROW_BM))) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+      OP_TRY(L.end());
+    }
+    return OP_OK;
+  }
+
+  // one layer on the panel path: LayerNorm -> q / k / v -> attention -> output projection -> LayerNorm -> Wi + GeGLU -> MLP output
+  int panel_layer(int li) {
+    const LayerWeights& lw = h->layers[li];
+    const bool is_global = h->cfg.layer_is_global[li] != 0;
+    // ---- panel path (hidden % 256 == 0): LayerNorm -> fragment-packed planes, k-streamed panel GEMMs ----
+    const dim3 ln_grid((unsigned)(r_pad / 16));
+    const bool pf8 = o_f8;  // kernel sets 3 / 4: activations as fp16 pieces + e4m3 pieces (x 2^12) of their lo part
+    // kernel sets 8 / 9: the attention side on the "f16" kernels (pi = PI_F16), the MLP -- LayerNorm(mlp_norm), Wi + GeGLU
+    // with h as fp16 + e4m3 pieces, MLP output projection -- on the fp16 + e4m3 kernels of sets 4 / 3
+    const bool mlp8 = f16 && h->mlp_f8;
+    const bool wlo8 = h->pi == opl::PI_F16_F8_W || (h->wi_f8 && h->pi == opl::PI_ALL_TERMS) || (mlp8 && h->mlp_wlo);
+    // OP_FLAG_PANEL_F8_WI: the format in the Wi GEMM alone -- its LayerNorm writes fp16 + e4m3 pieces, its epilogue
+    // writes h as the (hi, lo) bf16 pieces the MLP output projection's kernel reads
+    auto layer_norm_fp = [&](const float* w, bool with_lo, bool clear, bool f8_here = false) -> int {
+      OP_TRY(L.begin(PK_LN));
+      if (pf8 || f8_here) {
+        hipLaunchKernelGGL(ln_fp8_kernel, ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad, w ? 1 : 0, ws.ln_hi,
+                           ws.ln_lo);
+        return L.end();
+      }
+      if (with_lo)
+        hipLaunchKernelGGL((ln_fp_kernel<true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                           w ? 1 : 0, ws.ln_hi);
+      else if (f16)
+        hipLaunchKernelGGL((ln_fp_kernel<false, true>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                           w ? 1 : 0, ws.ln_hi);
+      else
+        hipLaunchKernelGGL((ln_fp_kernel<false>), ln_grid, dim3(256), 0, st, ws.x, w, h->cfg.norm_eps, H, r_pad,
+                           w ? 1 : 0, ws.ln_hi);
+      OP_TRY(L.end());
+      if (clear) OP_TRY(clear_lo(L, ws.ln_hi, 512, (size_t)(r_pad / 16) * (H / 32)));
+      return OP_OK;
+    };
+    auto panel = [&](int kind, int epi, const PanelParams& pp, int n_tiles, bool f8_here = false, bool f8_full = false) -> int {
+      OP_TRY(L.begin(kind));
+      PanelParams q = pp;
+      q.n_tiles = n_tiles;
+      q.row_group = 8;  // sweep 1 / 2 / 4 / 8 / 16 on base and en-gte: flat within 2 %, 8 best on the Wi GEMM (-5 %)
+      const unsigned per_xcd = ((unsigned)(r_pad / ROW_BM) + 7) / 8;  // row blocks each XCD owns
+      const unsigned groups = (per_xcd + q.row_group - 1) / q.row_group;
+      const dim3 grid(8u * groups * (unsigned)q.row_group * (unsigned)n_tiles);  // XCD-aware block map: see panel_gemm_kernel
+      const bool ok = f8_here ? opl::launch_panel_f8(st, q, 103, wlo8, grid)
+                      : f8_full ? opl::launch_panel_f8(st, q, epi, wlo8, grid)
+                      : pf8   ? (epi == 102 ? opl::launch_panel_f8_qkv(st, q, wlo8, attn16, grid) : opl::launch_panel_f8(st, q, epi, wlo8, grid))
+                              : (epi == 102 ? opl::launch_panel_qkv(st, q, h->pi, grid) : opl::launch_panel(st, q, epi, h->pi, grid));
+      if (!ok) return fail(h, OP_ERR_UNSUPPORTED, "internal: no panel kernel");
+      return L.end();
+    };
+    // layer 0: attn_norm is Identity -> plain split
+    OP_TRY(layer_norm_fp(li != 0 ? lw.attn_norm : nullptr, (V.wqkv & 1) != 0, clr_ln_attn));
+    PanelParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.r_pad = r_pad;
+    pp.hidden = H;
+    pp.range_flag = range_flagged ? ws.range_flag : nullptr;
+    pp.row_pos = ws.row_pos;
+    pp.rope_cos = h->rope_cos[is_global ? 1 : 0];
+    pp.rope_sin = h->rope_sin[is_global ? 1 : 0];
+    pp.max_pos = h->max_pos;
+    pp.a_fp = ws.ln_hi;
+    pp.a_lo8 = ws.ln_lo;
+    pp.n_ksteps = H / 32;
+    pp.wp = pf8 ? lw.wqkv_p16 : (f16 ? lw.wqkv_h16 : lw.wqkv_pk);
+    pp.wp8 = lw.wqkv_p8;
+    pp.w8_lo_off = (size_t)3 * H * H / 2;  // u16 elements: the tensor's e4m3(w) slabs, then those of lo(w)
+    pp.o0 = ws.q_hi;
+    pp.o1 = ws.k_hi;
+    if (pf8 || !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION)) {  // q, k, v^T in one launch
+      pp.o2 = ws.vt_hi;
+      pp.n_qk_tiles = 2 * H / 256;
+      OP_TRY(panel(PK_GEMM_QKV_ROPE, 102, pp, 3 * H / 256));
+    } else {
+      OP_TRY(panel(PK_GEMM_QK_ROPE, PE_QK, pp, 2 * H / 256));
+      pp.wp = (f16 ? lw.wqkv_h16 : lw.wqkv_pk) + (size_t)(2 * H / 256) * (H / 32) * 2 * 8192;
+      pp.o0 = ws.vt_hi;
+      OP_TRY(panel(PK_GEMM_V_T, PE_V, pp, H / 256));
+    }
+    if (!attn16) {  // (sets 10 / 11 neither write nor read a lo plane of q / k / v^T)
+      OP_TRY(clear_qkv());
+    }
+    OP_TRY(attention(is_global));
+    pp.a_fp = ws.o_hi;
+    pp.a_lo8 = ws.o_lo;
+    pp.wp = pf8 ? lw.wo_p16 : (f16 ? lw.wo_h16 : lw.wo_ks);
+    pp.wp8 = lw.wo_p8;
+    pp.w8_lo_off = (size_t)H * H / 2;
+    pp.x = ws.x;
+    pp.ld_out = H;
+    OP_TRY(panel(PK_GEMM_ATTN_OUT, 100, pp, H / 256));
+    const bool wi8 = h->wi_f8 && !pf8;
+    OP_TRY(layer_norm_fp(lw.mlp_norm, (V.wi & 1) != 0, clr_ln_mlp && !wi8, wi8 || mlp8));
+    pp.a_fp = ws.ln_hi;
+    pp.a_lo8 = ws.ln_lo;
+    pp.wp = (pf8 || wi8 || mlp8) ? lw.wi_p16 : (f16 ? lw.wi_h16 : lw.wi_pk);
+    pp.wp8 = lw.wi_p8;
+    pp.w8_lo_off = (size_t)2 * I * H / 2;
+    pp.o0 = ws.h_hi;
+    pp.o0_lo8 = ws.h_lo;
+    pp.ld_out = I;
+    OP_TRY(panel(PK_GEMM_WI_GEGLU, PE_GEGLU, pp, I / 128, wi8, mlp8));
+    OP_TRY(clear_h());
+    pp.a_fp = ws.h_hi;
+    pp.a_lo8 = ws.h_lo;
+    pp.n_ksteps = I / 32;
+    pp.wp = (pf8 || mlp8) ? lw.wo2_p16 : (f16 ? lw.wo2_h16 : lw.wo2_pk);
+    pp.wp8 = lw.wo2_p8;
+    pp.w8_lo_off = (size_t)H * I / 2;
+    pp.ld_out = H;
+    OP_TRY(panel(PK_GEMM_MLP_OUT, 101, pp, H / 256, false, mlp8));
+    return OP_OK;
+  }
+
+  // one layer on the tiled path (generic fallback)
+  int tiled_layer(int li) {
+    const LayerWeights& lw = h->layers[li];
+    const bool is_global = h->cfg.layer_is_global[li] != 0;
     // ---- tiled path (any hidden % 128 == 0): separate LayerNorm kernels, 128 x 128 x 32 tiles, row-major planes.
     // Two kernel sets (single pass / all terms); a narrower policy clears the lo planes it does not carry. ----
     auto layer_norm = [&](const float* w, int term_mask) -> int {
@@ -839,24 +880,45 @@ int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t*
     p.x = ws.x;
     p.ld_out = H;
     OP_TRY(launch_gemm<EPI_RESIDUAL>(L, PK_GEMM_MLP_OUT, p, split));
+    return OP_OK;
   }
 
-  const int mean_pool = h->cfg.pooling == OP_POOL_MEAN ? 1 : 0;
-  if (!head_done) {
-    OP_TRY(L.begin(PK_FINAL_LN_PRUNE));
-    hipLaunchKernelGGL(final_ln_prune_kernel, dim3(row_blocks), dim3(256), 0, st, ws.x, h->final_norm, h->cfg.norm_eps, H,
-                       r_pad, ws.row_tok, ws.row_seq, ws.row_pos, h->prune_w, h->prune_b, prune_out, keep_prob,
-                       h->cfg.prune_pre_final_norm ? 1 : 0, mean_pool, ws.cls,
-                       h->capture ? h->capture + (size_t)h->N * total_tokens * H : nullptr,
+  // final_norm + pruning head (unless the last whole-layer launch did it), ranking head
+  int heads() {
+    const int mean_pool = h->cfg.pooling == OP_POOL_MEAN ? 1 : 0;
+    if (!head_done) {
+      OP_TRY(L.begin(PK_FINAL_LN_PRUNE));
+      hipLaunchKernelGGL(final_ln_prune_kernel, dim3(row_blocks), dim3(256), 0, st, ws.x, h->final_norm, h->cfg.norm_eps, H,
+                         r_pad, ws.row_tok, ws.row_seq, ws.row_pos, h->prune_w, h->prune_b, prune_out, keep_prob,
+                         h->cfg.prune_pre_final_norm ? 1 : 0, mean_pool, ws.cls,
+                         h->capture ? h->capture + (size_t)h->N * total_tokens * H : nullptr,
+                         range_flagged ? ws.range_flag : nullptr);
+      OP_TRY(L.end());
+    }
+    OP_TRY(L.begin(PK_RANK_HEAD));
+    hipLaunchKernelGGL(rank_head_kernel, dim3((unsigned)ns), dim3(256), 0, st, ws.cls, ws.x, cu_dev, s0, ws.roff, mean_pool,
+                       H, h->nl, h->dense_t, h->head_norm, h->cfg.norm_eps, h->cls_w, h->cls_b, rank_out,
                        range_flagged ? ws.range_flag : nullptr);
     OP_TRY(L.end());
+    return OP_OK;
   }
-  OP_TRY(L.begin(PK_RANK_HEAD));
-  hipLaunchKernelGGL(rank_head_kernel, dim3((unsigned)ns), dim3(256), 0, st, ws.cls, ws.x, cu_dev, s0, ws.roff, mean_pool,
-                     H, h->nl, h->dense_t, h->head_norm, h->cfg.norm_eps, h->cls_w, h->cls_b, rank_out,
-                     range_flagged ? ws.range_flag : nullptr);
-  OP_TRY(L.end());
-  return OP_OK;
+
+  int run() {
+    OP_TRY(prologue());
+    for (int li = 0; li < h->N; ++li) {
+      OP_TRY(capture(li));
+      if (h->row_path) OP_TRY(row_layer(li));
+      else if (h->panel_path) OP_TRY(panel_layer(li));
+      else OP_TRY(tiled_layer(li));
+    }
+    return heads();
+  }
+};
+
+int forward_chunk(op_handle* h, Launcher& L, const Workspace& ws, const int32_t* ids_dev, const int32_t* cu_dev, int s0,
+                  int ns, int rows, int max_len, int total_tokens, const AttnPlan& plan, float* prune_out, float* rank_out,
+                  float* keep_prob) {
+  return ChunkPass(h, L, ws, ids_dev, cu_dev, s0, ns, rows, max_len, total_tokens, plan, prune_out, rank_out, keep_prob).run();
 }
 
 }  // namespace
