@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : 
 #include "opk_rowgemm_mlp_ops.inc"
 #include "opk_rowgemm_mlp_loop.inc"
       if constexpr (EPI == RE_NONE) {
-        if (FIN_HEAD && p.fin_ln != nullptr) final_head();
+        if (FIN_HEAD && p.fin_ln != nullptr) rowgemm_final_head<KS, MF>(p, sLn, m0, l15, g, acc1);
         else residual_ln(no_, yes_, no_, nullptr);  // acc1 = x + o Wo^T + h Wo^T: the layer's output
         OPK_STAMP(4);
         OPK_DUMP();

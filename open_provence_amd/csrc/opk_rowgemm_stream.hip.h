@@ -176,4 +176,89 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
   });
 }
 
+// final_norm + pruning head on the rows in the accumulators (see RowGemmParams::fin_ln).  Same arithmetic per row
+// as rowgemm_kernel's layer_ln; the head's two dot products ride on the normalised values (or, fin_pre_norm, on the raw row), the
+// four lanes of a row are summed, the lane of column group 0 writes the token's logits and keep-probability.
+// sLn: [mlp_norm | final_norm | pruning head row 0 | row 1] weights in LDS; acc1: the block's rows (x after the MLP).
+template <int KS, int MF>
+__device__ __forceinline__ void rowgemm_final_head(const RowGemmParams& p, const float* sLn, int m0, int l15, int g,
+                                                   const f32x4 (&acc1)[2 * KS][MF]) {
+  constexpr int K = KS * 32, NF1 = 2 * KS;
+  const float* lw_s = &sLn[K + g * 8];
+  const float* p0_s = &sLn[2 * K + g * 8];
+  const float* p1_s = &sLn[3 * K + g * 8];
+  const float b0 = p.fin_pb[0], b1 = p.fin_pb[1];
+  const bool pre = p.fin_pre_norm != 0;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int row = m0 + mf * 16 + l15;
+    const int tok = p.row_tok[row];
+    const bool is_cls = tok >= 0 && p.row_pos[row] == 0;
+    f32x2 v[2 * NF1];
+#pragma unroll
+    for (int nf = 0; nf < NF1; ++nf) {
+      const f32x4 a = acc1[nf][mf];
+      v[2 * nf] = f32x2{a[0], a[1]};
+      v[2 * nf + 1] = f32x2{a[2], a[3]};
+    }
+    f32x2 s4[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int i = 4; i < 2 * NF1; ++i) s4[i & 3] = pk_add(s4[i & 3], v[i]);
+    const f32x2 st = pk_add(pk_add(s4[0], s4[1]), pk_add(s4[2], s4[3]));
+    float sum = st.x + st.y;
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / (float)K);
+    const f32x2 m2 = f32x2{mean, mean};
+    f32x2 q4[4], d0[2], d1[2];
+    d0[0] = d0[1] = d1[0] = d1[1] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2 * NF1; ++i) {
+      const f32x2 c = pk_sub(v[i], m2);
+      q4[i & 3] = i < 4 ? pk_mul(c, c) : pk_fma(c, c, q4[i & 3]);
+    }
+    const f32x2 qt = pk_add(pk_add(q4[0], q4[1]), pk_add(q4[2], q4[3]));
+    float q = qt.x + qt.y;
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / (float)K) + p.eps);
+    const f32x2 r2 = f32x2{rstd, rstd};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 w0 = *reinterpret_cast<const float4*>(lw_s + ks * 32), w1 = *reinterpret_cast<const float4*>(lw_s + ks * 32 + 4);
+      const float4 a0 = *reinterpret_cast<const float4*>(p0_s + ks * 32), a1 = *reinterpret_cast<const float4*>(p0_s + ks * 32 + 4);
+      const float4 c0 = *reinterpret_cast<const float4*>(p1_s + ks * 32), c1 = *reinterpret_cast<const float4*>(p1_s + ks * 32 + 4);
+      const f32x2 lw[4] = {f32x2{w0.x, w0.y}, f32x2{w0.z, w0.w}, f32x2{w1.x, w1.y}, f32x2{w1.z, w1.w}};
+      const f32x2 pa[4] = {f32x2{a0.x, a0.y}, f32x2{a0.z, a0.w}, f32x2{a1.x, a1.y}, f32x2{a1.z, a1.w}};
+      const f32x2 pc[4] = {f32x2{c0.x, c0.y}, f32x2{c0.z, c0.w}, f32x2{c1.x, c1.y}, f32x2{c1.z, c1.w}};
+      f32x2 y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = pk_mul(pk_mul(pk_sub(v[4 * ks + j], m2), r2), lw[j]);
+        const f32x2 src = pre ? v[4 * ks + j] : y[j];
+        d0[j & 1] = pk_fma(src, pa[j], d0[j & 1]);
+        d1[j & 1] = pk_fma(src, pc[j], d1[j & 1]);
+      }
+      if (is_cls) {  // one row in a sequence: the ranking head's input
+        float* dst = p.fin_cls + (size_t)p.row_seq[row] * K + ks * 32 + g * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+      }
+    }
+    const f32x2 e0 = pk_add(d0[0], d0[1]), e1 = pk_add(d1[0], d1[1]);
+    float l0 = e0.x + e0.y, l1 = e1.x + e1.y;
+    l0 += __shfl_xor(l0, 16, 64);
+    l0 += __shfl_xor(l0, 32, 64);
+    l1 += __shfl_xor(l1, 16, 64);
+    l1 += __shfl_xor(l1, 32, 64);
+    if (g == 0 && tok >= 0) {
+      l0 += b0;
+      l1 += b1;
+      p.fin_prune[(size_t)tok * 2 + 0] = l0;
+      p.fin_prune[(size_t)tok * 2 + 1] = l1;
+      if (p.fin_keep) p.fin_keep[tok] = 1.0f / (1.0f + expf(l0 - l1));
+    }
+  }
+}
+
 }  // namespace opk
