@@ -15,6 +15,7 @@
 
 #include "opk_rowgemm_pack.hip.h"
 #include "opk_rowgemm_stream.hip.h"
+#include "opk_rowgemm_ln.hip.h"
 
 namespace opk {
 
