@@ -201,4 +201,106 @@ __device__ __forceinline__ void rowgemm_store_rows(const RowGemmParams& p, int m
   }
 }
 
+// ---- prologue of rowgemm_kernel: this wave's rows of the hidden state as MFMA operand fragments (a_hi / a_lo) ----------------
+// RP_SPLIT (layer 0; attn_norm is Identity): the rows are built from the embedding table + embeddings.norm (p.emb_table) or read
+// from x_in and split.  Every prologue but RP_MLP: the lo fragments are masked for a narrower policy (p.zero_a_lo).
+template <int KS, int MF, int PRO, bool A_LO, bool H16>
+__device__ __forceinline__ void rowgemm_prologue_rows(const RowGemmParams& p, int m0, int l15, int g, bf16x8 (&a_hi)[MF][KS],
+                                                      bf16x8 (&a_lo)[MF][KS]) {
+  constexpr int K = KS * 32;
+  // ---- prologue (layer 0, RP_SPLIT): this wave's rows of x as fragments, no LayerNorm (attn_norm is Identity) ----
+  if (PRO == RP_SPLIT && p.emb_table != nullptr) {
+    // x0 = LayerNorm(E[id]) (alignment rows: zeros), packed arithmetic as in layer_ln; explicit instructions, so that
+    // every instantiation (kernel set, rows per wave) produces the same bits for a row
+    const float* lnw_g = p.ln_w + g * 8;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int row = m0 + mf * 16 + l15;
+      const int tok = p.row_tok[row];
+      int id = p.emb_ids[tok < 0 ? 0 : tok];
+      id = id < 0 ? 0 : (id >= p.emb_vocab ? p.emb_vocab - 1 : id);
+      const float* src = p.emb_table + (size_t)id * K + g * 8;
+      const float live = tok < 0 ? 0.f : 1.f;
+      const f32x2 live2 = f32x2{live, live};
+      f32x2 v[4 * KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 f0 = *reinterpret_cast<const float4*>(src + ks * 32);
+        const float4 f1 = *reinterpret_cast<const float4*>(src + ks * 32 + 4);
+        v[4 * ks + 0] = pk_mul(f32x2{f0.x, f0.y}, live2);
+        v[4 * ks + 1] = pk_mul(f32x2{f0.z, f0.w}, live2);
+        v[4 * ks + 2] = pk_mul(f32x2{f1.x, f1.y}, live2);
+        v[4 * ks + 3] = pk_mul(f32x2{f1.z, f1.w}, live2);
+      }
+      f32x2 s4[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int i = 4; i < 4 * KS; ++i) s4[i & 3] = pk_add(s4[i & 3], v[i]);
+      const f32x2 st = pk_add(pk_add(s4[0], s4[1]), pk_add(s4[2], s4[3]));
+      float sum = st.x + st.y;
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.0f / (float)K);
+      const f32x2 m2 = f32x2{mean, mean};
+      f32x2 q4[4];
+#pragma unroll
+      for (int i = 0; i < 4 * KS; ++i) {
+        v[i] = pk_sub(v[i], m2);
+        q4[i & 3] = i < 4 ? pk_mul(v[i], v[i]) : pk_fma(v[i], v[i], q4[i & 3]);
+      }
+      const f32x2 qt = pk_add(pk_add(q4[0], q4[1]), pk_add(q4[2], q4[3]));
+      float q = qt.x + qt.y;
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / (float)K) + p.eps);
+      const f32x2 r2 = f32x2{rstd, rstd};
+      float* xrow = p.x_io + (size_t)row * K + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 w0 = *reinterpret_cast<const float4*>(lnw_g + ks * 32);
+        const float4 w1 = *reinterpret_cast<const float4*>(lnw_g + ks * 32 + 4);
+        const f32x2 lw[4] = {f32x2{w0.x, w0.y}, f32x2{w0.z, w0.w}, f32x2{w1.x, w1.y}, f32x2{w1.z, w1.w}};
+        f32x2 y[4];
+        uint32_t hb[4], lb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          y[j] = pk_mul(pk_mul(v[4 * ks + j], r2), lw[j]);
+          split2x_pk<A_LO, H16>(y[j], hb[j], lb[j]);
+        }
+        store_stream16(xrow + ks * 32, make_float4(y[0].x, y[0].y, y[1].x, y[1].y));
+        store_stream16(xrow + ks * 32 + 4, make_float4(y[2].x, y[2].y, y[3].x, y[3].y));
+        a_hi[mf][ks] = as_frag(make_uint4(hb[0], hb[1], hb[2], hb[3]));
+        a_lo[mf][ks] = as_frag(make_uint4(lb[0], lb[1], lb[2], lb[3]));
+      }
+    }
+  } else if (PRO == RP_SPLIT) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const size_t row = (size_t)(m0 + mf * 16 + l15);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 f0 = load_stream_f4(p.x_in + row * K + ks * 32 + g * 8);
+        const float4 f1 = load_stream_f4(p.x_in + row * K + ks * 32 + g * 8 + 4);
+        const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        pack8x<A_LO, H16>(v, a_hi[mf][ks], a_lo[mf][ks]);
+      }
+    }
+  }
+  // Numerics of a narrower policy on this (wider) instantiation: the lo fragments of the in-register operand are
+  // ANDed with a launch-constant mask (all ones, or zero: their product term then adds exact zeros, bit-identical to
+  // the kernel that omits the term).  Straight-line on purpose: a branch here makes the compiler keep two copies of
+  // the 64 fragment registers and spill.
+  if (A_LO && PRO != RP_MLP) {
+    const unsigned keep = p.zero_a_lo ? 0u : 0xffffffffu;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        FragU f;
+        f.v = a_lo[mf][ks];
+        f.u = make_uint4(f.u.x & keep, f.u.y & keep, f.u.z & keep, f.u.w & keep);
+        a_lo[mf][ks] = f.v;
+      }
+  }
+}
+
 }  // namespace opk
