@@ -120,6 +120,9 @@ struct RowGemmBlock {
   const float* rope_s_row[MF];
   f32x4 rope_c[MF], rope_s[MF];
   f32x4 rope_cc[MF][2], rope_ss[MF][2];
+  static constexpr int NF1 = 2 * KS;  // feature fragments of a row block's H outputs (phase 1, MLP)
+  f32x4 acc1[NF1][MF];                 // PHASE1: the block's rows [feature fragment][row fragment], x + o Wo^T (+ h Wo^T)
+  float4 xq0[(PRO == RP_MLP) ? NF1 : 1];  // RP_MLP: row fragment 0 of x, requested at the top of the kernel
   uint32_t lds_stage[2];  // LDS byte address of this lane's 16 bytes in piece 0 of each stage (the hand-placed fragment reads add immediates)
 #ifdef OPK_TIMING
   unsigned long long opk_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, opk_wait = 0, opk_wait2 = 0, opk_wait1 = 0, opk_x[4] = {0, 0, 0, 0}, opk_rt0 = 0;
@@ -231,6 +234,30 @@ struct RowGemmBlock {
 #define OPK_DUMP()
 #endif
 
+  // ---- the phases (defined in opk_rowgemm_phase1 / _mlp / _qkv_pairs / _chunks .hip.h) and the transitions between them ----
+  __device__ __forceinline__ void phase1();          // acc1 = A1 W1^T, K1 streamed (attention output projection)
+  __device__ __forceinline__ void mlp_phase();       // RP_MLP: acc1 += GeGLU(LN(acc1 + x) Wi^T) Wo^T, h on chip
+  __device__ __forceinline__ void qkv_pairs_loop();  // fp16 + e4m3 sets: q / k / v^T, one fragment stream per chunk pair
+  __device__ __forceinline__ void chunk_loop();      // the weight-chunk loop with its deferred epilogues
+  // residual add, (store the new hidden state,) LayerNorm, split -> fragments (opk_rowgemm_ln.hip.h)
+  // LOAD: acc1 += x rows from memory; STORE: write the rows back; then LayerNorm with `lnw` into a_hi / a_lo.
+  template <class LoadTag, class StoreTag, class LoTag>
+  __device__ __forceinline__ void residual_ln(LoadTag, StoreTag, LoTag, const float* __restrict__ lnw) {
+    rowgemm_residual_ln<KS, MF, PRO, LoadTag::value, StoreTag::value, LoTag::value>(p, m0, l15, g, lnw, acc1, xq0, a_hi, a_lo);
+  }
+  // the same transition in the whole-layer kernel: weights from LDS (sLn), the write-back left to store_rows()
+  template <class LoadTag, class LoTag>
+  __device__ __forceinline__ void layer_ln(LoadTag, LoTag, int which) {
+    const uint32_t sln_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)&sLn[0]);
+#ifdef OPK_TIMING
+    unsigned long long* const stamps = opk_x;
+#else
+    unsigned long long* const stamps = nullptr;
+#endif
+    rowgemm_layer_ln<KS, MF, F8, H16, LoadTag::value, LoTag::value>(p, m0, l15, g, sln_addr, which, acc1, xq0, a_hi, a_lo, a_lo8, a_h8, stamps);
+  }
+  __device__ __forceinline__ void store_rows() { rowgemm_store_rows<KS, MF>(p, m0, l15, g, acc1); }
+
   // the kernel body
   __device__ __forceinline__ void run() {
     tid = threadIdx.x;
@@ -261,17 +288,15 @@ struct RowGemmBlock {
     lds_stage[0] = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) u16*)&sW[0][0]) + (uint32_t)lane * 16u;
     lds_stage[1] = lds_stage[0] + (uint32_t)(STAGE_ALLOC * 2);
     if (PHASE1) {
-#include "opk_rowgemm_phase1.inc"
+      phase1();
       OPK_STAMP(1);
-#include "opk_rowgemm_ln.inc"
       const std::true_type yes_{};
       const std::false_type no_{};
       if constexpr (PRO == RP_KSTREAM) {
         stage_chunk(0, 0);  // first weight chunk of phase 2 flies while the LayerNorm below runs
         residual_ln(yes_, yes_, std::integral_constant<bool, A_LO>{}, p.ln_w);
       } else {
-#include "opk_rowgemm_mlp_ops.inc"
-#include "opk_rowgemm_mlp_loop.inc"
+        mlp_phase();
         if constexpr (EPI == RE_NONE) {
           if (FIN_HEAD && p.fin_ln != nullptr) rowgemm_final_head<KS, MF>(p, sLn, m0, l15, g, acc1);
           else residual_ln(no_, yes_, no_, nullptr);  // acc1 = x + o Wo^T + h Wo^T: the layer's output
@@ -311,12 +336,25 @@ struct RowGemmBlock {
     if constexpr (LN_V2) __builtin_amdgcn_s_barrier();  // (this wave's share of chunk 0 was waited for above)
     else __syncthreads();  // chunk 0 has landed (the barrier's release waits for this wave's DMA: vmcnt(0))
 
-#include "opk_rowgemm_qkv_pairs.inc"
-#include "opk_rowgemm_chunks.inc"
+    if constexpr (QKV_PAIRS) qkv_pairs_loop();  // (fp16 + e4m3 sets: one fragment stream per chunk pair)
+    else chunk_loop();
   }
+};
+
+}  // namespace opk
+
+#define OPK_RG_TPL template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF, int TW, int TM, int F8, bool H16>
+#define OPK_RG_BLOCK RowGemmBlock<KS, EPI, PRO, T1, T2, OLO, WAVES, MF, TW, TM, F8, H16>
+#include "opk_rowgemm_phase1.hip.h"
+#include "opk_rowgemm_mlp.hip.h"
+#include "opk_rowgemm_qkv_pairs.hip.h"
+#include "opk_rowgemm_chunks.hip.h"
+#undef OPK_RG_TPL
+#undef OPK_RG_BLOCK
 #undef OPK_STAMP
 #undef OPK_DUMP
-};
+
+namespace opk {
 
 template <int KS, int EPI, int PRO, int T1, int T2, int OLO, int WAVES, int MF = 2, int TW = 0, int TM = 0, int F8 = 0, bool H16 = false>
 __global__ __launch_bounds__(WAVES * 64, PRO == RP_MLP ? (WAVES == 8 ? 2 : 1) : ((MF == 1 && WAVES == 8) ? 4 : 2)) void rowgemm_kernel(RowGemmParams p) {

@@ -1,6 +1,10 @@
-// opk_rowgemm_chunks.inc -- the weight-chunk loop with its deferred epilogues (q / k / v^T + RoPE, GeGLU); chunk pairs of set "f16"
-// A section of the BODY of opk::rowgemm_kernel (opk_rowgemm.hip.h includes it in place, inside the function): it reads
-// and writes the kernel's locals directly.  Not a header; nothing else includes it.
+// opk_rowgemm_chunks.hip.h -- RowGemmBlock::chunk_loop(): the weight-chunk loop with its deferred epilogues (q / k / v^T + RoPE,
+// GeGLU); chunk pairs per barrier for kernel set "f16"
+#pragma once
+
+namespace opk {
+
+OPK_RG_TPL __device__ __forceinline__ void OPK_RG_BLOCK::chunk_loop() {
   // ---- stream the weight chunks ---------------------------------------------------------------
   uint2 hold_hi[MF], hold_lo[MF];  // RE_GEGLU: first half of a chunk pair
   uint2 qk_hold[MF][4];            // RE_QKV: first half-head of a q/k chunk pair: [mf][d<32 hi, lo, d>=32 hi, lo]
@@ -374,3 +378,6 @@
   }
   OPK_STAMP(5);
   OPK_DUMP();
+}
+
+}  // namespace opk

@@ -1,6 +1,10 @@
-// opk_rowgemm_qkv_pairs.inc -- fp16 + e4m3 kernel sets: the q / k / v^T projection as one fragment stream per chunk pair
-// A section of the BODY of opk::rowgemm_kernel (opk_rowgemm.hip.h includes it in place, inside the function): it reads
-// and writes the kernel's locals directly.  Not a header; nothing else includes it.
+// opk_rowgemm_qkv_pairs.hip.h -- RowGemmBlock::qkv_pairs_loop(): fp16 + e4m3 kernel sets, the q / k / v^T projection as one
+// fragment stream per chunk pair
+#pragma once
+
+namespace opk {
+
+OPK_RG_TPL __device__ __forceinline__ void OPK_RG_BLOCK::qkv_pairs_loop() {
   // ---- F8 kernel sets: the q / k / v^T projection as ONE fragment stream per chunk PAIR ---------------------------
   // (round 4) One chunk per barrier left this loop at 2.3 x its MFMA pipe time (55.7 k cycles per tile for 24.6 k of pipe,
   // fp32-valued weights) with next to nothing of it spent waiting for the DMA or the barrier: the wave is alone on its
@@ -218,3 +222,6 @@
     return;
   }
 
+}
+
+}  // namespace opk
