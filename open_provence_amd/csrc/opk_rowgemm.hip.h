@@ -234,6 +234,8 @@ struct RowGemmBlock {
 #define OPK_DUMP()
 #endif
 
+#include "opk_rowgemm_mlp_members.inc"
+
   // ---- the phases (defined in opk_rowgemm_phase1 / _mlp / _qkv_pairs / _chunks .hip.h) and the transitions between them ----
   __device__ __forceinline__ void phase1();          // acc1 = A1 W1^T, K1 streamed (attention output projection)
   __device__ __forceinline__ void mlp_phase();       // RP_MLP: acc1 += GeGLU(LN(acc1 + x) Wi^T) Wo^T, h on chip
