@@ -1,16 +1,17 @@
 // opk_rowgemm.hip.h -- row-stationary GEMMs (hidden <= 256) and the k-streamed output projection
-// The kernel: rowgemm_kernel below.  Its body is cut by phase into include files (the phases share ~30 register-resident
-// locals and every instantiation is pinned to its measured register allocation: the text is included in place, one
-// function for the compiler, seven files for the reader):
-//   opk_rowgemm_phase1.inc      attention output projection, K streamed (RP_KSTREAM / RP_MLP): A1 -> acc1
-//   opk_rowgemm_ln.inc          forwards to the transitions in opk_rowgemm_ln.hip.h (functions: residual + LayerNorm, row
-//                               write-back, layer-0 rows) and opk_rowgemm_stream.hip.h (final_norm + pruning head)
-//   opk_rowgemm_mlp_ops.inc     whole-layer kernel: stage DMA, GeGLU micro-operations, chunk / slab MFMA steps
-//   opk_rowgemm_mlp_loop.inc    whole-layer kernel: the macro-iterations of the MLP (and its tail)
-//   opk_rowgemm_qkv_pairs.inc   fp16 + e4m3 kernel sets: q / k / v^T as one fragment stream per chunk pair
-//   opk_rowgemm_chunks.inc      the chunk loop (q / k / v^T with RoPE, GeGLU) and its deferred epilogues
-// Parameters, pack kernels: opk_rowgemm_pack.hip.h; LDS layouts and MFMA streams: opk_rowgemm_stream.hip.h; the
-// k-streamed GEMM: opk_kstream.hip.h.
+// rowgemm_kernel = RowGemmBlock<...>::run() below: the instantiation's constants, the register state its phases hand to each
+// other and the staging helpers are members of the block; the phases are member functions defined in their own headers:
+//   opk_rowgemm_phase1.hip.h     phase1()          attention output projection, K streamed (RP_KSTREAM / RP_MLP): A1 -> acc1
+//   opk_rowgemm_mlp.hip.h        mlp_phase()       whole-layer kernel: the MLP with h on chip.  Its two sections stay closures
+//                                                  over the loop's register arrays, included in place: opk_rowgemm_mlp_ops.inc
+//                                                  (stage DMA, GeGLU micro-operations, MFMA steps), opk_rowgemm_mlp_loop.inc
+//                                                  (macro-iterations) -- as members they cost the fp16 + e4m3 instantiations
+//                                                  6 - 15 %
+//   opk_rowgemm_qkv_pairs.hip.h  qkv_pairs_loop()  fp16 + e4m3 kernel sets: q / k / v^T as one fragment stream per chunk pair
+//   opk_rowgemm_chunks.hip.h     chunk_loop()      the chunk loop (q / k / v^T with RoPE, GeGLU) and its deferred epilogues
+// and the transitions between them are functions over that state: opk_rowgemm_ln.hip.h (residual + LayerNorm, row write-back,
+// layer-0 rows), opk_rowgemm_stream.hip.h (final_norm + pruning head; LDS layouts and MFMA streams).  Parameters and pack
+// kernels: opk_rowgemm_pack.hip.h; the k-streamed GEMM: opk_kstream.hip.h.
 #pragma once
 
 #include "opk_rowgemm_pack.hip.h"
@@ -233,8 +234,6 @@ struct RowGemmBlock {
 #define OPK_STAMP(i)
 #define OPK_DUMP()
 #endif
-
-#include "opk_rowgemm_mlp_members.inc"
 
   // ---- the phases (defined in opk_rowgemm_phase1 / _mlp / _qkv_pairs / _chunks .hip.h) and the transitions between them ----
   __device__ __forceinline__ void phase1();          // acc1 = A1 W1^T, K1 streamed (attention output projection)

@@ -90,7 +90,7 @@ def test_product_kernel_headers_carry_no_ablation_switches(tmp_path):
     with open(root / "microbench" / "experiments" / "rowgemm_ablation_hooks.patch") as fh:
         applied = subprocess.run(["patch", "-p1", "-s"], stdin=fh, cwd=tmp_path, capture_output=True, text=True)
     assert applied.returncode == 0, applied.stdout + applied.stderr
-    assert "OPK_ABL_NO_DMA" in (dst / "csrc" / "opk_rowgemm_mlp_loop.inc").read_text()  # (the kernel body is cut by phase into .inc files)
+    assert "OPK_ABL_NO_DMA" in (dst / "csrc" / "opk_rowgemm_mlp_loop.inc").read_text()  # (a section of RowGemmBlock::mlp_phase)
 
 
 def test_named_dims_overrides_are_checked():
