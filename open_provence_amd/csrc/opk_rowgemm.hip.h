@@ -124,6 +124,22 @@ struct RowGemmBlock {
   static constexpr int NF1 = 2 * KS;  // feature fragments of a row block's H outputs (phase 1, MLP)
   f32x4 acc1[NF1][MF];                 // PHASE1: the block's rows [feature fragment][row fragment], x + o Wo^T (+ h Wo^T)
   float4 xq0[(PRO == RP_MLP) ? NF1 : 1];  // RP_MLP: row fragment 0 of x, requested at the top of the kernel
+  // the MLP loop's register arrays, where they live in the block (opk_rowgemm_mlp_ops.inc): the single-pass 8 x 16 kernels
+  static constexpr bool MLP_REGS_IN_BLOCK = PRO == RP_MLP && WAVES == 8 && F8 == 0 && T1 == 0 && TW == 0 && TM == 0;
+  struct MlpRegs {
+    f32x4 acc_b[2][MF];
+    uint2 hold_hi[MF];
+    uint2 hold_lo[MF];
+    bf16x8 h_hi[MF];
+    bf16x8 h_lo[MF];
+    float g_prev[MF][4];
+    float g_cur[MF][4];
+    float gx[MF * 4];
+    float gq[MF * 4];
+    uint2 pk_hi[MF];
+    float pk_d[MF][4];
+    f32x4 nbv[2][MF];
+  } mlp_regs;
   uint32_t lds_stage[2];  // LDS byte address of this lane's 16 bytes in piece 0 of each stage (the hand-placed fragment reads add immediates)
 #ifdef OPK_TIMING
   unsigned long long opk_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, opk_wait = 0, opk_wait2 = 0, opk_wait1 = 0, opk_x[4] = {0, 0, 0, 0}, opk_rt0 = 0;

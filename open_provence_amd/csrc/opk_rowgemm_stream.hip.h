@@ -176,6 +176,13 @@ __device__ __forceinline__ void rowgemm_chunk_mfma_f8(uint32_t lds_addr, const b
   });
 }
 
+// a reference to `a` (FIRST) or `b`: the choice is a compile-time fact, both have the same type
+template <bool FIRST, class T>
+__device__ __forceinline__ T& pick_ref(T& a, T& b) {
+  if constexpr (FIRST) return a;
+  else return b;
+}
+
 // final_norm + pruning head on the rows in the accumulators (see RowGemmParams::fin_ln).  Same arithmetic per row
 // as rowgemm_kernel's layer_ln; the head's two dot products ride on the normalised values (or, fin_pre_norm, on the raw row), the
 // four lanes of a row are summed, the lane of column group 0 writes the token's logits and keep-probability.
