@@ -295,6 +295,7 @@ def cpu_baseline(dims: EncoderDims, state, seq_len: int) -> dict:
 
 
 def main() -> None:
+    os.environ.setdefault("OPEN_PROVENCE_CALIBRATE_FULL", "1")  # the line reports every candidate of the load-time calibration
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=100)

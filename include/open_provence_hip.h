@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 7 /* 7: kernel sets 10 / 11 (fp16 attention inside the fp16 + e4m3 sets), op_calibration holds 16 candidates; 6: op_select_kernel_set, op_calibrate, kernel set 7 ("f16": single-pass fp16 operands); 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
+#define OP_ABI_VERSION 8 /* 8: op_calibration.flags (OP_CAL_FULL_REPORT; the search stops at the first candidate that holds otherwise), op_calibrate validates its batch before it touches the handle, op_load_weight of a GEMM weight drops a pinned / calibrated kernel set; 7: kernel sets 10 / 11 (fp16 attention inside the fp16 + e4m3 sets), op_calibration holds 16 candidates; 6: op_select_kernel_set, op_calibrate, kernel set 7 ("f16": single-pass fp16 operands); 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
@@ -227,7 +227,9 @@ typedef struct op_calibration {
                              * the tolerance (it is the set the parity tests stand on), but when it is NOT FINITE -- an
                              * activation beyond fp16's range on sets 3 - 6 -- and no candidate passes, the reference set is
                              * chosen right away instead of at the first forward that overflows */
+  uint32_t flags;           /* IN: OP_CAL_* bits */
 } op_calibration;
+#define OP_CAL_FULL_REPORT 1u /* measure every candidate (the report lists them all); default: cheapest first, stop at the first that holds */
 int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const int32_t* cu_seqlens_host, int n_seqs,
                  op_calibration* report);
 

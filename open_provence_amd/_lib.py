@@ -12,9 +12,10 @@ import os
 from pathlib import Path
 
 OP_MAX_LAYERS = 128
-OP_ABI_VERSION = 7
+OP_ABI_VERSION = 8
 
 OP_OK = 0
+OP_ERR_INVALID, OP_ERR_UNSUPPORTED, OP_ERR_HIP, OP_ERR_STATE, OP_ERR_WORKSPACE, OP_ERR_NOMEM = -1, -2, -3, -4, -5, -6
 OP_DTYPE_F32, OP_DTYPE_BF16, OP_DTYPE_F16 = 0, 1, 2
 OP_PRECISION_BF16X3, OP_PRECISION_BF16, OP_PRECISION_BF16X2, OP_PRECISION_CUSTOM = 0, 1, 2, 3
 OP_TERM_LEFT_LO, OP_TERM_RIGHT_LO = 1, 2
@@ -110,7 +111,11 @@ class OpCalibration(ctypes.Structure):
         ("n_rows", ctypes.c_int32),
         ("n_tokens", ctypes.c_int32),
         ("default_err", ctypes.c_float),
+        ("flags", ctypes.c_uint32),
     ]
+
+
+OP_CAL_FULL_REPORT = 1
 
 
 class OpProfileEntry(ctypes.Structure):

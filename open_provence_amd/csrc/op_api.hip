@@ -1256,6 +1256,10 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     zero_lo = (req_mask[family] & OP_TERM_RIGHT_LO) ? 0 : 1;
     any_lo = h->any_lo_dev + family;
     h->resolved = false;
+    // a kernel set pinned by op_select_kernel_set or measured by op_calibrate belongs to the weights it was chosen on: new
+    // GEMM weights start from the default selection again (and from the compact formats, if op_set_compact_operands left them)
+    h->forced_set = -1;
+    h->f8_off = false;
   }
   switch (kind) {
     case F32_COPY:
@@ -1574,10 +1578,27 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
     return fail(h, OP_ERR_INVALID, "op_calibrate: ids_host / cu_seqlens_host / n_seqs must be given together");
   int rc = op_weights_ready(h);
   if (rc != OP_OK) return rc;
+  // the caller's batch is checked BEFORE the handle's state is touched: a refused call leaves a pinned set where it was
+  if (ids_host) {
+    if (cu_seqlens_host[0] != 0 || cu_seqlens_host[n_seqs] <= 0)
+      return fail(h, OP_ERR_INVALID, "op_calibrate: cu_seqlens must start at 0 and hold at least one token");
+    for (int s = 0; s < n_seqs; ++s) {
+      const int len = cu_seqlens_host[s + 1] - cu_seqlens_host[s];
+      if (len < 0 || len > h->cfg.max_position_embeddings)
+        return fail(h, OP_ERR_INVALID, "op_calibrate: row %d has %d tokens (cu_seqlens must not decrease; max_position_embeddings is %d)", s, len,
+                    h->cfg.max_position_embeddings);
+    }
+    for (int i = 0; i < cu_seqlens_host[n_seqs]; ++i)
+      if (ids_host[i] < 0 || ids_host[i] >= h->cfg.vocab_size)
+        return fail(h, OP_ERR_INVALID, "op_calibrate: token id %d at position %d is outside the embedding table (vocab_size %d)", ids_host[i], i,
+                    h->cfg.vocab_size);
+  }
+  const bool full_report = report && (report->flags & OP_CAL_FULL_REPORT) != 0;
   OP_HIP(h, hipSetDevice(h->cfg.device_id));
 
   // the default selection and its (hi, lo) bf16 realisation = the reference of the comparison
   const bool f8_off_before = h->f8_off;
+  const int forced_before = h->forced_set;
   h->forced_set = -1;
   h->resolved = false;
   OP_TRY(resolve_policy(h));
@@ -1597,11 +1618,20 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
   rep.reference_set = reference_set;
   rep.default_set = default_set;
   rep.chosen_set = default_set;
-  auto finish = [&]() {
+  rep.flags = report ? report->flags : 0u;
+  auto finish = [&]() -> int {
     if (report) *report = rep;
     return OP_OK;
   };
-  if (default_set < 0 || reference_set < 0) return finish();  // a custom policy on the all-terms kernels: nothing cheaper is defined
+  // nothing to measure: whatever was pinned before the call stays pinned
+  auto finish_unchanged = [&]() -> int {
+    h->forced_set = forced_before;
+    h->resolved = false;
+    OP_TRY(resolve_policy(h));
+    rep.chosen_set = public_set(h);
+    return finish();
+  };
+  if (default_set < 0 || reference_set < 0) return finish_unchanged();  // a custom policy on the all-terms kernels: nothing cheaper is defined
 
   // candidates: every available kernel set cheaper than the default one, cheapest first
   std::vector<int> cand;
@@ -1609,12 +1639,11 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
     if (set != default_set && set_available(h, set) && set_cost(h, set) < set_cost(h, default_set)) cand.push_back(set);
   std::sort(cand.begin(), cand.end(), [&](int a, int b) { return set_cost(h, a) < set_cost(h, b); });
   if (cand.size() > 16) cand.resize(16);
-  if (cand.empty()) return finish();
+  if (cand.empty()) return finish_unchanged();
 
   std::vector<int32_t> ids, cu;
   if (ids_host) {
     cu.assign(cu_seqlens_host, cu_seqlens_host + n_seqs + 1);
-    if (cu[0] != 0 || cu[n_seqs] <= 0) return fail(h, OP_ERR_INVALID, "op_calibrate: cu_seqlens must start at 0 and hold at least one token");
     ids.assign(ids_host, ids_host + cu[n_seqs]);
   } else {
     synthetic_calibration_rows(h, ids, cu);
@@ -1691,6 +1720,7 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
       rep.candidate_err[rep.n_candidates] = err;
       rep.n_candidates += 1;
       if (chosen < 0 && err <= tolerance) chosen = cand[c];
+      if (chosen >= 0 && !full_report) break;  // cheapest first: the first one that holds is the answer (OP_CAL_FULL_REPORT measures them all)
     }
   }
   h->profiling = profiling;

@@ -61,24 +61,37 @@ def parse_precision(precision: "str | Mapping[str, int]") -> tuple[int, list[int
 _DTYPES = {torch.float32: _lib.OP_DTYPE_F32, torch.bfloat16: _lib.OP_DTYPE_BF16, torch.float16: _lib.OP_DTYPE_F16}
 
 DEFAULT_CALIBRATION_TOLERANCE = 1e-4  # max |logit difference| to the (hi, lo) bf16 kernels; the path's bar is 1e-3
+PATH_TOLERANCE = 1e-3  # BASELINE.json north_star: logits within 1e-3 of the fp32 CPU reference
 
 
 def resolve_calibration_tolerance(calibrate: "bool | float | None") -> float:
     """``False`` / ``0`` -> 0.0 (no calibration); a float -> that tolerance; ``True`` / ``None`` -> ``OPEN_PROVENCE_CALIBRATE``
     (``0`` / ``off`` disables, a number is the tolerance) or :data:`DEFAULT_CALIBRATION_TOLERANCE`."""
 
-    if calibrate is False:
-        return 0.0
-    if calibrate is not None and calibrate is not True:
-        return max(float(calibrate), 0.0)
+    if isinstance(calibrate, (bool, np.bool_)):  # (by TYPE: `1` / `np.True_` are not `True` by identity)
+        if not calibrate:
+            return 0.0
+        calibrate = None
+    if calibrate is not None:
+        tolerance = float(calibrate)
+        if isinstance(calibrate, (int, np.integer)) and tolerance == 1.0:
+            calibrate = None  # `calibrate=1` means "on", not a tolerance of 1.0 logit
+        elif not tolerance < PATH_TOLERANCE:  # (also NaN)
+            raise ValueError(f"calibration tolerance {calibrate!r} is not inside the path's own bar ({PATH_TOLERANCE:g} on a logit): "
+                             "any candidate would pass; use kernel_set= to pin a set regardless of its error")
+        else:
+            return max(tolerance, 0.0)
     env = os.environ.get("OPEN_PROVENCE_CALIBRATE", "").strip().lower()
     if env in ("0", "off", "false", "no"):
         return 0.0
     if env and env not in ("1", "on", "true", "yes"):
         try:
-            return max(float(env), 0.0)
+            tolerance = max(float(env), 0.0)
+            if not tolerance < PATH_TOLERANCE:
+                raise ValueError
+            return tolerance
         except ValueError as exc:
-            raise ValueError(f"OPEN_PROVENCE_CALIBRATE must be 0 / off or a tolerance, got {env!r}") from exc
+            raise ValueError(f"OPEN_PROVENCE_CALIBRATE must be 0 / off or a tolerance below {PATH_TOLERANCE:g}, got {env!r}") from exc
     return DEFAULT_CALIBRATION_TOLERANCE
 
 
@@ -207,6 +220,10 @@ class HipEncoder:
                 continue
             self.load_weight(name, tensor)
         _lib.check(self.lib, self._handle, self.lib.op_weights_ready(self._handle), "op_weights_ready")
+        # A kernel set pinned or calibrated on the PREVIOUS checkpoint is not a property of this one: op_load_weight drops it
+        # for every GEMM weight that changes (ABI 8); a state dict that reloads only norms / heads / embeddings keeps the
+        # weights the set was measured on, but the measurement covered those tensors too -- back to the default selection.
+        _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(_lib.OP_KS_AUTO)), "op_select_kernel_set(auto)")
         self.__dict__["_f8_active"] = None
         self.__dict__["_audit_pending"] = False
         self.calibration = None
@@ -229,7 +246,7 @@ class HipEncoder:
         self.__dict__["_f8_active"] = None
         self.__dict__["_audit_pending"] = False  # (a pinned set is the caller's decision: nothing to audit)
 
-    def calibrate(self, tolerance: float = 1e-4, rows: "Sequence[Sequence[int]] | None" = None) -> dict:
+    def calibrate(self, tolerance: float = 1e-4, rows: "Sequence[Sequence[int]] | None" = None, *, full_report: "bool | None" = None) -> dict:
         """``op_calibrate``: one batch (``rows`` of token ids -- a sample of real inputs -- or the library's synthetic
         batch) through the (hi, lo) bf16 kernels and through every kernel set cheaper than the default one; the
         cheapest whose logits stay within ``tolerance`` of them (and finite) is what the forward runs on from now on.
@@ -238,6 +255,11 @@ class HipEncoder:
 
         report = _lib.OpCalibration()
         report.struct_bytes = ctypes.sizeof(_lib.OpCalibration)
+        # cheapest first, stop at the first candidate that holds (up to 11 fewer forwards at load on the deep models);
+        # full_report=True / OPEN_PROVENCE_CALIBRATE_FULL=1 measures every candidate (scripts/calibration_probe.py)
+        if full_report is None:
+            full_report = os.environ.get("OPEN_PROVENCE_CALIBRATE_FULL", "").strip().lower() in ("1", "on", "true", "yes")
+        report.flags = _lib.OP_CAL_FULL_REPORT if full_report else 0
         if rows is not None:
             ids_np, cu_np, _ = pack_rows(rows)
             self.check_ids(ids_np)
@@ -310,6 +332,11 @@ class HipEncoder:
         self.__dict__["_f8_active"] = None
         if changed.value:
             import warnings
+
+            if self.calibration is not None:  # the report names what RUNS, not what was chosen before the fallback
+                self.calibration["chosen_set"] = self.effective_policy()["kernel_set"]
+                self.calibration["fallback"] = "fp16 range guard"
+            self.__dict__["_audit_pending"] = False
 
             self.fallbacks = int(getattr(self, "fallbacks", 0)) + 1  # reported by process() (timing / performance_trace)
 
@@ -405,9 +432,20 @@ class HipEncoder:
             self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, int(max_seqlen),
                                  prune.data_ptr(), rank.data_ptr(), keep_prob.data_ptr() if keep_prob is not None else None,
                                  ws, stream)
-            if self.__dict__.get("_audit_pending") and total >= 64 and self._capture is None:
-                self._audit_first_batch(ids, cu_seqlens, cu_host, n_seqs, total, int(max_seqlen), prune, rank, keep_prob, ws, stream)
+            self._maybe_audit(ids, cu_seqlens, cu_host, n_seqs, total, int(max_seqlen), prune, rank, keep_prob, ws, stream)
         return prune, rank
+
+    def _maybe_audit(self, ids, cu_seqlens, cu_host, n_seqs, total, max_seqlen, prune, rank, keep_prob, ws, stream) -> None:
+        """The first-real-batch audit of a synthetically calibrated kernel set, from EITHER forward entry point
+        (``forward_packed`` / ``forward_packed_on``).  Skipped -- and left pending -- for batches under 64 tokens, while hidden
+        states are captured, and while the stream is being captured into a hipGraph (the audit synchronises and switches the
+        handle's kernel set in the middle of the forward)."""
+
+        if not self.__dict__.get("_audit_pending") or total < 64 or self._capture is not None:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self._audit_first_batch(ids, cu_seqlens, cu_host, n_seqs, total, max_seqlen, prune, rank, keep_prob, ws, stream)
 
     def _audit_first_batch(self, ids, cu_seqlens, cu_host, n_seqs, total, max_seqlen, prune, rank, keep_prob, ws, stream) -> None:
         """The calibration ran on synthetic token ids; the FIRST real batch a calibrated model sees is its audit: the same
@@ -565,6 +603,9 @@ class HipEncoder:
             self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, int(max_seqlen),
                                  prune.data_ptr(), rank.data_ptr(), keep_prob.data_ptr() if keep_prob is not None else None,
                                  ws, side.cuda_stream)
+            # (the audit synchronises this pipeline's stream once; the other pipeline must not be mid-forward on another
+            # host thread while it runs -- the pipelines of one encoder are driven from ONE thread everywhere in this package)
+            self._maybe_audit(ids, cu_seqlens, cu_host, n_seqs, total, int(max_seqlen), prune, rank, keep_prob, ws, side.cuda_stream)
         return prune, rank
 
     def pipeline_stream(self, part: int) -> torch.cuda.Stream:

@@ -580,18 +580,34 @@ class HostFrontEnd:
             raise TypeError("HostFrontEnd sends the model's tokenizer to its worker processes and it cannot be pickled "
                             f"({type(exc).__name__}: {exc}); pass tokenizer_factory=<a module-level function that builds it>") from exc
         self._procs, conns = [], []
-        with _main_module_hidden(not import_main):
-            for rank in range(self.world):
-                mine, theirs = ctx.Pipe(duplex=True)
-                proc = ctx.Process(target=_serve_host_stages, args=(rank, self.world, theirs, spec), daemon=True)
-                proc.start()
-                theirs.close()
-                self._procs.append(proc)
-                conns.append(mine)
-        for conn in conns:
-            kind, _request, _payload = conn.recv()  # "ready": the replica has its tokenizer
-            if kind != "ready":
-                raise RuntimeError("a host-stage worker did not start")
+        try:
+            with _main_module_hidden(not import_main):
+                for rank in range(self.world):
+                    mine, theirs = ctx.Pipe(duplex=True)
+                    proc = ctx.Process(target=_serve_host_stages, args=(rank, self.world, theirs, spec), daemon=True)
+                    proc.start()
+                    theirs.close()
+                    self._procs.append(proc)
+                    conns.append(mine)
+            for conn in conns:
+                kind, _request, _payload = conn.recv()  # "ready": the replica has its tokenizer
+                if kind != "ready":
+                    raise RuntimeError("a host-stage worker did not start")
+        except BaseException:
+            # a later start() or handshake failed: the replicas that DID start must not outlive this constructor (the caller
+            # never gets an object to close; modeling.process() catches the exception and carries on in-process)
+            for conn in conns:
+                try:
+                    conn.close()
+                except OSError:
+                    pass
+            for proc in self._procs:
+                if proc.is_alive():
+                    proc.terminate()
+            for proc in self._procs:
+                proc.join(timeout=5)
+            self._procs = []
+            raise
         self._hub = _OwnerHub(conns)
         self._open = True
         self._lock = threading.Lock()

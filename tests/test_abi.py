@@ -104,3 +104,30 @@ def test_named_dims_overrides_are_checked():
     assert named_dims("xsmall", vocab_size=2048).vocab_size == 2048
     with pytest.raises(TypeError):
         named_dims("base", layers=3)
+
+
+def test_calibration_tolerance_argument_forms(monkeypatch):
+    """``calibrate=1`` (an int, not ``True``) used to become a tolerance of 1.0 -- any candidate passed; ``np.bool_``
+    likewise.  Booleans are recognised by type, ``1`` means "on", and a tolerance at or above the path's own bar is refused."""
+
+    import numpy as np
+    import pytest
+
+    from open_provence_amd.engine import DEFAULT_CALIBRATION_TOLERANCE, resolve_calibration_tolerance
+
+    monkeypatch.delenv("OPEN_PROVENCE_CALIBRATE", raising=False)
+    for on in (True, None, 1, np.True_, np.int64(1)):
+        assert resolve_calibration_tolerance(on) == DEFAULT_CALIBRATION_TOLERANCE, on
+    for off in (False, 0, 0.0, np.False_):
+        assert resolve_calibration_tolerance(off) == 0.0, off
+    assert resolve_calibration_tolerance(2e-4) == 2e-4
+    for bad in (1.0, 1e-3, 5, float("nan")):
+        with pytest.raises(ValueError):
+            resolve_calibration_tolerance(bad)
+    monkeypatch.setenv("OPEN_PROVENCE_CALIBRATE", "3e-5")
+    assert resolve_calibration_tolerance(None) == 3e-5
+    monkeypatch.setenv("OPEN_PROVENCE_CALIBRATE", "0.5")
+    with pytest.raises(ValueError):
+        resolve_calibration_tolerance(True)
+    monkeypatch.setenv("OPEN_PROVENCE_CALIBRATE", "off")
+    assert resolve_calibration_tolerance(None) == 0.0

@@ -25,6 +25,14 @@ pytestmark = pytest.mark.gpu
 PAIRS, SEQ_LEN = 256, 512
 
 
+@pytest.fixture(autouse=True)
+def _every_candidate_measured(monkeypatch):
+    """The tests below read the WHOLE report (a set that must fail, a set that must have been tried); the product's default
+    stops at the first candidate that holds (``test_the_search_stops_at_the_first_candidate_that_holds``)."""
+
+    monkeypatch.setenv("OPEN_PROVENCE_CALIBRATE_FULL", "1")
+
+
 def _bf16_rounded(state):
     return {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
 
@@ -438,4 +446,75 @@ def test_first_real_batch_audits_the_calibrated_set():
         assert any("first real batch" in str(w.message) for w in caught)
     assert not enc.calibration["audit"]["passed"] and enc.effective_policy()["kernel_set"] == "f16-f8-w" == enc.calibration["chosen_set"]
     assert all(np.array_equal(a, b) for a, b in zip(got, want_default))
+    enc.close()
+
+
+def test_the_search_stops_at_the_first_candidate_that_holds(monkeypatch):
+    """every candidate used to run after one had already passed (up to 11 extra forwards at load on the deep
+    models).  Default now: cheapest first, stop at the first that holds; the full report is opt-in.  Same choice either way."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict
+
+    dims = named_dims("xsmall")
+    state = refinit_state_dict(dims, seed=7)
+    monkeypatch.delenv("OPEN_PROVENCE_CALIBRATE_FULL", raising=False)
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(state)
+    short = enc.calibration
+    full = enc.calibrate(1e-4, full_report=True)
+    assert short["chosen_set"] == full["chosen_set"] == "f16"
+    assert list(short["candidates"])[-1] == "f16" and short["candidates"]["f16"] <= 1e-4, short
+    assert len(full["candidates"]) > len(short["candidates"]) and full["candidates"]["f16"] == short["candidates"]["f16"]
+    enc.close()
+
+
+def test_reloading_weights_drops_the_previous_checkpoints_kernel_set():
+    """a calibrated / pinned kernel set survived ``load_state_dict(new_state, calibrate=False)`` -- new
+    weights then ran on an approximating set measured on the PREVIOUS checkpoint.  A reload starts from the default selection:
+    the O(1) weights loaded over a model calibrated to "f16" run on "f16-f8-w" and match a fresh encoder bit for bit."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch, synth_state_dict
+
+    dims = named_dims("xsmall")
+    rows = synth_pair_batch(dims, 4, 128, seed=5)
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(refinit_state_dict(dims, seed=7))
+    assert enc.effective_policy()["kernel_set"] == "f16"
+    o1 = synth_state_dict(dims, seed=7)
+    enc.load_state_dict(o1, calibrate=False)
+    assert enc.calibration is None and enc.effective_policy()["kernel_set"] == "f16-f8-w"
+    p1, r1, _ = enc.forward_rows(rows)
+    enc.select_kernel_set("bf16")  # a pinned set does not survive either
+    enc.load_state_dict(o1, calibrate=False)
+    assert enc.effective_policy()["kernel_set"] == "f16-f8-w"
+    fresh = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    fresh.load_state_dict(o1, calibrate=False)
+    p2, r2, _ = fresh.forward_rows(rows)
+    assert torch.equal(p1, p2) and torch.equal(r1, r2)
+    enc.close()
+    fresh.close()
+
+
+def test_a_refused_calibration_batch_leaves_a_pinned_set_alone():
+    """op_calibrate cleared the pinned set before it looked at the caller's rows; ids are range-checked in C now."""
+
+    import ctypes
+
+    from open_provence_amd import _lib
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict
+
+    dims = named_dims("xsmall")
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(refinit_state_dict(dims, seed=7), kernel_set="bf16")
+    ids = np.array([1, 2, dims.vocab_size + 5, 3], dtype=np.int32)  # out of range: refused by the library itself
+    cu = np.array([0, 4], dtype=np.int32)
+    code = enc.lib.op_calibrate(enc._handle, ctypes.c_float(1e-4), ids.ctypes.data_as(ctypes.c_void_p), cu.ctypes.data_as(ctypes.c_void_p), 1, None)
+    assert code == _lib.OP_ERR_INVALID and "embedding table" in _lib.last_error(enc.lib, enc._handle)
+    cu_bad = np.array([0, 3, 2], dtype=np.int32)
+    code = enc.lib.op_calibrate(enc._handle, ctypes.c_float(1e-4), ids.ctypes.data_as(ctypes.c_void_p), cu_bad.ctypes.data_as(ctypes.c_void_p), 2, None)
+    assert code == _lib.OP_ERR_INVALID
+    assert enc.effective_policy()["kernel_set"] == "bf16"
     enc.close()
