@@ -87,6 +87,7 @@ enum op_flags {
   OP_FLAG_ATTN_XCD_GROUP = 1024,  /* row path too: the XCD-grouped attention block map (the query blocks of a sequence-head follow each other on one XCD; default on the panel path only) (A/B hook) */
   OP_FLAG_PANEL_F8 = 2048,        /* hidden 512 / 768 (panel GEMMs): select the fp16 + e4m3 kernel sets there too.  OFF by default: through 19-25 layers their error against the fp32 reference reaches 0.45-1.0e-3 on logits (the (hi, lo) bf16 sets: 0.2-0.5e-3), too close to the 1e-3 bar of the path for +2.5 % (bf16 checkpoint) / +14 % (fp32) pairs/s.  On this opt-in path the MLP activation h is an fp16 operand converted with saturation: a value beyond 65504 is CLAMPED, not reported (the row path's sets turn it into NaN and fall back; the default panel sets keep h as (hi, lo) bf16 pairs with fp32's range) */
   OP_FLAG_PANEL_F8_WI = 4096,     /* hidden 512 / 768: the fp16 + e4m3 format in the Wi GEMM alone (52 % of the GEMM FLOPs; LayerNorm(mlp_norm) written in that format, h still as (hi, lo) bf16 pieces for the MLP output projection): the cheapest place for the format's error.  DEFAULT for fp32-valued weights (+5.6 % pairs/s on base, <= 5.4e-4 at 19-25 layers); this flag requests it for bf16-valued weights too (+0.7 %).  OP_FLAG_NO_F8 switches it off */
+  OP_FLAG_NO_LAYER_PAIRS = 8192,  /* hidden = 256, single-pass kernel sets ("f16" / "bf16"): keep the 8 waves x 16 rows whole-layer kernel instead of the wave-pair kernel (opk_layer16p.hip.h) (A/B and test hook) */
   OP_FLAG_NO_F8 = 512             /* never select kernel set 3 (fp16 hi + e4m3 lo operands in the whole-layer kernel): keep the (hi, lo) bf16 kernel sets (A/B and bit-identity test hook) */
 };
 

@@ -14,6 +14,7 @@
 
 #include "opk_rowgemm.hip.h"
 #include "opk_layer32.hip.h"
+#include "opk_layer16p.hip.h"
 
 #ifndef ABL_T
 #define ABL_T 1
@@ -189,7 +190,7 @@ int main() {
   p.rope_cos = d_cos;
   p.rope_sin = d_sin;
   p.max_pos = 8192;
-#if ABL_LAYER == 32
+#if ABL_LAYER == 32 || ABL_LAYER == 34
   // the same launch on the 32x32x16 shape (opk_layer32.hip.h); buffers are reused (its packs are hi planes only)
   Layer32Params lp;
   memset(&lp, 0, sizeof(lp));
@@ -214,7 +215,18 @@ int main() {
   lp.rope_cos = d_cos;
   lp.rope_sin = d_sin;
   lp.max_pos = 8192;
+#ifndef ABL_XT
+#define ABL_XT false
+#endif
+#if ABL_LAYER == 34  // the wave-pair form on 16x16x32 MFMAs (opk_layer16p.hip.h)
+#ifdef ABL_H16
+  auto launch = [&]() { hipLaunchKernelGGL((layer16p_kernel<8, true, true, ABL_XT, ABL_XT>), dim3(R / 128), dim3(512), 0, 0, lp); };
+#else
+  auto launch = [&]() { hipLaunchKernelGGL((layer16p_kernel<8, true, false, ABL_XT, ABL_XT>), dim3(R / 128), dim3(512), 0, 0, lp); };
+#endif
+#else
   auto launch = [&]() { hipLaunchKernelGGL((layer32_kernel<8, true, ABL_T != 0, 7>), dim3(R / 128), dim3(256), 0, 0, lp); };
+#endif
 #else
 #ifdef ABL_F8
   constexpr int kF8 = ABL_F8;  // 1: bf16-valued weights (ABL_T = 1), 2: fp32-valued weights (ABL_T = 3)
@@ -300,7 +312,7 @@ int main() {
     for (int b = 0; b < blocks; ++b) {
       const unsigned long long* s = &t[(size_t)b * 16];
       if (!s[11] || !s[12]) continue;
-      x[0] += (double)(s[11] - s[1]);
+      x[0] += (double)(s[11] - (ABL_LAYER == 34 ? s[0] : s[1]));
       x[1] += (double)(s[12] - s[3]);
       x[2] += (double)(s[13] - s[3]);
       x[3] += (double)(s[14] - s[3]);
@@ -318,6 +330,75 @@ int main() {
     if (nx)
       printf("  LayerNorm 1: row fragment 0 done at +%.0f | LayerNorm 2: fragment 0 +%.0f, arithmetic +%.0f, DMA/RoPE wait +%.0f (then the row stores)\n",
              x[0] / nx, x[1] / nx, x[2] / nx, x[3] / nx);
+  }
+#endif
+#if defined(ABL_LAYER) && ABL_LAYER == 34
+  {  // determinism probe: two launches from the same inputs must give the same bytes
+    const size_t nx = (size_t)R * H, nq = (size_t)R * H * 2;
+    std::vector<float> x1(nx), x2(nx);
+    std::vector<u16> q1(nq), q2(nq), k1(nq), k2(nq), v1(nq), v2(nq);
+    for (int rep = 0; rep < 2; ++rep) {
+      CHECK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+      CHECK(hipMemset(d_q, 0, nq * 2));
+      CHECK(hipMemset(d_k, 0, nq * 2));
+      CHECK(hipMemset(d_v, 0, nq * 2));
+      launch();
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipMemcpy(rep ? x2.data() : x1.data(), d_x, nx * 4, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(rep ? q2.data() : q1.data(), d_q, nq * 2, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(rep ? k2.data() : k1.data(), d_k, nq * 2, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(rep ? v2.data() : v1.data(), d_v, nq * 2, hipMemcpyDeviceToHost));
+    }
+    size_t dx = 0, dq = 0, dk = 0, dv = 0, fx = ~(size_t)0, fq = ~(size_t)0;
+    for (size_t i = 0; i < nx; ++i) if (memcmp(&x1[i], &x2[i], 4)) { if (!dx) fx = i; ++dx; }
+    for (size_t i = 0; i < nq; ++i) { if (q1[i] != q2[i]) { if (!dq) fq = i; ++dq; } dk += k1[i] != k2[i]; dv += v1[i] != v2[i]; }
+    printf("  determinism: x differs in %zu of %zu (first %zu), q %zu (first %zu), k %zu, v %zu\n", dx, nx, fx, dq, fq, dk, dv);
+    if (dq) {
+      size_t h_pw[4] = {0}, h_mf[2] = {0}, h_hf[2] = {0}, h_g[4] = {0}, h_ks[8] = {0}, h_r[4] = {0}, h_n[16] = {0}, h_blk[8] = {0};
+      for (size_t i = 0; i < nq; ++i) if (q1[i] != q2[i]) {
+        const size_t piece = i / 512, within = i % 512, rb = piece / 16, ks = (piece / 2) % 8, ln = within / 8, e = within % 8;
+        h_pw[(rb / 2) % 4]++; h_mf[rb % 2]++; h_hf[(ln / 16) >> 1]++; h_g[2 * ((ln / 16) & 1) + (e >> 2)]++; h_ks[ks]++; h_r[e & 3]++; h_n[ln % 16]++; h_blk[(rb / 8) % 8]++;
+      }
+      printf("  q diffs by pw:"); for (auto v_ : h_pw) printf(" %zu", v_);
+      printf(" | mf:"); for (auto v_ : h_mf) printf(" %zu", v_);
+      printf(" | hf:"); for (auto v_ : h_hf) printf(" %zu", v_);
+      printf(" | g:"); for (auto v_ : h_g) printf(" %zu", v_);
+      printf(" | k-step:"); for (auto v_ : h_ks) printf(" %zu", v_);
+      printf(" | r:"); for (auto v_ : h_r) printf(" %zu", v_);
+      printf(" | n16:"); for (auto v_ : h_n) printf(" %zu", v_);
+      printf(" | block%%8:"); for (auto v_ : h_blk) printf(" %zu", v_);
+      printf("\n");
+      int shown = 0;
+      for (size_t i = 0; i < nq && shown < 12; ++i) if (q1[i] != q2[i]) { printf("    q[%zu] %04x vs %04x\n", i, q1[i], q2[i]); ++shown; }
+    }
+    if (dv) {
+      size_t h_e[8] = {0}, h_kg[4] = {0}, h_n4[4] = {0}, h_d[16] = {0}, h_tok[32] = {0}, h_head[4] = {0};
+      for (size_t i = 0; i < nq; ++i) if (v1[i] != v2[i]) {
+        const size_t piece = i / 512, within = i % 512, ln = within / 8, e = within % 8;
+        h_e[e]++; h_kg[ln / 16]++; h_d[ln % 16]++; h_n4[piece % 4]++; h_tok[(e < 4 ? 0 : 16) + 4 * (ln / 16) + (e & 3)]++;
+        h_head[(piece / 8) / (R / 32) % 4]++;
+      }
+      printf("  v diffs by e:"); for (auto v_ : h_e) printf(" %zu", v_);
+      printf(" | kg:"); for (auto v_ : h_kg) printf(" %zu", v_);
+      printf(" | n4:"); for (auto v_ : h_n4) printf(" %zu", v_);
+      printf(" | head:"); for (auto v_ : h_head) printf(" %zu", v_);
+      printf(" | d':"); for (auto v_ : h_d) printf(" %zu", v_);
+      printf("\n  v diffs by token of the 32-row tile:"); for (auto v_ : h_tok) printf(" %zu", v_);
+      printf("\n");
+    }
+    // which positions of x differ: histogram over (element index within the 4 KiB tile piece) -> wave-pair / lane structure
+    if (dx) {
+      size_t by_tile[8] = {0}, by_i4[4] = {0}, by_lane_g[4] = {0}, by_rowtile[4] = {0};
+      for (size_t i = 0; i < nx; ++i) if (memcmp(&x1[i], &x2[i], 4)) {
+        const size_t piece = i / 256, within = i % 256;  // tiled layout (ABL_XT)
+        by_i4[piece % 4]++; by_tile[(piece / 4) % 8]++; by_rowtile[(piece / 32) % 4]++; by_lane_g[(within / 4) / 16]++;
+      }
+      printf("  x diffs by feature tile:"); for (int i = 0; i < 8; ++i) printf(" %zu", by_tile[i]);
+      printf(" | by piece (2mf+fh):"); for (int i = 0; i < 4; ++i) printf(" %zu", by_i4[i]);
+      printf(" | by lane group g:"); for (int i = 0; i < 4; ++i) printf(" %zu", by_lane_g[i]);
+      printf(" | by row tile pw:"); for (int i = 0; i < 4; ++i) printf(" %zu", by_rowtile[i]);
+      printf("\n");
+    }
   }
 #endif
   CHECK(hipGetLastError());

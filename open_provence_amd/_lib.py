@@ -30,6 +30,7 @@ OP_FLAG_NO_F8 = 512
 OP_FLAG_ATTN_XCD_GROUP = 1024
 OP_FLAG_PANEL_F8 = 2048
 OP_FLAG_PANEL_F8_WI = 4096
+OP_FLAG_NO_LAYER_PAIRS = 8192
 OP_POOL_CLS, OP_POOL_MEAN = 0, 1
 # enum op_kernel_set (op_effective_policy / op_select_kernel_set / op_calibrate)
 OP_KS_AUTO = -1

@@ -25,7 +25,7 @@ _COMMON = [CSRC / "opk_common.hip.h"]
 _ROWGEMM = [CSRC / name for name in ("opk_rowgemm.hip.h", "opk_rowgemm_pack.hip.h", "opk_rowgemm_stream.hip.h", "opk_rowgemm_ln.hip.h", "opk_kstream.hip.h",
                                      "opk_rowgemm_phase1.hip.h", "opk_rowgemm_mlp.hip.h", "opk_rowgemm_mlp_ops.inc", "opk_rowgemm_mlp_loop.inc",
                                      "opk_rowgemm_qkv_pairs.hip.h", "opk_rowgemm_chunks.hip.h")]
-_INTERNAL = _COMMON + [CSRC / "op_internal.h", CSRC / "opk_attn.hip.h", CSRC / "opk_panel.hip.h", CSRC / "opk_layer32.hip.h"] + _ROWGEMM
+_INTERNAL = _COMMON + [CSRC / "op_internal.h", CSRC / "opk_attn.hip.h", CSRC / "opk_panel.hip.h", CSRC / "opk_layer32.hip.h", CSRC / "opk_layer16p.hip.h"] + _ROWGEMM
 
 # (object name, source, extra defines, headers it depends on)
 UNITS = [

@@ -71,6 +71,8 @@ struct LayerWeights {
   u16* wo_ks = nullptr;   // ... and attention output projection (fused kernels)
   // hi planes in the fragment order of the 32x32x16 whole-layer kernel (opk_layer32.hip.h), hidden = 256 only
   u16 *wo_p32 = nullptr, *wi_p32 = nullptr, *wo2_p32 = nullptr, *wqkv_p32 = nullptr;
+  // the wave-pair whole-layer kernel (opk_layer16p.hip.h), hidden = 256: one plane in its fragment order, [0] bf16 / [1] fp16 values
+  u16 *wo_pp[2] = {nullptr, nullptr}, *wi_pp[2] = {nullptr, nullptr}, *wo2_pp[2] = {nullptr, nullptr}, *wqkv_pp[2] = {nullptr, nullptr};
   // "f16 + fp8" kernel set (opk_common.hip.h): chunks of [fp16 plane | e4m3 plane] (Wqkv, Wi), fp16 k-streamed slabs
   // (attention Wo, MLP Wo) and the e4m3 K = 128 slabs of the attention Wo
   u16 *wqkv_f8 = nullptr, *wi_f8 = nullptr, *wo_f16 = nullptr, *wo_f8 = nullptr, *wo2_f16 = nullptr;
@@ -339,6 +341,7 @@ struct ChunkPass {
   unsigned row_grid;
   const char* no_kernel = "internal: no row-stationary kernel for hidden %d";
   bool layer_fused, head_in_last_layer;
+  bool pair_layers;  // whole-layer launches as wave pairs on 32x32x16 MFMAs (opk_layer16p.hip.h)
   bool head_done = false;
 
   ChunkPass(op_handle* h_, Launcher& L_, const Workspace& ws_, const int32_t* ids_dev_, const int32_t* cu_dev_, int s0_, int ns_, int rows_,
@@ -391,6 +394,9 @@ struct ChunkPass {
     // projection) as ONE kernel with h kept on chip; the all-terms set keeps the two fused kernels per layer.
     layer_fused = h->row_path && !h->emulate && opl::has_row_layer_fused(h->pi) && !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION);
     head_in_last_layer = layer_fused && h->cfg.pooling != OP_POOL_MEAN && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
+    pair_layers = layer_fused && H == 256 && I % 64 == 0 && (f16 || h->pi == 2) && !h->capture && !small_blocks &&
+                  !(h->cfg.flags & (OP_FLAG_NO_LAYER_PAIRS | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32)) &&
+                  h->layers[0].wo_pp[f16 ? 1 : 0] != nullptr;
   }
 
   // row map, the range flag, padding rows of the attention output, embeddings
@@ -593,6 +599,39 @@ struct ChunkPass {
         lp.max_pos = h->max_pos;
         OP_TRY(L.begin(PK_FUSED_LAYER));
         if (!opl::launch_layer32(st, lp, h->pi, with_qkv, (unsigned)(r_pad / ROW_BM))) return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
+        OP_TRY(L.end());
+        return OP_OK;
+      }
+      // Single-pass kernel sets ("f16" / "bf16"), hidden = 256, at least a block per CU: the wave-pair kernel
+      // (opk_layer16p.hip.h).  The last layer keeps the 8 x 16 kernel (it ends with final_norm + the pruning head).  Between two
+      // wave-pair launches the residual stream is TILED (coalesced 1 KiB loads / stores): the first one reads rows, the last
+      // one writes rows.  Hidden-state capture reads rows after every layer: it keeps the 8 x 16 kernel.
+      if (pair_layers && with_qkv) {
+        Layer32Params lp;
+        memset(&lp, 0, sizeof(lp));
+        const LayerWeights& nx = h->layers[li + 1];
+        lp.o_fp = ws.o_hi;
+        lp.x_io = ws.x;
+        lp.ln_mlp = lw.mlp_norm;
+        lp.ln_next = nx.attn_norm;
+        lp.eps = h->cfg.norm_eps;
+        lp.wo_p = lw.wo_pp[f16 ? 1 : 0];
+        lp.wi_p = lw.wi_pp[f16 ? 1 : 0];
+        lp.wo2_p = lw.wo2_pp[f16 ? 1 : 0];
+        lp.wqkv_p = nx.wqkv_pp[f16 ? 1 : 0];
+        lp.n_pairs = I / 32;
+        lp.q_fp = ws.q_hi;
+        lp.k_fp = ws.k_hi;
+        lp.vt_fp = ws.vt_hi;
+        lp.r_pad = r_pad;
+        lp.row_pos = ws.row_pos;
+        const int gl = h->cfg.layer_is_global[li + 1] ? 1 : 0;
+        lp.rope_cos = h->rope_cos[gl];
+        lp.rope_sin = h->rope_sin[gl];
+        lp.max_pos = h->max_pos;
+        OP_TRY(L.begin(PK_FUSED_LAYER));
+        if (!opl::launch_layer16p(st, lp, f16, true, /*xin_t=*/li > 0, /*xout_t=*/li + 2 < h->N, (unsigned)(r_pad / ROW_BM)))
+          return fail(h, OP_ERR_UNSUPPORTED, no_kernel, H);
         OP_TRY(L.end());
         return OP_OK;
       }
@@ -1107,6 +1146,12 @@ int op_create(const op_config* cfg, op_handle** out) {
         OP_CREATE_TRY(dev_alloc(h, &lw.wi_p32, (size_t)2 * I * H));
         OP_CREATE_TRY(dev_alloc(h, &lw.wo2_p32, (size_t)H * I));
         OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_p32, 3 * HH));
+        for (int f = 0; f < (h->h16_packs ? 2 : 1); ++f) {
+          OP_CREATE_TRY(dev_alloc(h, &lw.wo_pp[f], HH));
+          OP_CREATE_TRY(dev_alloc(h, &lw.wi_pp[f], (size_t)2 * I * H));
+          OP_CREATE_TRY(dev_alloc(h, &lw.wo2_pp[f], (size_t)H * I));
+          OP_CREATE_TRY(dev_alloc(h, &lw.wqkv_pp[f], 3 * HH));
+        }
       }
     }
     h->missing.push_back(pre + "mlp_norm.weight");
@@ -1153,6 +1198,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
   u16* dst_pk = nullptr;
   u16* dst_ks = nullptr;  // additional k-streamed packing (attention Wo)
   u16* dst_p32 = nullptr; // additional packing for the 32x32x16 whole-layer kernel
+  u16* const* dst_pp = nullptr;  // the wave-pair kernel's packs ([0] bf16, [1] fp16)
   u16 *dst_f8a = nullptr, *dst_f8b = nullptr;  // "f16 + fp8" packs: chunked (a) or k-streamed fp16 (a) + e4m3 (b)
   u16 *dst_p16 = nullptr, *dst_p8 = nullptr;   // ... on the panel path: fp16 slabs + e4m3 slabs
   u16 *dst_pk_h16 = nullptr, *dst_ks_h16 = nullptr;  // kernel set "f16": the layouts of dst_pk / dst_ks with fp16 values
@@ -1200,28 +1246,28 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     } else if (t == "attn.Wqkv.weight") {
       kind = PLANES; dst_hi = lw.wqkv_hi; dst_lo = lw.wqkv_lo; expect(3 * H, H);
       dst_pk = lw.wqkv_pk; pk_mode = RE_QKV; family = OP_FAM_WQKV;
-      dst_p32 = lw.wqkv_p32; p32_mode = L32_QKV; p32_kmajor = 0;
+      dst_p32 = lw.wqkv_p32; dst_pp = lw.wqkv_pp; p32_mode = L32_QKV; p32_kmajor = 0;
       dst_f8a = lw.wqkv_f8;
       dst_p16 = lw.wqkv_p16; dst_p8 = lw.wqkv_p8;
       dst_pk_h16 = lw.wqkv_h16;
     } else if (t == "attn.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo_hi; dst_lo = lw.wo_lo; expect(H, H);
       dst_pk = nullptr; pk_mode = 101; dst_ks = lw.wo_ks; family = OP_FAM_ATTN_OUT;
-      dst_p32 = lw.wo_p32; p32_mode = L32_RESID; p32_kmajor = 1;
+      dst_p32 = lw.wo_p32; dst_pp = lw.wo_pp; p32_mode = L32_RESID; p32_kmajor = 1;
       dst_f8a = lw.wo_f16; dst_f8b = lw.wo_f8;
       dst_p16 = lw.wo_p16; dst_p8 = lw.wo_p8;
       dst_ks_h16 = lw.wo_h16;
     } else if (t == "mlp.Wi.weight") {
       kind = PLANES_GEGLU; dst_hi = lw.wi_hi; dst_lo = lw.wi_lo; expect(2 * I, H);
       dst_pk = lw.wi_pk; pk_mode = RE_GEGLU; family = OP_FAM_WI;
-      dst_p32 = lw.wi_p32; p32_mode = L32_GEGLU; p32_kmajor = 0;
+      dst_p32 = lw.wi_p32; dst_pp = lw.wi_pp; p32_mode = L32_GEGLU; p32_kmajor = 0;
       dst_f8a = lw.wi_f8;
       dst_p16 = lw.wi_p16; dst_p8 = lw.wi_p8;
       dst_pk_h16 = lw.wi_h16;
     } else if (t == "mlp.Wo.weight") {
       kind = PLANES; dst_hi = lw.wo2_hi; dst_lo = lw.wo2_lo; expect(H, I);
       dst_pk = lw.wo2_pk; pk_mode = 100; family = OP_FAM_MLP_OUT;  // k-streamed
-      dst_p32 = lw.wo2_p32; p32_mode = L32_RESID; p32_kmajor = 1;
+      dst_p32 = lw.wo2_p32; dst_pp = lw.wo2_pp; p32_mode = L32_RESID; p32_kmajor = 1;
       dst_f8a = lw.wo2_f16;
       dst_p16 = lw.wo2_p16; dst_p8 = lw.wo2_p8;
       dst_pk_h16 = lw.wo2_h16;
@@ -1361,6 +1407,9 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     if (dst_p32)  // the 32x32x16 whole-layer kernel's order (hi plane; that kernel runs only when the lo planes are zero)
       hipLaunchKernelGGL(pack_layer32_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, p32_mode, p32_kmajor, H, I,
                          dst_p32);
+    for (int f = 0; dst_pp && f < 2; ++f)  // (the modes of Layer32Pack and Layer16pPack are the same numbers)
+      if (dst_pp[f])
+        hipLaunchKernelGGL(pack_layer16p_kernel, dim3(blocks), dim3(256), 0, 0, f32, (int)d0, (int)d1, p32_mode, p32_kmajor, H, I, dst_pp[f], f);
   }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(0);

@@ -9,6 +9,7 @@
 #include "opk_attn.hip.h"
 #include "opk_common.hip.h"
 #include "opk_layer32.hip.h"
+#include "opk_layer16p.hip.h"
 #include "opk_panel.hip.h"
 #include "opk_rowgemm.hip.h"
 
@@ -76,6 +77,7 @@ bool launch_row_layer_h16(hipStream_t st, const opk::RowGemmParams& p, int ks, b
 // the same launch on the 32x32x16 shape (hidden = 256; kernel sets 1 and 2)
 bool has_layer32(int pi);
 bool launch_layer32(hipStream_t st, const opk::Layer32Params& p, int pi, bool with_qkv, unsigned grid);
+bool launch_layer16p(hipStream_t st, const opk::Layer32Params& p, bool h16, bool with_qkv, bool xin_t, bool xout_t, unsigned grid);
 // waves x kt: (8, 2) and (4, 2) full attention / long and short sequences, (4, 1) sliding window.
 // zero_p_lo (pi == 0 only): the policy has no lo(p) x hi(v) term.
 // f16_in_f8_out (kernel sets 10 / 11; pi = PI_F16_F8 / PI_F16_F8_W): the fp16 single-pass kernels of PI_F16 on fp16 q / k / v^T,

@@ -42,4 +42,27 @@ bool launch_layer32(hipStream_t st, const Layer32Params& p, int pi, bool with_qk
   }
 }
 
+// the wave-pair form (opk_layer16p.hip.h): single-pass operands, bf16 or fp16; x row-major or tiled on either side
+bool launch_layer16p(hipStream_t st, const Layer32Params& p, bool h16, bool with_qkv, bool xin_t, bool xout_t, unsigned grid) {
+  const dim3 g(grid), b(512);
+#define OPL_L16P(H16, XI, XO)                                                                   \
+  do {                                                                                          \
+    if (with_qkv) hipLaunchKernelGGL((layer16p_kernel<8, true, H16, XI, XO>), g, b, 0, st, p);  \
+    else hipLaunchKernelGGL((layer16p_kernel<8, false, H16, XI, XO>), g, b, 0, st, p);          \
+  } while (0)
+  if (h16) {
+    if (xin_t && xout_t) OPL_L16P(true, true, true);
+    else if (xin_t) OPL_L16P(true, true, false);
+    else if (xout_t) OPL_L16P(true, false, true);
+    else OPL_L16P(true, false, false);
+  } else {
+    if (xin_t && xout_t) OPL_L16P(false, true, true);
+    else if (xin_t) OPL_L16P(false, true, false);
+    else if (xout_t) OPL_L16P(false, false, true);
+    else OPL_L16P(false, false, false);
+  }
+#undef OPL_L16P
+  return true;
+}
+
 }  // namespace opl

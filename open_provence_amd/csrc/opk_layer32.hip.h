@@ -59,7 +59,7 @@ __host__ __device__ inline int l32_source_row(int mode, int T, int m, int H, int
 #ifdef OPK_PACK_KERNELS
 // hi plane only.  chunk-major: dst[T][s][lane][8], k-major: dst[s][T][lane][8]; lane = 32 hh + m holds k = 16 s + 8 hh + e
 __global__ void pack_layer32_kernel(const float* __restrict__ src, int n_rows, int K, int mode, int kmajor, int H, int I,
-                                    u16* __restrict__ dst) {
+                                    u16* __restrict__ dst, int f16 = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n_rows * K) return;
   const int KS = K / 16, NT = n_rows / 32;
@@ -75,7 +75,8 @@ __global__ void pack_layer32_kernel(const float* __restrict__ src, int n_rows, i
     T = (int)(t / KS);
   }
   const int row = l32_source_row(mode, T, l & 31, H, I);
-  dst[idx] = f2bf(src[(size_t)row * K + 16 * s + 8 * (l >> 5) + e]);
+  const float v = src[(size_t)row * K + 16 * s + 8 * (l >> 5) + e];
+  dst[idx] = f16 ? f2h(v) : f2bf(v);  // f16: the packs of the wave-pair kernel on fp16 operands (kernel set "f16")
 }
 #endif
 

@@ -33,6 +33,7 @@ _ENV_FLAGS = {
     "OPEN_PROVENCE_ATTN_XCD_GROUP": _lib.OP_FLAG_ATTN_XCD_GROUP,
     "OPEN_PROVENCE_PANEL_F8": _lib.OP_FLAG_PANEL_F8,
     "OPEN_PROVENCE_PANEL_F8_WI": _lib.OP_FLAG_PANEL_F8_WI,
+    "OPEN_PROVENCE_NO_LAYER_PAIRS": _lib.OP_FLAG_NO_LAYER_PAIRS,
 }
 
 
