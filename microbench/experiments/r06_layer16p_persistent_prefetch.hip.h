@@ -123,9 +123,26 @@ template <int N>
 __device__ __forceinline__ void lds_wait3(bf16x8& a, bf16x8& b, bf16x8& c) {
   asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
 }
+#ifndef L16P_PLAIN_QKV
+#define L16P_PLAIN_QKV 0
+#endif
+#ifndef L16P_PLAIN_X
+#define L16P_PLAIN_X 0
+#endif
 __device__ __forceinline__ void store_stream8(void* dst, const uint2& v) {
   typedef unsigned int u32x2_nt __attribute__((ext_vector_type(2)));
-  __builtin_nontemporal_store(u32x2_nt{v.x, v.y}, reinterpret_cast<u32x2_nt*>(dst));
+  if (L16P_PLAIN_QKV) *reinterpret_cast<u32x2_nt*>(dst) = u32x2_nt{v.x, v.y};
+  else __builtin_nontemporal_store(u32x2_nt{v.x, v.y}, reinterpret_cast<u32x2_nt*>(dst));
+}
+__device__ __forceinline__ void l16p_store16(void* dst, const uint4& v) {
+  typedef unsigned int u32x4_p __attribute__((ext_vector_type(4)));
+  if (L16P_PLAIN_QKV) *reinterpret_cast<u32x4_p*>(dst) = u32x4_p{v.x, v.y, v.z, v.w};
+  else store_stream16(dst, v);
+}
+__device__ __forceinline__ void l16p_store_x(float* dst, const float4& v) {
+  typedef float f32x4_p __attribute__((ext_vector_type(4)));
+  if (L16P_PLAIN_X) *reinterpret_cast<f32x4_p*>(dst) = f32x4_p{v.x, v.y, v.z, v.w};
+  else store_stream16(dst, v);
 }
 
 // A stream of NSTEPS steps of NF (2 or 3) weight fragments each; fragment j of step s is at LDS byte offset Off::at(s, j)
@@ -182,15 +199,20 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pw = wave & 3, hf = wave >> 2;
   const int n16 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 128 + pw * 32;
+  // PERSISTENT (QKV launches): block b of the grid walks row blocks b, b + gridDim.x, ...  While the q / k / v^T loop of one
+  // row block runs, the attention output of the NEXT one is fetched into LDS, and behind the loop its first two Wo stages and
+  // its residual rows are requested: the fetch that opens a row block (17 k cycles of a 140 k block: every CU of the launch
+  // pulling o and x at once) is paid by the first row block of a CU only.
+  const int n_blocks = p.r_pad >> 7;
+  int blk = blockIdx.x;
+  int m0 = blk * 128 + pw * 32;
 #ifdef OPK_TIMING
   unsigned long long opk_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, opk_wait = 0, opk_x[4] = {0, 0, 0, 0};
-  const unsigned long long opk_rt0 = wall_clock64();
+  unsigned long long opk_rt0 = wall_clock64();
 #define L16P_STAMP(i) opk_ts[i] = __builtin_readcyclecounter()
 #else
 #define L16P_STAMP(i)
 #endif
-  L16P_STAMP(0);
   if (hf) __builtin_amdgcn_s_setprio(1);  // the younger half loses every arbitration otherwise (older-first at equal priority)
 
   const int ln_i = tid < H ? tid : H - 1;
@@ -206,16 +228,16 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // ---- phase 1: acc1[i] = tile 4 hf + i of o Wo^T (K = H, 2 k-pairs per LDS stage), o fragments straight from memory ----
+  // ---- phase 1: acc1[i] = tile 4 hf + i of o Wo^T (K = H, 2 k-pairs per LDS stage) ----
   bf16x8 a[2][KP];  // Y operands of this wave's rows [row half][k-pair]: phase 1 = o (k order); afterwards LN(x), own-first order
-  const size_t rb0 = (size_t)(m0 >> 4);
-  // o pieces (row block rb0 + mf, k-pair kp) -> LDS piece O_PIECE0 + (2 pw + mf) * 8 + kp: each wave of the pair fetches the four
+  size_t rb0 = (size_t)(m0 >> 4);
+  // o pieces (row block rb + mf, k-pair kp) -> LDS piece O_PIECE0 + (2 pw + mf) * 8 + kp: each wave of the pair fetches the four
   // k-pairs of its half, both read all sixteen (the pair's rows are the same: fetched once instead of twice)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  auto request_o_piece = [&](int b, int j) {  // piece j = 0..7 of this wave's share of row block b
+    const size_t rb = (size_t)((b * 128 + pw * 32) >> 4);
     const int mf = j >> 2, kp = 4 * hf + (j & 3);
-    dma_piece(p.o_fp + (((rb0 + mf) * NT + kp) * 2) * 512, O_PIECE0 + (2 * pw + mf) * 8 + kp);
-  }
+    dma_piece(p.o_fp + (((rb + mf) * NT + kp) * 2) * 512, O_PIECE0 + (2 * pw + mf) * 8 + kp);
+  };
   auto stage_p1 = [&](int j, int stage) {  // k-pairs 2 j, 2 j + 1: 32 pieces, 4 per wave
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -223,24 +245,34 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
       dma_piece(p.wo_p + (size_t)(2 * j) * SLAB + piece * 512, stage * STAGE_PIECES + piece);
     }
   };
-  stage_p1(0, 0);
-  stage_p1(1, 1);
-  __builtin_amdgcn_sched_barrier(0);
   // residual rows of the own tiles: lane (n16, g) owns features 32 T + 8 g + 4 fh + (0..3) of rows 16 mf + n16, T = 4 hf + i
   float* xrow = p.x_io + (size_t)(m0 + n16) * H + 128 * hf + 8 * g;  // + 16 mf rows
   float* xtile = p.x_io + ((size_t)(m0 >> 5) * NT + 4 * hf) * 1024 + lane * 4;  // + i * 1024 + (2 mf + fh) * 256
   float4 xa[4][2][2];  // [tile][mf][fh]
+  auto request_x = [&](int b) {
+    const int mb = b * 128 + pw * 32;
+    const float* xr = p.x_io + (size_t)(mb + n16) * H + 128 * hf + 8 * g;
+    const float* xt = p.x_io + ((size_t)(mb >> 5) * NT + 4 * hf) * 1024 + lane * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+      for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-      for (int fh = 0; fh < 2; ++fh)
-        xa[i][mf][fh] = XIN_T ? load_stream_f4(xtile + i * 1024 + (2 * mf + fh) * 256) : load_stream_f4(xrow + (size_t)(16 * mf) * H + 32 * i + 4 * fh);
+        for (int fh = 0; fh < 2; ++fh)
+          xa[i][mf][fh] = XIN_T ? load_stream_f4(xt + i * 1024 + (2 * mf + fh) * 256) : load_stream_f4(xr + (size_t)(16 * mf) * H + 32 * i + 4 * fh);
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j) request_o_piece(blk, j);
+  stage_p1(0, 0);
+  stage_p1(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  request_x(blk);
   __builtin_amdgcn_sched_barrier(0);
   sLn[ln_i] = ln_fill0;
   sLn[H + ln_i] = ln_fill1;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (;;) {  // one row block per trip
+  L16P_STAMP(0);
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // all but the residual rows: o and the first two weight stages
   block_barrier();
 #ifdef OPK_TIMING
@@ -410,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
 #pragma unroll
         for (int fh = 0; fh < 2; ++fh) {
           const f32x4 t = acc1[i][fh][mf];
-          store_stream16(XOUT_T ? xtile + i * 1024 + (2 * mf + fh) * 256 : xrow + (size_t)(16 * mf) * H + 32 * i + 4 * fh, make_float4(t[0], t[1], t[2], t[3]));
+          l16p_store_x(XOUT_T ? xtile + i * 1024 + (2 * mf + fh) * 256 : xrow + (size_t)(16 * mf) * H + 32 * i + 4 * fh, make_float4(t[0], t[1], t[2], t[3]));
         }
   };
   const std::true_type yes_{};
@@ -483,8 +515,15 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
     opk_wait += __builtin_readcyclecounter() - w0_;
 #endif
   };
+#ifndef L16P_ACC_AGPR
+#define L16P_ACC_AGPR 0
+#endif
   auto macro = [&](int t, auto par_tag) {
     constexpr int P = decltype(par_tag)::value;  // t & 1 = LDS stage, accumulator, h buffer of h(t-2)
+    if constexpr (L16P_ACC_AGPR != 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("" : "+a"(acc1[q >> 2][(q >> 1) & 1][q & 1]));
+    }
     bf16x8 hb[2];
     hb[0] = lds_read_frag<0>(hx_pair + (uint32_t)(P * 8192));
     hb[1] = lds_read_frag<1024>(hx_pair + (uint32_t)(P * 8192));
@@ -566,6 +605,7 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
         dma_piece(p.wqkv_p + (size_t)(2 * it) * CHUNK + piece * 512, stage * STAGE_PIECES + piece);
       }
     };
+    const int nxt = blk + (int)gridDim.x < n_blocks ? blk + (int)gridDim.x : blk;  // (no next row block: the prefetches repeat this one)
     stage_pair(0, 0);
     // RoPE rows of this lane's two tokens: cos / sin [pos][16 hf + 4 g + (0..3)] (the own tile = half hf of a head's rotary pairs)
     f32x4 rc[2], rs[2];
@@ -584,9 +624,9 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
 #ifdef OPK_TIMING
     opk_x[3] = __builtin_readcyclecounter();
 #endif
-    // (the write-back of x rides on the first eight pair steps, two KiB-stores each: issued here in one burst -- every CU of
-    // the launch at once -- the sixteen stores of a wave take 7 k cycles to issue; spread, the loop is 9 k longer and the forward
-    // 2 % faster: the launch's write burst (q, k, v^T and x of every CU at once) is what both forms wait for)
+    // (spreading these sixteen stores over the q / k pair steps shortens this phase by 7 k cycles and lengthens the loop by 9 k:
+    // the write burst of a launch -- q, k, v^T and x of every CU at once -- is what both wait for)
+    store_rows();
     block_barrier();  // pair 0 everywhere; everyone has read its partner's fragments (stage 1 is free)
     L16P_STAMP(4);
 
@@ -641,8 +681,8 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
           store_stream8(st_p[mf] + 1024, st_v[2 * mf + 1]);
         }
       } else {
-        store_stream16(st_p[0], st_w[0]);
-        store_stream16(st_p[0] + 512, st_w[1]);
+        l16p_store16(st_p[0], st_w[0]);
+        l16p_store16(st_p[0] + 512, st_w[1]);
       }
     };
     auto interleave4 = [&]() {
@@ -652,10 +692,9 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
     };
-    auto iteration = [&](auto it_tag, auto first_tag, auto sw_tag, auto swp_tag) {
-      constexpr int it = decltype(it_tag)::value, cur = it & 1;
-      constexpr bool FIRST = decltype(first_tag)::value, SW = decltype(sw_tag)::value, SWP = decltype(swp_tag)::value;
-      constexpr bool XS = it < 8;  // this step carries the x pieces of own tile it / 2, row half it % 2
+    auto iteration = [&](int it, auto cur_tag, auto first_tag, auto sw_tag, auto swp_tag, auto op_tag) {
+      constexpr int cur = decltype(cur_tag)::value;
+      constexpr bool FIRST = decltype(first_tag)::value, SW = decltype(sw_tag)::value, SWP = decltype(swp_tag)::value, OP = decltype(op_tag)::value;
       stage_pair(it + 1 < N_IT ? it + 1 : it, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       const uint32_t addr[2] = {b_lo + (uint32_t)(cur * STAGE_B), b_hi + (uint32_t)(cur * STAGE_B)};
@@ -672,34 +711,58 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
         }
       });
       if constexpr (!FIRST) epilogue_store(swp_tag);
-      if constexpr (XS) {
-#pragma unroll
-        for (int fh = 0; fh < 2; ++fh) {
-          const f32x4 t = acc1[it >> 1][fh][it & 1];
-          store_stream16(XOUT_T ? xtile + (it >> 1) * 1024 + (2 * (it & 1) + fh) * 256 : xrow + (size_t)(16 * (it & 1)) * H + 32 * (it >> 1) + 4 * fh,
-                       make_float4(t[0], t[1], t[2], t[3]));
-        }
-      }
-      constexpr int N_STORES = (FIRST ? 0 : (SWP ? 4 : 2)) + (XS ? 2 : 0);
+      // the next row block's attention output, one piece per step from step 4 on (the LayerNorm exchange that shares its LDS
+      // region is over; the stages of the steps lie below it): requested BEHIND this step's stores, so that the wait below
+      // leaves it in flight -- it has until the end of the next step
+      if constexpr (OP) request_o_piece(nxt, it - 4);
+      constexpr int N_STORES = (FIRST ? 0 : (SWP ? 4 : 2)) + (OP ? 1 : 0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
       block_barrier();
     };
-    iteration(std::integral_constant<int, 0>{}, yes_, yes_, yes_);
-    static_for<N_SW - 1>([&](auto j_tag) { iteration(std::integral_constant<int, 1 + decltype(j_tag)::value>{}, no_, yes_, yes_); });
-    iteration(std::integral_constant<int, N_SW>{}, no_, no_, yes_);
-    static_for<N_IT - N_SW - 1>([&](auto j_tag) { iteration(std::integral_constant<int, N_SW + 1 + decltype(j_tag)::value>{}, no_, no_, no_); });
+    const std::integral_constant<int, 0> even{};
+    const std::integral_constant<int, 1> odd{};
+    iteration(0, even, yes_, yes_, yes_, no_);
+    iteration(1, odd, no_, yes_, yes_, no_);
+    iteration(2, even, no_, yes_, yes_, no_);
+    iteration(3, odd, no_, yes_, yes_, no_);
+    for (int i0 = 4; i0 < N_SW; i0 += 2) {
+      iteration(i0, even, no_, yes_, yes_, yes_);
+      iteration(i0 + 1, odd, no_, yes_, yes_, yes_);
+    }
+    iteration(N_SW, even, no_, no_, yes_, yes_);
+    iteration(N_SW + 1, odd, no_, no_, no_, yes_);
+    for (int i0 = N_SW + 2; i0 < N_IT; i0 += 2) {
+      iteration(i0, even, no_, no_, no_, yes_);
+      iteration(i0 + 1, odd, no_, no_, no_, yes_);
+    }
+    // both stages are free: the next row block's first two Wo stages, the last tile's epilogue, then its residual rows (LAST:
+    // the wait that opens a row block leaves exactly these sixteen loads in flight)
+    stage_p1(0, 0);
+    stage_p1(1, 1);
     static_for<8>([&](auto s_tag) { epilogue_slice(N_IT - 1, no_, s_tag, qa[1]); });
     epilogue_store(no_);
+    __builtin_amdgcn_sched_barrier(0);
+    request_x(nxt);
+    __builtin_amdgcn_sched_barrier(0);
   }
   L16P_STAMP(5);
 #ifdef OPK_TIMING
   if (threadIdx.x == 0) {
-    for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = opk_ts[i];
-    p.dbg[(size_t)blockIdx.x * 16 + 8] = opk_wait;
-    for (int i = 0; i < 4; ++i) p.dbg[(size_t)blockIdx.x * 16 + 11 + i] = opk_x[i];
-    p.dbg[(size_t)blockIdx.x * 16 + 15] = wall_clock64() - opk_rt0;
+    for (int i = 0; i < 8; ++i) p.dbg[(size_t)blk * 16 + i] = opk_ts[i];
+    p.dbg[(size_t)blk * 16 + 8] = opk_wait;
+    for (int i = 0; i < 4; ++i) p.dbg[(size_t)blk * 16 + 11 + i] = opk_x[i];
+    p.dbg[(size_t)blk * 16 + 15] = wall_clock64() - opk_rt0;
+    opk_wait = 0;
+    opk_rt0 = wall_clock64();
   }
 #endif
+  if (!QKV || blk + (int)gridDim.x >= n_blocks) break;
+  blk += (int)gridDim.x;
+  m0 = blk * 128 + pw * 32;
+  rb0 = (size_t)(m0 >> 4);
+  xrow = p.x_io + (size_t)(m0 + n16) * H + 128 * hf + 8 * g;
+  xtile = p.x_io + ((size_t)(m0 >> 5) * NT + 4 * hf) * 1024 + lane * 4;
+  }  // row blocks
 #undef L16P_STAMP
 }
 

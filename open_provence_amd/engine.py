@@ -436,6 +436,61 @@ class HipEncoder:
             self._maybe_audit(ids, cu_seqlens, cu_host, n_seqs, total, int(max_seqlen), prune, rank, keep_prob, ws, stream)
         return prune, rank
 
+    # -- the audit under a process group: ONE verdict for all ranks (sharding.collective_audit) -----------------------
+    @property
+    def audit_pending(self) -> bool:
+        """True while a kernel set chosen on the library's synthetic batch has not seen real rows yet."""
+
+        return bool(self.__dict__.get("_audit_pending"))
+
+    def audit_rows(self, rows: "Sequence[Sequence[int]]") -> "bool | None":
+        """The first-real-batch audit as an explicit call that only MEASURES: ``rows`` through the calibrated set and through the
+        reference set, ``calibration["audit"]`` filled, the pending flag cleared; the kernel set is left where it is (the
+        caller -- ``sharding.collective_audit`` -- combines the ranks' verdicts and reverts all of them or none).  Returns the
+        verdict, or None when there is nothing to audit (no calibrated set pending, or fewer than 64 tokens)."""
+
+        if not self.audit_pending:
+            return None
+        ids_np, cu_np, max_len = pack_rows(rows)
+        total, n_seqs = int(cu_np[-1]), len(cu_np) - 1
+        if total < 64:
+            return None
+        self.check_ids(ids_np)
+        ids = torch.from_numpy(ids_np).to(self.device)
+        cu = torch.from_numpy(cu_np).to(self.device)
+        cal = self.calibration or {}
+        chosen, reference = cal.get("chosen_set"), cal.get("reference_set")
+        self.__dict__["_audit_pending"] = False
+        if not chosen or chosen == cal.get("default_set") or reference not in _lib.KERNEL_SET_IDS:
+            return None
+        outs = {}
+        for name in (chosen, reference):
+            _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(_lib.KERNEL_SET_IDS[name])), "op_select_kernel_set")
+            outs[name] = self.forward_packed(ids, cu, cu_np, max_len)
+        _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(_lib.KERNEL_SET_IDS[chosen])), "op_select_kernel_set")
+        self.__dict__["_f8_active"] = None
+        err = float(torch.maximum((outs[chosen][0] - outs[reference][0]).abs().max(), (outs[chosen][1] - outs[reference][1]).abs().max()).item())
+        bound = float(cal.get("tolerance", DEFAULT_CALIBRATION_TOLERANCE)) * float(getattr(self, "audit_factor", 3.0))
+        passed = err == err and err <= bound
+        cal["audit"] = {"tokens": total, "rows": n_seqs, "max_abs_err": err, "bound": bound, "passed": bool(passed), "collective": True}
+        return bool(passed)
+
+    def revert_to_default(self, reason: str) -> str:
+        """Back to the default selection of ``op_weights_ready`` for good (what a failed audit does), with a warning."""
+
+        import warnings
+
+        before = self.effective_policy()["kernel_set"]
+        self.select_kernel_set("auto")
+        after = self.effective_policy()["kernel_set"]
+        if self.calibration is not None:
+            self.calibration["chosen_set"] = after
+            self.calibration["reverted"] = reason
+        if after != before:
+            warnings.warn(f"open_provence_amd: kernel set {before!r} dropped ({reason}); this model runs on {after!r} from now on.",
+                          RuntimeWarning, stacklevel=3)
+        return after
+
     def _maybe_audit(self, ids, cu_seqlens, cu_host, n_seqs, total, max_seqlen, prune, rank, keep_prob, ws, stream) -> None:
         """The first-real-batch audit of a synthetically calibrated kernel set, from EITHER forward entry point
         (``forward_packed`` / ``forward_packed_on``).  Skipped -- and left pending -- for batches under 64 tokens, while hidden
@@ -443,6 +498,8 @@ class HipEncoder:
         handle's kernel set in the middle of the forward)."""
 
         if not self.__dict__.get("_audit_pending") or total < 64 or self._capture is not None:
+            return
+        if getattr(self, "audit_collective", False):  # under a process group the ranks audit TOGETHER (sharding.collective_audit)
             return
         if torch.cuda.is_current_stream_capturing():
             return

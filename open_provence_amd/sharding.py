@@ -229,3 +229,54 @@ def sharded_forward(
     mine = shards[me]
     prune, rank_logits, _cu = forward_rows([list(rows[i]) for i in mine])
     return gather_row_outputs(prune, rank_logits, mine, lengths, shards, dst=dst, group=group)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# One arithmetic per job (round 6).  Every rank chooses its kernel set at load time from the same weights on the same
+# synthetic batch with deterministic kernels -- the same choice -- but the AUDIT of that choice looks at real rows, and a
+# rank's shard is not its neighbour's: left to themselves, a rank that failed alone went back to the default selection
+# alone (outputs depending on how the batch was cut, and one rank 1.8 x slower inside a synchronous gather).  Under a
+# process group the ranks therefore (a) compare their load-time choices once, (b) audit the SAME rows and combine the
+# verdicts with MIN: all keep the calibrated set or all leave it.  What is gathered afterwards: standalone.py:3075-3092.
+# ``encoder`` = HipEncoder, or anything with effective_policy() / audit_pending / audit_rows(rows) / revert_to_default(reason).
+# ------------------------------------------------------------------------------------------------------------------
+def _flag_device(group) -> "torch.device":
+    import torch.distributed as dist
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def agree_on_kernel_set(encoder, group=None) -> str:
+    """Collective, once per attach: the ranks' kernel sets are compared; any difference sends EVERY rank to the default
+    selection.  Returns the set all ranks run afterwards."""
+
+    import torch.distributed as dist
+
+    mine = encoder.effective_policy()["kernel_set"]
+    world = dist.get_world_size(group)
+    if world <= 1:
+        return mine
+    names: list = [None] * world
+    dist.all_gather_object(names, mine, group=group)
+    if any(n != names[0] for n in names):
+        return encoder.revert_to_default(f"the ranks of the process group chose different kernel sets at load time: {names}")
+    return mine
+
+
+def collective_audit(encoder, rows, group=None) -> "bool | None":
+    """Collective: every rank audits the SAME ``rows`` (a sample every rank has: the head of the request) and the verdicts are
+    combined with MIN -- one failing rank sends every rank to the default selection.  No-op (and no collective) when no
+    calibrated set is pending: that state is the same on every rank.  Returns the common verdict (None: nothing audited)."""
+
+    import torch.distributed as dist
+
+    if not encoder.audit_pending:
+        return None
+    verdict = encoder.audit_rows(rows)
+    flag = torch.tensor([0 if verdict is False else 1], dtype=torch.int32, device=_flag_device(group))
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        encoder.revert_to_default("the first-batch audit failed on at least one rank of the process group")
+        return False
+    return None if verdict is None else True

@@ -164,6 +164,90 @@ def refinit_state_dict(dims: EncoderDims, seed: int, *, initializer_range: float
     return out
 
 
+def _unit_stream(seed: int, tag: int, count: int) -> np.ndarray:
+    """float64 uniforms in (0, 1) from the counter-based stream (values depend on (seed, tag, index) only)."""
+
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([np.uint64(seed) * np.uint64(0x2000005) + np.uint64(tag)], dtype=np.uint64))[0]
+        bits = _splitmix64(np.arange(count, dtype=np.uint64) + base) >> np.uint64(11)
+    return (bits.astype(np.float64) + 0.5) * (1.0 / (1 << 53))
+
+
+def trained_like_state_dict(dims: EncoderDims, seed: int, *, row_sigma: float = 0.5, gain_range: tuple[float, float] = (0.1, 10.0),
+                            n_outlier_channels: int = 4, outlier_range: tuple[float, float] = (30.0, 100.0),
+                            zipf_alpha: float = 0.35) -> dict[str, torch.Tensor]:
+    """A PROXY for a trained checkpoint (none can be downloaded here): :func:`refinit_state_dict`, then the statistics that
+    set a trained encoder apart from a freshly initialised one and that decide which arithmetic a checkpoint can take
+    (what is mirrored is the load-time choice of standalone.py:219-244, 1631-1642):
+
+    * heavy-tailed weights: every row of a GEMM weight scaled by a log-normal factor exp(row_sigma * z), z ~ N(0, 1);
+    * LayerNorm gains log-uniform in ``gain_range`` instead of 1;
+    * outlier hidden channels: ``n_outlier_channels`` of the hidden size carry activations 30-100x the others -- the rows of
+      every output projection (attention Wo, MLP Wo) and the embedding columns of those channels are scaled by a factor
+      log-uniform in ``outlier_range`` (the outlier-feature pattern of trained transformer encoders);
+    * token embeddings with Zipf-distributed norms: row r of a random permutation scaled by (1 + r) ** -zipf_alpha
+      (frequent tokens have large embeddings), renormalised to the initialisation's mean square.
+
+    Deterministic in ``(dims, seed)``.  Not a claim about any published checkpoint: a stress proxy between the reference
+    initialisation (:func:`refinit_state_dict`) and the O(1) worst case (:func:`synth_state_dict`)."""
+
+    H = dims.hidden_size
+    out = refinit_state_dict(dims, seed)
+    u = _unit_stream(seed, 9001, n_outlier_channels * 2)
+    channels = sorted({int(u[i] * H) % H for i in range(n_outlier_channels)})
+    factors = {c: float(np.exp(np.log(outlier_range[0]) + u[n_outlier_channels + i] * np.log(outlier_range[1] / outlier_range[0])))
+               for i, c in enumerate(channels)}
+    for tag, (name, tensor) in enumerate(list(out.items())):
+        t = tensor.clone()
+        if name.endswith("norm.weight"):
+            g = _unit_stream(seed, 7000 + tag, t.numel())
+            t = torch.from_numpy(np.exp(np.log(gain_range[0]) + g * np.log(gain_range[1] / gain_range[0])).astype(np.float32)).reshape(t.shape)
+        elif t.ndim == 2 and name.endswith(("Wqkv.weight", "Wi.weight", "attn.Wo.weight", "mlp.Wo.weight", "dense.weight")):
+            z = _unit_stream(seed, 8000 + tag, 2 * t.shape[0])
+            normal = np.sqrt(-2.0 * np.log(z[: t.shape[0]])) * np.cos(2.0 * np.pi * z[t.shape[0]:])
+            t = t * torch.from_numpy(np.exp(row_sigma * normal).astype(np.float32))[:, None]
+            if name.endswith(("attn.Wo.weight", "mlp.Wo.weight")):  # output feature c = row c
+                for c, f in factors.items():
+                    t[c] *= f
+        elif name.endswith("tok_embeddings.weight"):
+            V = t.shape[0]
+            order = np.argsort(_unit_stream(seed, 8500, V))  # a random permutation: rank of every token
+            scale = (1.0 + np.arange(V, dtype=np.float64)) ** (-zipf_alpha)
+            scale *= 1.0 / np.sqrt(np.mean(scale ** 2))
+            per_row = np.empty(V, dtype=np.float32)
+            per_row[order] = scale.astype(np.float32)
+            t = t * torch.from_numpy(per_row)[:, None]
+            for c, f in factors.items():
+                t[:, c] *= f
+        out[name] = t.contiguous()
+    return out
+
+
+def zipf_token_rows(dims: EncoderDims, n_rows: int, seq_len: int, seed: int, *, alpha: float = 1.1) -> list[list[int]]:
+    """Rows shaped like :func:`synth_pair_batch`'s ([CLS] query [SEP] context [SEP]) whose token ids follow a Zipf law over a
+    random permutation of the vocabulary (a few ids make up most of the text) instead of the uniform ids of the other
+    synthetic batches: calibration / audit rows for :func:`trained_like_state_dict`."""
+
+    V = dims.vocab_size
+    margin = 1000 if V > 4000 else max(4, V // 8)
+    lo, n_vocab = margin, V - 2 * margin
+    weights = (1.0 + np.arange(n_vocab, dtype=np.float64)) ** (-alpha)
+    cdf = np.cumsum(weights / weights.sum())
+    perm = np.argsort(_unit_stream(seed, 8600, n_vocab))
+
+    def draw(tag: int, count: int) -> list[int]:
+        u = _unit_stream(seed, tag, count)
+        return [int(t) for t in lo + perm[np.minimum(np.searchsorted(cdf, u), n_vocab - 1)]]
+
+    cls_id = dims.cls_token_id if dims.cls_token_id is not None else 1
+    sep_id = dims.sep_token_id if dims.sep_token_id is not None else 2
+    query_tokens = 24
+    if seq_len < query_tokens + 4:
+        raise ValueError("seq_len too short")
+    query = draw(8699, query_tokens)  # ONE query shared by all contexts (SURVEY.md section 8d)
+    return [[cls_id] + query + [sep_id] + draw(8700 + r, seq_len - query_tokens - 3) + [sep_id] for r in range(n_rows)]
+
+
 def synth_pair_batch(
     dims: EncoderDims,
     n_pairs: int,

@@ -1,2 +1,1 @@
-python scripts/pair_kernel_debug.py 2>&1 | tail -6
-python scripts/pair_kernel_check.py 2>&1 | tail -8
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15

@@ -57,7 +57,11 @@ def test_bench_json_line_contract():
         assert {"prune_sum", "prune_abs_sum", "rank_sum"} <= set(rec["output_checksum"])
         # (8 pairs: no stored checksum for this workload; the default workloads compare with tests/golden/bench_checksums.json)
         assert rec["output_checksum"]["stored"].startswith("none")
-    assert roof["avg_launch_ms_source"] == "event_bracketed" and roof["frac_in_step"] > 0
+    # round 6: `frac` is the in-step figure (the bracketed one is secondary), the config says what was REQUESTED under that name,
+    # and the untimed clock-settling steps behind the W warm-up steps are on the record
+    assert roof["avg_launch_ms_source"] == "in_step" and roof["frac_in_step"] == roof["frac"] and roof["frac_bracketed"] > 0
+    assert roof["avg_launch_ms_bracketed"] > 0 and "requested_policy" in line["config"] and "precision" not in line["config"]
+    assert line["config"]["clock_settling"]["extra_steps"] >= 3
     # the panel path (base dims) as a sub-record, both checkpoint dtypes: calibrated (default), what op_weights_ready selects
     # without calibration, and the calibration at 2e-4 (which takes the single-pass fp16 set at this depth)
     base = line["base_model"]

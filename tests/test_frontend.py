@@ -147,6 +147,12 @@ def test_process_routes_large_requests_through_replicas_when_the_environment_ask
         got = model.process(**_request())
         front = model.__dict__.get("_host_front_end")
         assert front is not None and front.world == 2 and front.last_trace["rows"] > 0  # the replicas' forwards went through here
+        # through the replicas `timing` used to read preprocess = inference = 0 with the whole call under
+        # postprocess -- the fields the reference's harness publishes (scripts/eval_datasets.py:225, 359-365).  They now come
+        # from the owner's time line of the request: non-zero, and together no more than the call
+        timing = got["timing"]
+        assert timing["preprocess_seconds"] > 0 and timing["inference_seconds"] > 0 and timing["postprocess_seconds"] >= 0, timing
+        assert timing["preprocess_seconds"] + timing["inference_seconds"] + timing["postprocess_seconds"] <= timing["total_seconds"] + 1e-6, timing
         small = dict(_request(), context=_request()["context"][:3])
         assert model.process(**small)["pruned_context"] == plain_model.process(**small)["pruned_context"]
         local = dict(_request(), sentence_splitter=lambda text: period_splitter(text))  # cannot be pickled

@@ -410,3 +410,47 @@ def test_overflow_of_the_f8_sets_falls_back_to_the_bf16_sets_instead_of_failing(
                 got = model.get_raw_predictions("what is gamma", [text[:200]])
                 assert got.ranking_score == want_raw.ranking_score and np.array_equal(got.pruning_probs, want_raw.pruning_probs)
         assert not model.encoder.f8_active()
+
+
+NO_LAYER_PAIRS = 8192  # OP_FLAG_NO_LAYER_PAIRS: keep the 8 waves x 16 rows whole-layer kernel on the single-pass sets
+
+
+@pytest.mark.parametrize("kernel_set", ["f16", "bf16"])
+def test_wave_pair_layer_kernel_matches_the_8x16_kernel_and_the_oracle(kernel_set):
+    """Round 6: on the single-pass kernel sets a batch of more than one 128-row block per CU runs its whole-layer launches
+    on the wave-pair kernel (opk_layer16p.hip.h: two waves per SIMD share a 32-row tile and split the output features; other
+    weight packs, LayerNorm statistics combined from two halves, h and LN(x) exchanged through LDS, the residual stream
+    tiled between launches).  Same terms as the 8 x 16 kernel it replaces: equal to it up to the summation order (fp16:
+    <= 6e-5 on logits of magnitude 7; bf16: its own rounding noise), bit-identical from run to run, and -- fp16 on
+    reference-initialised weights -- within the calibration's bound of the fp32 oracle on ragged rows."""
+
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.packing import pack_rows
+    from open_provence_amd.synthetic import named_dims, pad_rows, refinit_state_dict, synth_pair_batch
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = named_dims("xsmall")
+    state = refinit_state_dict(dims, seed=21)
+    rows = [r[: 29 + (i * 53) % 480] for i, r in enumerate(synth_pair_batch(dims, 640, 512, seed=9))]  # ~165 k rows: > 256 blocks
+    ids_np, cu_np, max_len = pack_rows(rows)
+    ids, cu = torch.from_numpy(ids_np).cuda(), torch.from_numpy(cu_np).cuda()
+    outs = {}
+    for label, flags in (("pairs", 0), ("pairs again", 0), ("8x16", NO_LAYER_PAIRS)):
+        enc = HipEncoder(dims, device="cuda:0", flags=flags)
+        enc.load_state_dict(state, calibrate=False, kernel_set=kernel_set)
+        prune, rank = enc.forward_packed(ids, cu, cu_np, max_len)
+        torch.cuda.synchronize()
+        outs[label] = (prune.cpu().numpy(), rank.cpu().numpy())
+        enc.close()
+    assert np.array_equal(outs["pairs"][0], outs["pairs again"][0]) and np.array_equal(outs["pairs"][1], outs["pairs again"][1])
+    tol = 6e-5 if kernel_set == "f16" else 6e-4
+    assert np.abs(outs["pairs"][0] - outs["8x16"][0]).max() < tol and np.abs(outs["pairs"][1] - outs["8x16"][1]).max() < tol
+    if kernel_set == "f16":
+        sample = list(range(0, len(rows), 40))  # 16 ragged rows through the oracle
+        pad_ids, mask = pad_rows([rows[i] for i in sample])
+        ref = oracle_forward(state, dims, pad_ids, mask)
+        rp, rr = ref.pruning_logits.numpy(), ref.ranking_logits.numpy()
+        for j, i in enumerate(sample):
+            a, b = int(cu_np[i]), int(cu_np[i + 1])
+            assert np.abs(outs["pairs"][0][a:b] - rp[j, : b - a]).max() < 3e-4, (i, b - a)
+            assert np.abs(outs["pairs"][1][i] - rr[j]).max() < 3e-4

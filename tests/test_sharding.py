@@ -481,3 +481,69 @@ def test_bench_exchange_lands_in_row_order_for_unequal_rows(tmp_path, world, n_p
             assert float(part["rank"][k, 0]) == float(sum(rows_all[row]) % 1013), row
             seen.append(row)
     assert sorted(seen) == list(range(len(rows_all)))  # every row exactly once across the launch sequences
+
+
+class _FakeEncoder:
+    """Stand-in for HipEncoder's kernel-set / audit surface (test infrastructure): what sharding.agree_on_kernel_set and
+    sharding.collective_audit talk to."""
+
+    def __init__(self, chosen, audit_verdict, default="f16-f8-w"):
+        self.kernel_set, self.default, self.verdict, self.audit_pending = chosen, default, audit_verdict, chosen != default
+        self.audited_rows, self.reverted = None, None
+
+    def effective_policy(self):
+        return {"kernel_set": self.kernel_set}
+
+    def audit_rows(self, rows):
+        self.audited_rows, self.audit_pending = [list(r) for r in rows], False
+        return self.verdict
+
+    def revert_to_default(self, reason):
+        self.kernel_set, self.reverted, self.audit_pending = self.default, reason, False
+        return self.kernel_set
+
+
+def _one_arithmetic_worker(rank, world, port, case, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from open_provence_amd.sharding import agree_on_kernel_set, collective_audit
+
+        rows = [[1, 2, 3, 4] * 20, [5, 6] * 40]
+        if case == "audit fails on one rank":
+            enc = _FakeEncoder("f16", audit_verdict=(rank != world - 1))
+        elif case == "load-time choices differ":
+            enc = _FakeEncoder("f16" if rank == 0 else "bf16", audit_verdict=True)
+        else:
+            enc = _FakeEncoder("f16", audit_verdict=True)
+        agreed = agree_on_kernel_set(enc, None)
+        verdict = collective_audit(enc, rows, None)
+        again = collective_audit(enc, rows, None)  # nothing pending any more: no collective, no audit
+        torch.save({"agreed": agreed, "verdict": verdict, "again": again, "set": enc.effective_policy()["kernel_set"],
+                    "audited": enc.audited_rows, "reverted": enc.reverted}, f"{out_path}.{rank}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["all pass", "audit fails on one rank", "load-time choices differ"])
+def test_every_rank_of_a_job_runs_the_same_kernel_set(tmp_path, case):
+    """each rank used to audit its own shard, and a rank that failed alone went back to the
+    default selection alone -- outputs depending on how the batch was cut, one rank 1.8 x slower inside a synchronous
+    gather.  Now the ranks compare their load-time choices once and audit the SAME rows with the verdicts combined by MIN:
+    one failing rank (or one differing choice) sends EVERY rank to the default selection."""
+
+    world, port, out = 2, _free_port(), str(tmp_path / "out")
+    mp.spawn(_one_arithmetic_worker, args=(world, port, case, out), nprocs=world, join=True)
+    got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    assert got[0]["set"] == got[1]["set"]
+    assert all(g["again"] is None for g in got)
+    if case == "all pass":
+        assert all(g["set"] == "f16" and g["verdict"] is True and g["reverted"] is None for g in got)
+        assert got[0]["audited"] == got[1]["audited"] and got[0]["audited"] is not None  # the same rows on every rank
+    elif case == "audit fails on one rank":
+        assert all(g["set"] == "f16-f8-w" and g["verdict"] is False and "audit failed" in g["reverted"] for g in got)
+    else:
+        assert all(g["agreed"] == "f16-f8-w" and g["set"] == "f16-f8-w" and "different kernel sets" in g["reverted"] for g in got)
+        assert all(g["audited"] is None for g in got)  # (reverted at attach time: nothing left to audit)
