@@ -829,7 +829,7 @@ def main() -> None:
         enc_t = HipEncoder(dims, device=device, precision=args.precision, chunk_rows=args.chunk_rows or None)
         with warnings.catch_warnings(record=True) as caught_t:
             warnings.simplefilter("always")
-            enc_t.load_state_dict(trained_like_state_dict(dims, seed=7), calibrate=calibrate)
+            enc_t.load_state_dict(trained_like_state_dict(dims, seed=7, outlier_range=(5.0, 20.0)), calibrate=calibrate)
             cal_t = dict(enc_t.calibration or {})
             ids_t_np, cu_t_np, max_t = pack_rows(rows_t)
             ids_t, cu_t = torch.from_numpy(ids_t_np).to(device), torch.from_numpy(cu_t_np).to(device)
@@ -873,8 +873,10 @@ def main() -> None:
                  "warnings": [str(w.message)[:120] for w in caught_t],
                  "whole_forward_frac": n_pairs_rank / dt_t2 * flops_pair / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                  "kernel_ms_per_forward": {k: v["total_ms"] / prof_steps for k, v in prof_t.items()},
-                 "what": "synthetic.trained_like_state_dict (heavy-tailed rows, LayerNorm gains 0.1-10, outlier channels 30-100 x, Zipf "
-                         "embedding norms) on Zipf-distributed token ids: a proxy, not a published checkpoint"}
+                 "what": "synthetic.trained_like_state_dict (heavy-tailed rows, LayerNorm gains 0.1-10, outlier channels 5-20 x, Zipf "
+                         "embedding norms) on Zipf-distributed token ids: a proxy, not a published checkpoint.  Single-pass fp16 is refused "
+                         "on it (4e-3 on the calibration batch); at outliers of 30-100 x the fp32 reference itself is 1.2e-3 from fp64 and "
+                         "the calibration escalates to the (hi, lo) bf16 kernels (tests/test_gpu_calibration.py, scripts/trained_like_probe.py)"}
         dom_t = max(prof_t.items(), key=lambda kv: kv[1]["total_ms"])[0]
         if dom_t in flops_per_forward:
             lpf_t = prof_t[dom_t]["launches"] / prof_steps
@@ -933,6 +935,23 @@ def main() -> None:
                 rec["kernel_ms_per_forward"] = {k: v["total_ms"] / 2 for k, v in prof_b.items()}
                 rec["output_checksum"] = output_checksum(out_b[0], out_b[1], checksum_key("base", f"{args.pairs}x{args.seq_len}", args.init, wdt)
                                                          if (args.precision == "bf16x3" and kernel_set is None and tol is calibrate) else None)
+            if profile_it and wdt == "fp32" and args.pairs >= 128:
+                # BASELINE config 3's PER-GPU shape (512 pairs x 512 over 8 GPUs = 64 pairs per GPU): what one rank of that run
+                # computes per step (its gather moves 4 B per fragment + the ranking logits of 64 rows: KB); same encoder
+                rows_c3 = rows_b[:64]
+                i_c3_np, c_c3_np, m_c3 = pack_rows(rows_c3)
+                i_c3, c_c3 = torch.from_numpy(i_c3_np).to(device), torch.from_numpy(c_c3_np).to(device)
+                for _ in range(3):
+                    enc_b.forward_packed(i_c3, c_c3, c_c3_np, m_c3)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                for _ in range(base_steps * 2):
+                    enc_b.forward_packed(i_c3, c_c3, c_c3_np, m_c3)
+                torch.cuda.synchronize(device)
+                dt_c3 = (time.perf_counter() - t1) / (base_steps * 2)
+                rec["config3_per_gpu_shape"] = {"pairs": 64, "seq_len": args.seq_len, "value": 64 / dt_c3, "unit": "pairs/s per GPU", "ms_per_step": dt_c3 * 1e3,
+                                                "whole_forward_frac": 64 / dt_c3 * flops_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                                "what": "BASELINE configs[2] = 512 pairs x 512 on 8 GPUs: the 64 pairs one rank runs per step (N > 1 itself is the driver's to measure)"}
             enc_b.close()
             return rec
 

@@ -226,8 +226,8 @@ typedef struct op_calibration {
   int32_t n_rows, n_tokens; /* the calibration batch */
   float default_err;        /* the default set's own difference to the reference outputs on that batch.  It is not held to
                              * the tolerance (it is the set the parity tests stand on), but when it is NOT FINITE -- an
-                             * activation beyond fp16's range on sets 3 - 6 -- and no candidate passes, the reference set is
-                             * chosen right away instead of at the first forward that overflows */
+                             * activation beyond fp16's range on sets 3 - 6 -- or beyond 10 x tolerance, and no candidate
+                             * passes, the reference set is chosen right away (ABI 8: the bound on a finite default_err) */
   uint32_t flags;           /* IN: OP_CAL_* bits */
 } op_calibration;
 #define OP_CAL_FULL_REPORT 1u /* measure every candidate (the report lists them all); default: cheapest first, stop at the first that holds */

@@ -204,6 +204,15 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_piece0 + lane * 8),
                                      (__attribute__((address_space(3))) void*)(&sW[dst_piece * 512]), 16, 0, 0);
   };
+  // Weight stages by buffer_load ... lds: one resource per weight tensor, the piece's byte offset as the SCALAR offset, lane * 16
+  // as the (constant) vector offset -- per DMA one s_add and the M0 write, where the global_load_lds form pays a 64-bit scalar
+  // add / addc on the pointer (36 of ~300 non-MFMA instructions per two MLP steps)
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto weight_rsrc = [](const u16* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(base), 0, 0x7fffffff, 0x00020000); };
+  const __amdgpu_buffer_rsrc_t rs_wo = weight_rsrc(p.wo_p), rs_wi = weight_rsrc(p.wi_p), rs_wo2 = weight_rsrc(p.wo2_p), rs_qkv = weight_rsrc(p.wqkv_p);
+  auto dma_weight = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, int dst_piece) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(&sW[dst_piece * 512]), 16, (int)lane16, (int)byte_off, 0, 0);
+  };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ---- phase 1: acc1[i] = tile 4 hf + i of o Wo^T (K = H, 2 k-pairs per LDS stage), o fragments straight from memory ----
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int piece = wave + 8 * u;
-      dma_piece(p.wo_p + (size_t)(2 * j) * SLAB + piece * 512, stage * STAGE_PIECES + piece);
+      dma_weight(rs_wo, (uint32_t)(((2 * j) * SLAB + piece * 512) * 2), stage * STAGE_PIECES + piece);
     }
   };
   stage_p1(0, 0);
@@ -293,8 +302,8 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
     const int tc = t < n_it ? t : n_it - 1;
     const int ts = t >= 2 ? (t - 2 < n_it ? t - 2 : n_it - 1) : 0;
     const int piece = wave + 8 * u;
-    const u16* src = u < 4 ? p.wi_p + (size_t)(2 * tc) * CHUNK + piece * 512 : p.wo2_p + (size_t)ts * SLAB + (piece - 32) * 512;
-    dma_piece(src, stage * STAGE_PIECES + piece);
+    if constexpr (u < 4) dma_weight(rs_wi, (uint32_t)(((2 * tc) * CHUNK + piece * 512) * 2), stage * STAGE_PIECES + piece);
+    else dma_weight(rs_wo2, (uint32_t)((ts * SLAB + (piece - 32) * 512) * 2), stage * STAGE_PIECES + piece);
   };
   static_for<6>([&](auto u) { stage_piece(u, 0, 0); });  // flies during the last phase-1 stage and the LayerNorm
   p1_stage(std::integral_constant<int, 3>{});
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void layer16p_kernel(Layer32Params p) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int piece = wave + 8 * u;
-        dma_piece(p.wqkv_p + (size_t)(2 * it) * CHUNK + piece * 512, stage * STAGE_PIECES + piece);
+        dma_weight(rs_qkv, (uint32_t)(((2 * it) * CHUNK + piece * 512) * 2), stage * STAGE_PIECES + piece);
       }
     };
     stage_pair(0, 0);

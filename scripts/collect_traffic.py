@@ -19,6 +19,9 @@ import sys
 from collections import defaultdict
 
 KIND = [
+    (r"layer16p_kernel", "fused_layer_attnout_mlp_qkv"),  # round 6: the wave-pair whole-layer kernel (per-launch average of ITS launches:
+    # the last layer's launch stays on rowgemm_kernel and is reported under "fused_layer_last" so that it does not dilute the average)
+    (r"rowgemm_kernel<\d+, 1, 4,", "fused_layer_last"),
     (r"rowgemm_kernel<\d+, [01], 4,", "fused_layer_attnout_mlp_qkv"),
     (r"rowgemm_kernel<\d+, 2, 3,", "fused_attnout_ln_wi_geglu"),
     (r"rowgemm_kernel<\d+, 0, 3,", "fused_mlpout_ln_qkv_rope"),

@@ -27,3 +27,28 @@ for tag in sys.argv[1:]:
         traffic.update(json.load(open(part)))
     print("published", tag)
 json.dump(traffic, open(traffic_path, "w"), indent=1, sort_keys=True)
+
+# per-launch averages of the dominant kernels in the committed kernel traces: what bench.py prints beside its own in-step
+# figure (roofline.rocprofv3_avg_launch_ms) -- key = "<kernel kind>|<model>|<shape>|<kernel set>" as roofline.traffic_key
+import csv
+import re
+
+avgs_path = os.path.join(PROFILES, "rocprof_launch_avgs.json")
+avgs = json.load(open(avgs_path)) if os.path.exists(avgs_path) else {}
+KINDS = [(r"layer16p_kernel", "fused_layer_attnout_mlp_qkv"), (r"rowgemm_kernel<\d+, 0, 4,", "fused_layer_attnout_mlp_qkv")]
+for tag in sys.argv[1:]:
+    bench_json = os.path.join(PROFILES, f"{tag}_bench_under_rocprofv3.json")
+    stats_csv = os.path.join(PROFILES, f"{tag}_kernel_stats.csv")
+    if not (os.path.exists(bench_json) and os.path.exists(stats_csv)):
+        continue
+    line = json.load(open(bench_json))
+    key_tail = line["roofline"]["traffic_key"].split("|", 1)[1]
+    rows = list(csv.DictReader(open(stats_csv)))
+    for pat, kind in KINDS:
+        hit = [r for r in rows if re.search(pat, r.get("Name", ""))]
+        if hit:
+            calls = sum(int(r["Calls"]) for r in hit)
+            total = sum(float(r["TotalDurationNs"]) for r in hit)
+            avgs[f"{kind}|{key_tail}"] = {"avg_ms": total / calls / 1e6, "calls": calls, "source": f"profiles/{tag}_kernel_stats.csv ({pat})"}
+            break
+json.dump(avgs, open(avgs_path, "w"), indent=1, sort_keys=True)

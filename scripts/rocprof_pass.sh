@@ -23,5 +23,5 @@ PY
 echo "workload key: $KEY"
 python scripts/collect_traffic.py $OUT/pmc_fetch $OUT/pmc_write "$KEY" $OUT/pmc_traffic.json
 head -16 $OUT/summary.txt
-grep -E "rowgemm|attn_fp|kstream|panel" $OUT/summary.txt | grep -E "MFMA|FETCH|WRITE" | cut -c1-330
+grep -E "layer16p|rowgemm|attn_fp|kstream|panel" $OUT/summary.txt | grep -E "MFMA|FETCH|WRITE" | cut -c1-330
 find $OUT -name "*.csv" -size +6M -delete

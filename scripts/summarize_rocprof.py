@@ -12,7 +12,7 @@ root = sys.argv[1]
 
 def short(name: str) -> str:
     name = name.replace("void ", "")
-    for key in ("rowgemm_kernel", "kstream_gemm_kernel", "attn_fp_kernel", "panel_gemm_kernel", "panel_qkv_kernel", "gemm_kernel", "attn_kernel", "embed_ln_kernel",
+    for key in ("layer16p_kernel", "rowgemm_kernel", "kstream_gemm_kernel", "attn_fp_kernel", "panel_gemm_kernel", "panel_qkv_kernel", "gemm_kernel", "attn_kernel", "embed_ln_kernel",
                 "ln_kernel", "final_ln_prune_kernel", "rank_head_kernel", "row_map_kernel", "seq_offsets_kernel",
                 "capture_rows_kernel"):
         if key in name:

@@ -37,18 +37,10 @@ def _bench_setup(weights: str):
     return dims, state, rows, enc
 
 
-def _oracle(state, dims, rows):
-    from open_provence_amd.synthetic import pad_rows
-    from oracle.modernbert_oracle import oracle_forward
+def _oracle(tag, state, dims, rows):
+    from oracle_cache import oracle_rows  # the stored oracle outputs of this workload, or the oracle itself (tests/oracle_cache.py)
 
-    ids, mask = pad_rows(rows)
-    prune, rank = [], []
-    with torch.no_grad():
-        for start in range(0, len(rows), 32):  # (in batches the CPU caches like)
-            ref = oracle_forward(state, dims, ids[start : start + 32], mask[start : start + 32], attn="sdpa")
-            prune.append(ref.pruning_logits.numpy())
-            rank.append(ref.ranking_logits.numpy())
-    return np.concatenate(prune), np.concatenate(rank)
+    return oracle_rows(tag, state, dims, rows)
 
 
 @pytest.mark.parametrize("weights,kernel_set", [("bf16", "f16-f8"), ("fp32", "f16-f8-w")])
@@ -90,7 +82,7 @@ def test_bench_configuration_matches_the_oracle(weights, kernel_set):
     # a pair's outputs do not depend on its batch companions, the chunking or the CUs that ran it: bit for bit
     assert np.array_equal(prune1, prune2) and np.array_equal(rank1, rank2)
 
-    ref_prune, ref_rank = _oracle(state, dims, [rows[i] for i in CHECKED])
+    ref_prune, ref_rank = _oracle(f"timed_xsmall_o1_{weights}_256x512", state, dims, [rows[i] for i in CHECKED])
     got_prune, got_rank = prune1[CHECKED], rank1[CHECKED]
     # bar of the path: 1e-3; regression bound of THIS configuration: 8e-4 (measured over all 256 pairs: 6.5e-4 fp32-valued,
     # 4.9e-4 bf16-valued)
@@ -121,7 +113,7 @@ def _panel_setup(model: str, weights: str):
     return dims, state, enc
 
 
-def _run_and_check(enc, dims, state, rows, checked, expect_kinds):
+def _run_and_check(tag, enc, dims, state, rows, checked, expect_kinds):
     from open_provence_amd.packing import pack_rows
 
     ids_np, cu_np, max_len = pack_rows(rows)
@@ -134,7 +126,7 @@ def _run_and_check(enc, dims, state, rows, checked, expect_kinds):
     assert expect_kinds <= kinds, kinds
     prune, rank = prune.cpu().numpy(), rank.cpu().numpy()
     assert np.isfinite(prune).all() and np.isfinite(rank).all()
-    ref_prune, ref_rank = _oracle(state, dims, [rows[i] for i in checked])
+    ref_prune, ref_rank = _oracle(tag, state, dims, [rows[i] for i in checked])
     worst = 0.0
     for j, i in enumerate(checked):
         n = len(rows[i])
@@ -156,7 +148,7 @@ def test_base_model_at_bench_size_matches_the_oracle(weights, kernel_set):
     assert enc.effective_policy()["kernel_set"] == kernel_set
     rows = synth_pair_batch(dims, PAIRS, SEQ_LEN, seed=1234)
     # pairs 1 / 2 and 15 / 16 straddle XCD-group boundaries (8 row blocks = 2 pairs per group, 8 groups per round)
-    worst = _run_and_check(enc, dims, state, rows, [0, 1, 2, 15, 16, 127, 128, 200, 254, 255], PANEL_KINDS)
+    worst = _run_and_check(f"timed_base_o1_{weights}_256x512_spots", enc, dims, state, rows, [0, 1, 2, 15, 16, 127, 128, 200, 254, 255], PANEL_KINDS)
     enc.close()
     assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
 
@@ -174,7 +166,7 @@ def test_en_gte_varlen_at_bench_size_matches_the_oracle(weights):
     # first, last, the longest and the shortest row, and two in the middle
     order = sorted(range(len(rows)), key=lambda i: len(rows[i]))
     checked = sorted({0, len(rows) - 1, order[0], order[-1], len(rows) // 3, 2 * len(rows) // 3})
-    worst = _run_and_check(enc, dims, state, rows, checked, PANEL_KINDS)
+    worst = _run_and_check(f"timed_gte_o1_{weights}_varlen_spots", enc, dims, state, rows, checked, PANEL_KINDS)
     enc.close()
     assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
 
@@ -189,7 +181,7 @@ def test_large_model_at_2048_matches_the_oracle(weights):
 
     dims, state, enc = _panel_setup("large", weights)
     rows = synth_pair_batch(dims, 64, 2048, seed=1234)
-    worst = _run_and_check(enc, dims, state, rows, [0, 1, 31, 32, 62, 63], PANEL_KINDS)
+    worst = _run_and_check(f"timed_large_o1_{weights}_64x2048_spots", enc, dims, state, rows, [0, 1, 31, 32, 62, 63], PANEL_KINDS)
     enc.close()
     assert worst < 8e-4, worst  # (bar of the path: 1e-3; these configurations measure 2e-4 .. 5e-4)
 
@@ -212,6 +204,6 @@ def test_xsmall_at_2048_matches_the_oracle_on_every_pair(init, weights, kernel_s
     enc.load_state_dict(state)
     assert enc.effective_policy()["kernel_set"] == kernel_set, enc.calibration
     rows = synth_pair_batch(dims, 64, 2048, seed=1234)
-    worst = _run_and_check(enc, dims, state, rows, list(range(64)), {"fused_layer_attnout_mlp_qkv", "attn_global", "attn_local"})
+    worst = _run_and_check(f"timed_xsmall_{init}_{weights}_64x2048", enc, dims, state, rows, list(range(64)), {"fused_layer_attnout_mlp_qkv", "attn_global", "attn_local"})
     enc.close()
     assert worst < (3e-4 if init == "refinit" else 8e-4), worst

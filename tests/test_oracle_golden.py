@@ -81,3 +81,32 @@ def test_g2_varlen_fixture_against_oracle():
     m = mask.bool().numpy()
     assert np.abs(out.pruning_logits.numpy() - arrays["pruning_logits"][pick, :width])[m].max() < TOL
     assert np.abs(out.ranking_logits.numpy() - arrays["ranking_logits"][pick]).max() < TOL
+
+
+def test_oracle_cache_entry_is_what_the_oracle_computes():
+    """tests/golden/oracle_cache/ holds the oracle's outputs for the full-size GPU comparisons (tests/oracle_cache.py: 55 % of
+    the GPU suite's time went into recomputing them in every run).  One entry end to end on the CPU: its fingerprint is that of
+    the weights and rows the GPU test builds, and rows of it -- first, last, one inside -- are what the oracle computes now."""
+
+    import numpy as np
+    import torch
+
+    from oracle_cache import CACHE_DIR, fingerprint
+    from open_provence_amd.synthetic import named_dims, pad_rows, refinit_state_dict, synth_pair_batch
+    from oracle.modernbert_oracle import oracle_forward
+
+    path = CACHE_DIR / "calibration_xsmall_refinit_fp32_256x512.npz"
+    assert path.exists(), "run the GPU suite once with OPEN_PROVENCE_WRITE_ORACLE_CACHE=<dir> and copy <dir>/*.npz to tests/golden/oracle_cache/"
+    dims = named_dims("xsmall")
+    state = refinit_state_dict(dims, seed=7)
+    rows = synth_pair_batch(dims, 256, 512, seed=1234)
+    with np.load(path) as data:
+        assert str(data["fingerprint"]) == fingerprint(state, rows)
+        prune, rank = data["a0"], data["a1"]
+    assert prune.shape == (256, 512, 2) and rank.shape == (256, dims.num_labels)
+    pick = [0, 131, 255]
+    ids, mask = pad_rows([rows[i] for i in pick])
+    with torch.no_grad():
+        ref = oracle_forward(state, dims, ids, mask, attn="sdpa")
+    assert np.abs(ref.pruning_logits.numpy() - prune[pick]).max() < 2e-5  # (batch of 3 here, batches of 32 there: fp32 summation order)
+    assert np.abs(ref.ranking_logits.numpy() - rank[pick]).max() < 2e-5
