@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OP_ABI_VERSION 8 /* 8: op_calibration.flags (OP_CAL_FULL_REPORT; the search stops at the first candidate that holds otherwise), op_calibrate validates its batch before it touches the handle, op_load_weight of a GEMM weight drops a pinned / calibrated kernel set; 7: kernel sets 10 / 11 (fp16 attention inside the fp16 + e4m3 sets), op_calibration holds 16 candidates; 6: op_select_kernel_set, op_calibrate, kernel set 7 ("f16": single-pass fp16 operands); 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
+#define OP_ABI_VERSION 9 /* 9: kernel sets 8 / 9 layer by layer (op_calibration.mlp_layers / mlp_layers_err, OP_CAL_WHOLE_DEPTH, op_mlp_correction_layers, op_select_mlp_correction_layers); 8: op_calibration.flags (OP_CAL_FULL_REPORT; the search stops at the first candidate that holds otherwise), op_calibrate validates its batch before it touches the handle, op_load_weight of a GEMM weight drops a pinned / calibrated kernel set; 7: kernel sets 10 / 11 (fp16 attention inside the fp16 + e4m3 sets), op_calibration holds 16 candidates; 6: op_select_kernel_set, op_calibrate, kernel set 7 ("f16": single-pass fp16 operands); 5: op_set_compact_operands (run-time fallback to the (hi, lo) bf16 kernel sets); 4: kernel set 3 (fp16 + e4m3 operands), flag NO_F8; 3: op_segment_means, flags LAYER_M32 / NO_HEAD_FUSION (struct layouts as in 2) */
 #define OP_MAX_LAYERS 128
 
 typedef struct op_handle op_handle;
@@ -229,10 +229,22 @@ typedef struct op_calibration {
                              * activation beyond fp16's range on sets 3 - 6 -- or beyond 10 x tolerance, and no candidate
                              * passes, the reference set is chosen right away (ABI 8: the bound on a finite default_err) */
   uint32_t flags;           /* IN: OP_CAL_* bits */
+  float mlp_layers_err;     /* chosen_set 8 / 9 with layers dropped: the difference of what runs now (0 when no layer was dropped) */
+  uint64_t mlp_layers;      /* chosen_set 8 / 9 (the "f16" set with the MLP in the fp16 + e4m3 format): bit li = layer li keeps that
+                             * MLP; in the other layers the batch stayed within the tolerance on the "f16" set's MLP (ABI 9).
+                             * 0 for every other chosen_set */
 } op_calibration;
 #define OP_CAL_FULL_REPORT 1u /* measure every candidate (the report lists them all); default: cheapest first, stop at the first that holds */
+#define OP_CAL_WHOLE_DEPTH 2u /* sets 8 / 9 for the whole depth or not at all (no per-layer search) */
 int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const int32_t* cu_seqlens_host, int n_seqs,
                  op_calibration* report);
+
+/* Kernel sets 8 / 9 layer by layer: bit li of *layer_mask = layer li runs its MLP in the fp16 + e4m3 format (0 when another
+ * set runs).  op_select_mlp_correction_layers pins a mask on a handle whose set 8 / 9 was pinned by op_select_kernel_set or
+ * chosen by op_calibrate (OP_ERR_STATE otherwise; at most 64 layers) -- what a process group uses to give every rank the
+ * mask one rank measured.  Replaces: nothing (see op_calibrate). */
+int op_mlp_correction_layers(op_handle* h, uint64_t* layer_mask);
+int op_select_mlp_correction_layers(op_handle* h, uint64_t layer_mask);
 
 /* Run-time switch between the fp16 + e4m3 kernel sets (3 / 4) and the (hi, lo) bf16 sets (1 / 0) they replace: both
  * weight packs of a handle stay resident, so this only re-runs the selection of op_weights_ready (with enabled = 0 as if

@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 
 OP_MAX_LAYERS = 128
-OP_ABI_VERSION = 8
+OP_ABI_VERSION = 9
 
 OP_OK = 0
 OP_ERR_INVALID, OP_ERR_UNSUPPORTED, OP_ERR_HIP, OP_ERR_STATE, OP_ERR_WORKSPACE, OP_ERR_NOMEM = -1, -2, -3, -4, -5, -6
@@ -54,6 +54,8 @@ EXPORTED_SYMBOLS = (
     "op_effective_policy",
     "op_set_compact_operands",
     "op_select_kernel_set",
+    "op_mlp_correction_layers",
+    "op_select_mlp_correction_layers",
     "op_calibrate",
     "op_workspace_bytes",
     "op_forward_packed",
@@ -113,10 +115,13 @@ class OpCalibration(ctypes.Structure):
         ("n_tokens", ctypes.c_int32),
         ("default_err", ctypes.c_float),
         ("flags", ctypes.c_uint32),
+        ("mlp_layers_err", ctypes.c_float),
+        ("mlp_layers", ctypes.c_uint64),
     ]
 
 
 OP_CAL_FULL_REPORT = 1
+OP_CAL_WHOLE_DEPTH = 2
 
 
 class OpProfileEntry(ctypes.Structure):
@@ -171,6 +176,11 @@ def load_library() -> ctypes.CDLL:
     if hasattr(lib, "op_select_kernel_set"):
         lib.op_select_kernel_set.restype = ci
         lib.op_select_kernel_set.argtypes = [vp, ci]
+        if hasattr(lib, "op_mlp_correction_layers"):
+            lib.op_mlp_correction_layers.restype = ci
+            lib.op_mlp_correction_layers.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+            lib.op_select_mlp_correction_layers.restype = ci
+            lib.op_select_mlp_correction_layers.argtypes = [vp, ctypes.c_uint64]
         lib.op_calibrate.restype = ci
         lib.op_calibrate.argtypes = [vp, ctypes.c_float, vp, vp, ci, ctypes.POINTER(OpCalibration)]
     lib.op_segment_means.restype = ci

@@ -110,6 +110,8 @@ struct op_handle {
   bool wi_f8 = false;              // panel path, OP_FLAG_PANEL_F8_WI: the Wi GEMM (and its LayerNorm) in the fp16 + e4m3 format
   bool mlp_f8 = false;             // panel path, kernel sets 8 / 9: pi = PI_F16 for the attention side, the whole MLP in the fp16 + e4m3 format
   bool mlp_wlo = false;            // ... with the weights' lo part (set 8)
+  uint64_t mlp_layers = ~0ull;     // sets 8 / 9: the layers whose MLP runs in that format (bit li); the others run the "f16" set's MLP
+  uint64_t forced_mlp_layers = ~0ull;  // ... as pinned with forced_set (op_calibrate's per-layer search, op_select_mlp_correction_layers)
   bool attn_f16 = false;           // panel path, kernel sets 10 / 11: pi = PI_F16_F8_W / PI_F16_F8 with the attention on set 7's fp16 kernels
   bool row_path = false;    // hidden <= 256: row-stationary GEMMs with fused LayerNorm
   bool panel_path = false;  // hidden % 256 == 0, intermediate % 128 == 0: k-streamed panel GEMMs, fragment-packed operands
@@ -728,7 +730,8 @@ struct ChunkPass {
     const bool pf8 = o_f8;  // kernel sets 3 / 4: activations as fp16 pieces + e4m3 pieces (x 2^12) of their lo part
     // kernel sets 8 / 9: the attention side on the "f16" kernels (pi = PI_F16), the MLP -- LayerNorm(mlp_norm), Wi + GeGLU
     // with h as fp16 + e4m3 pieces, MLP output projection -- on the fp16 + e4m3 kernels of sets 4 / 3
-    const bool mlp8 = f16 && h->mlp_f8;
+    // -- layer by layer: op_calibrate keeps the fp16 + e4m3 MLP only in the layers the tolerance needs it in (mlp_layers)
+    const bool mlp8 = f16 && h->mlp_f8 && (li >= 64 || ((h->mlp_layers >> li) & 1ull) != 0);
     const bool wlo8 = h->pi == opl::PI_F16_F8_W || (h->wi_f8 && h->pi == opl::PI_ALL_TERMS) || (mlp8 && h->mlp_wlo);
     // OP_FLAG_PANEL_F8_WI: the format in the Wi GEMM alone -- its LayerNorm writes fp16 + e4m3 pieces, its epilogue
     // writes h as the (hi, lo) bf16 pieces the MLP output projection's kernel reads
@@ -1305,6 +1308,7 @@ int op_load_weight(op_handle* h, const char* name_c, const void* data, int dtype
     // a kernel set pinned by op_select_kernel_set or measured by op_calibrate belongs to the weights it was chosen on: new
     // GEMM weights start from the default selection again (and from the compact formats, if op_set_compact_operands left them)
     h->forced_set = -1;
+    h->forced_mlp_layers = ~0ull;
     h->f8_off = false;
   }
   switch (kind) {
@@ -1462,6 +1466,7 @@ void apply_set(op_handle* h, int set) {
   h->wi_f8 = set == OP_KS_BF16X3_WI_F8 || set == OP_KS_BF16_WEIGHTS_WI_F8;
   h->mlp_f8 = set == OP_KS_F16_MLP_F8_W || set == OP_KS_F16_MLP_F8;
   h->mlp_wlo = set == OP_KS_F16_MLP_F8_W;
+  h->mlp_layers = (h->mlp_f8 && set == h->forced_set) ? h->forced_mlp_layers : ~0ull;
   h->attn_f16 = set == OP_KS_F16_F8_W_ATTN_F16 || set == OP_KS_F16_F8_ATTN_F16;
   h->pi = (set == OP_KS_F16 || h->mlp_f8) ? opl::PI_F16 : (h->wi_f8 ? set - 5 : set);
   if (h->attn_f16) h->pi = set == OP_KS_F16_F8_W_ATTN_F16 ? opl::PI_F16_F8_W : opl::PI_F16_F8;
@@ -1490,6 +1495,7 @@ int resolve_policy(op_handle* h) {
   h->emulate = true;
   h->wi_f8 = false;
   h->mlp_f8 = h->mlp_wlo = false;
+  h->mlp_layers = ~0ull;
   h->attn_f16 = false;
   if (!(h->cfg.flags & OP_FLAG_NO_POLICY_KERNELS)) {
     for (int i = 0; i < opl::N_POLICIES; ++i)
@@ -1599,7 +1605,10 @@ int op_set_compact_operands(op_handle* h, int enabled, int* changed) {
   if (rc != OP_OK) return rc;
   const int before = public_set(h);
   h->f8_off = enabled == 0;
-  if (!enabled) h->forced_set = -1;  // a pinned / calibrated compact set goes too
+  if (!enabled) {  // a pinned / calibrated compact set goes too
+    h->forced_set = -1;
+    h->forced_mlp_layers = ~0ull;
+  }
   h->resolved = false;
   rc = resolve_policy(h);
   if (changed) *changed = (rc == OP_OK && public_set(h) != before) ? 1 : 0;
@@ -1613,6 +1622,30 @@ int op_select_kernel_set(op_handle* h, int kernel_set) {
   if (kernel_set != OP_KS_AUTO && !set_available(h, kernel_set))
     return fail(h, OP_ERR_UNSUPPORTED, "op_select_kernel_set: kernel set %d cannot run on this handle (shape, flags or weights)", kernel_set);
   h->forced_set = kernel_set == OP_KS_AUTO ? -1 : kernel_set;
+  h->forced_mlp_layers = ~0ull;
+  h->resolved = false;
+  return resolve_policy(h);
+}
+
+int op_mlp_correction_layers(op_handle* h, uint64_t* layer_mask) {
+  if (!h || !layer_mask) return fail(h, OP_ERR_INVALID, "op_mlp_correction_layers: NULL argument");
+  int rc = op_weights_ready(h);
+  if (rc != OP_OK) return rc;
+  const int n = h->cfg.num_layers;
+  const uint64_t all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  *layer_mask = h->mlp_f8 ? (h->mlp_layers & all) : 0ull;
+  return OP_OK;
+}
+
+int op_select_mlp_correction_layers(op_handle* h, uint64_t layer_mask) {
+  if (!h) return fail(nullptr, OP_ERR_INVALID, "op_select_mlp_correction_layers: NULL handle");
+  int rc = op_weights_ready(h);
+  if (rc != OP_OK) return rc;
+  if (h->forced_set != OP_KS_F16_MLP_F8 && h->forced_set != OP_KS_F16_MLP_F8_W)
+    return fail(h, OP_ERR_STATE, "op_select_mlp_correction_layers: pin kernel set %d or %d first (op_select_kernel_set / op_calibrate)", OP_KS_F16_MLP_F8_W,
+                OP_KS_F16_MLP_F8);
+  if (h->cfg.num_layers > 64) return fail(h, OP_ERR_UNSUPPORTED, "op_select_mlp_correction_layers: more than 64 layers");
+  h->forced_mlp_layers = layer_mask;
   h->resolved = false;
   return resolve_policy(h);
 }
@@ -1648,7 +1681,9 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
   // the default selection and its (hi, lo) bf16 realisation = the reference of the comparison
   const bool f8_off_before = h->f8_off;
   const int forced_before = h->forced_set;
+  const uint64_t forced_mlp_before = h->forced_mlp_layers;
   h->forced_set = -1;
+  h->forced_mlp_layers = ~0ull;
   h->resolved = false;
   OP_TRY(resolve_policy(h));
   const int default_set = public_set(h);
@@ -1675,6 +1710,7 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
   // nothing to measure: whatever was pinned before the call stays pinned
   auto finish_unchanged = [&]() -> int {
     h->forced_set = forced_before;
+    h->forced_mlp_layers = forced_mlp_before;
     h->resolved = false;
     OP_TRY(resolve_policy(h));
     rep.chosen_set = public_set(h);
@@ -1734,8 +1770,9 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
   float* const capture = h->capture;
   h->profiling = false;
   h->capture = nullptr;
-  auto run = [&](int set, std::vector<float>& out) -> int {
+  auto run = [&](int set, std::vector<float>& out, uint64_t mlp_layers = ~0ull) -> int {
     h->forced_set = set;
+    h->forced_mlp_layers = mlp_layers;
     h->resolved = false;
     OP_TRY(resolve_policy(h));
     OP_TRY(op_forward_packed(h, ids_dev, cu_dev, cu.data(), n_seqs, total, max_len, out_dev, out_dev + n_prune, nullptr, ws_aligned,
@@ -1772,6 +1809,54 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
       if (chosen >= 0 && !full_report) break;  // cheapest first: the first one that holds is the answer (OP_CAL_FULL_REPORT measures them all)
     }
   }
+  // Kernel sets 8 / 9 chosen (the "f16" set alone is beyond the tolerance, the MLP in the fp16 + e4m3 format brings it back):
+  // the correction is a per-layer choice (panel_layer): drop it layer by layer for as long as the batch stays within the
+  // tolerance.  The error is a maximum over logits, not a sum over layers, so the order of the walk decides how many layers
+  // go: three walks (first to last, last to first, and by the price of dropping each layer alone), the one that keeps the
+  // fewest layers wins.  About four forwards of the calibration batch per layer, at load.
+  const int n_layers = h->cfg.num_layers;
+  const uint64_t all_layers = n_layers >= 64 ? ~0ull : ((1ull << n_layers) - 1ull);
+  uint64_t mlp_layers = all_layers;
+  if (rc == OP_OK && (chosen == OP_KS_F16_MLP_F8 || chosen == OP_KS_F16_MLP_F8_W) && n_layers <= 64 && !(rep.flags & OP_CAL_WHOLE_DEPTH)) {
+    std::vector<std::pair<float, int>> alone;
+    for (int li = 0; li < n_layers && rc == OP_OK; ++li) {
+      rc = run(chosen, got, all_layers & ~(1ull << li));
+      if (rc == OP_OK) alone.emplace_back(max_diff(), li);
+    }
+    std::vector<std::vector<int>> walks(3);
+    for (int li = 0; li < n_layers; ++li) {
+      walks[0].push_back(li);
+      walks[1].push_back(n_layers - 1 - li);
+    }
+    std::vector<std::pair<float, int>> by_price = alone;
+    std::stable_sort(by_price.begin(), by_price.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+    for (const auto& pr : by_price) walks[2].push_back(pr.second);
+    int best_kept = n_layers + 1;
+    for (size_t w = 0; w < walks.size() && rc == OP_OK && alone.size() == (size_t)n_layers; ++w) {
+      uint64_t mask = all_layers;
+      float mask_err = 0.f;
+      for (int li : walks[w]) {
+        const uint64_t trial = mask & ~(1ull << li);
+        if (trial == 0ull) break;  // (= the "f16" set, measured above)
+        float err = alone[li].first;
+        if (trial != (all_layers & ~(1ull << li))) {
+          rc = run(chosen, got, trial);
+          if (rc != OP_OK) break;
+          err = max_diff();
+        }
+        if (err <= tolerance) {
+          mask = trial;
+          mask_err = err;
+        }
+      }
+      const int kept = __builtin_popcountll(mask);
+      if (rc == OP_OK && kept < best_kept) {
+        best_kept = kept;
+        mlp_layers = mask;
+        rep.mlp_layers_err = mask_err;
+      }
+    }
+  }
   h->profiling = profiling;
   h->capture = capture;
   release();
@@ -1783,11 +1868,13 @@ int op_calibrate(op_handle* h, float tolerance, const int32_t* ids_host, const i
       (!std::isfinite(rep.default_err) || rep.default_err > 10.0f * tolerance))
     chosen = reference_set;
   h->forced_set = (rc == OP_OK && chosen >= 0) ? chosen : -1;
+  h->forced_mlp_layers = (rc == OP_OK && chosen >= 0) ? (mlp_layers | ~all_layers) : ~0ull;
   h->resolved = false;
   const int rc2 = resolve_policy(h);
   if (rc != OP_OK) return rc;
   if (rc2 != OP_OK) return rc2;
   rep.chosen_set = public_set(h);
+  rep.mlp_layers = h->mlp_f8 ? (h->mlp_layers & all_layers) : 0ull;
   return finish();
 }
 

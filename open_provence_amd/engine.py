@@ -247,6 +247,17 @@ class HipEncoder:
         self.__dict__["_f8_active"] = None
         self.__dict__["_audit_pending"] = False  # (a pinned set is the caller's decision: nothing to audit)
 
+    def _repin_calibrated(self, chosen: str) -> None:
+        """Pin the calibrated set again after a detour through another one (the audits run the reference set in between):
+        ``op_select_kernel_set`` means the whole depth, so the layer mask of sets 8 / 9 is pinned again behind it."""
+
+        self.select_kernel_set(chosen)
+        layers = (self.calibration or {}).get("mlp_correction_layers")
+        if layers is not None and chosen in ("f16+mlp-f16-f8-w", "f16+mlp-f16-f8") and chosen == (self.calibration or {}).get("chosen_set"):
+            mask = sum(1 << int(li) for li in layers)
+            _lib.check(self.lib, self._handle, self.lib.op_select_mlp_correction_layers(self._handle, ctypes.c_uint64(mask)),
+                       "op_select_mlp_correction_layers")
+
     def calibrate(self, tolerance: float = 1e-4, rows: "Sequence[Sequence[int]] | None" = None, *, full_report: "bool | None" = None) -> dict:
         """``op_calibrate``: one batch (``rows`` of token ids -- a sample of real inputs -- or the library's synthetic
         batch) through the (hi, lo) bf16 kernels and through every kernel set cheaper than the default one; the
@@ -286,6 +297,11 @@ class HipEncoder:
             "tokens": int(report.n_tokens),
             "batch": "caller rows" if rows is not None else "synthetic (uniform token ids)",
         }
+        # kernel sets 8 / 9 layer by layer (ABI 9): the layers that keep the fp16 + e4m3 MLP, the others run the "f16" set's
+        if self.calibration["chosen_set"] in ("f16+mlp-f16-f8-w", "f16+mlp-f16-f8"):
+            mask = int(report.mlp_layers)
+            self.calibration["mlp_correction_layers"] = [li for li in range(self.dims.num_layers) if (mask >> li) & 1]
+            self.calibration["mlp_correction_err"] = float(report.mlp_layers_err)
         # a set chosen on SYNTHETIC token ids is audited on the first real batch (_audit_first_batch); the caller's own rows
         # are real inputs already.  OPEN_PROVENCE_AUDIT=0 switches the audit off.
         self.__dict__["_audit_pending"] = (rows is None and self.calibration["chosen_set"] != self.calibration["default_set"]
@@ -304,10 +320,16 @@ class HipEncoder:
         code = self.lib.op_effective_policy(self._handle, terms, ctypes.byref(kernel_set))
         _lib.check(self.lib, self._handle, code, "op_effective_policy")
         names = _lib.KERNEL_SET_NAMES
-        return {
+        policy = {
             "terms": {name: int(terms[i]) for i, name in enumerate(_lib.OP_FAMILIES)},
             "kernel_set": names.get(int(kernel_set.value), str(kernel_set.value)),
         }
+        if policy["kernel_set"] in ("f16+mlp-f16-f8-w", "f16+mlp-f16-f8") and hasattr(self.lib, "op_mlp_correction_layers"):
+            mask = ctypes.c_uint64(0)
+            code = self.lib.op_mlp_correction_layers(self._handle, ctypes.byref(mask))
+            _lib.check(self.lib, self._handle, code, "op_mlp_correction_layers")
+            policy["mlp_correction_layers"] = [li for li in range(self.dims.num_layers) if (int(mask.value) >> li) & 1]
+        return policy
 
     # -- the range guard of the fp16 + e4m3 kernel sets ---------------------------------------------
     def f8_active(self) -> bool:
@@ -464,10 +486,10 @@ class HipEncoder:
         if not chosen or chosen == cal.get("default_set") or reference not in _lib.KERNEL_SET_IDS:
             return None
         outs = {}
-        for name in (chosen, reference):
-            _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(_lib.KERNEL_SET_IDS[name])), "op_select_kernel_set")
-            outs[name] = self.forward_packed(ids, cu, cu_np, max_len)
-        _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(_lib.KERNEL_SET_IDS[chosen])), "op_select_kernel_set")
+        outs[chosen] = self.forward_packed(ids, cu, cu_np, max_len)  # (what is pinned now: the calibrated set, its layer mask included)
+        _lib.check(self.lib, self._handle, self.lib.op_select_kernel_set(self._handle, int(_lib.KERNEL_SET_IDS[reference])), "op_select_kernel_set")
+        outs[reference] = self.forward_packed(ids, cu, cu_np, max_len)
+        self._repin_calibrated(chosen)
         self.__dict__["_f8_active"] = None
         err = float(torch.maximum((outs[chosen][0] - outs[reference][0]).abs().max(), (outs[chosen][1] - outs[reference][1]).abs().max()).item())
         bound = float(cal.get("tolerance", DEFAULT_CALIBRATION_TOLERANCE)) * float(getattr(self, "audit_factor", 3.0))
@@ -527,7 +549,7 @@ class HipEncoder:
             self._forward_native(ids.data_ptr(), cu_seqlens.data_ptr(), cu_host, n_seqs, total, max_seqlen,
                                  p_ref.data_ptr(), r_ref.data_ptr(), None, ws, stream)
         finally:
-            self.select_kernel_set(chosen)
+            self._repin_calibrated(chosen)
             if profiling:
                 self.lib.op_profile_enable(self._handle, 1)
         err = float(torch.maximum((prune - p_ref).abs().max(), (rank - r_ref).abs().max()).item())  # (synchronises)

@@ -252,12 +252,16 @@ def agree_on_kernel_set(encoder, group=None) -> str:
 
     import torch.distributed as dist
 
-    mine = encoder.effective_policy()["kernel_set"]
+    policy = encoder.effective_policy()
+    mine = policy["kernel_set"]
     world = dist.get_world_size(group)
     if world <= 1:
         return mine
+    # (sets 8 / 9 run layer by layer: the layers that keep the corrected MLP are part of the arithmetic)
+    layers = policy.get("mlp_correction_layers")
+    key = mine if layers is None else f"{mine}@{','.join(map(str, layers))}"
     names: list = [None] * world
-    dist.all_gather_object(names, mine, group=group)
+    dist.all_gather_object(names, key, group=group)
     if any(n != names[0] for n in names):
         return encoder.revert_to_default(f"the ranks of the process group chose different kernel sets at load time: {names}")
     return mine

@@ -19,7 +19,7 @@ import sys
 from collections import defaultdict
 
 KIND = [
-    (r"layer16p_kernel", "fused_layer_attnout_mlp_qkv"),  # round 6: the wave-pair whole-layer kernel (per-launch average of ITS launches:
+    (r"(?<!pack_)layer16p_kernel<", "fused_layer_attnout_mlp_qkv"),  # round 6: the wave-pair whole-layer kernel (per-launch average of ITS launches:
     # the last layer's launch stays on rowgemm_kernel and is reported under "fused_layer_last" so that it does not dilute the average)
     (r"rowgemm_kernel<\d+, 1, 4,", "fused_layer_last"),
     (r"rowgemm_kernel<\d+, [01], 4,", "fused_layer_attnout_mlp_qkv"),
@@ -50,7 +50,14 @@ def per_kernel(directory, counter):
         rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         residual_ids = {}  # the residual panel GEMM runs twice per layer, in this order: attention out, MLP out
+        # bench.py runs the batch as one launch sequence AND as two half-batch sequences: per-launch figures are those of the
+        # whole-batch launches (the largest grid of each kernel name), what roofline.achieved is quoted on
+        widest = defaultdict(int)
         for r in rows:
+            widest[r["Kernel_Name"]] = max(widest[r["Kernel_Name"]], int(r.get("Grid_Size", 0) or 0))
+        for r in rows:
+            if int(r.get("Grid_Size", 0) or 0) < widest[r["Kernel_Name"]]:
+                continue
             for pat, kind in KIND:
                 if re.search(pat, r["Kernel_Name"]):
                     if kind == "panel_residual":

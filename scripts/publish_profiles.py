@@ -35,7 +35,7 @@ import re
 
 avgs_path = os.path.join(PROFILES, "rocprof_launch_avgs.json")
 avgs = json.load(open(avgs_path)) if os.path.exists(avgs_path) else {}
-KINDS = [(r"layer16p_kernel", "fused_layer_attnout_mlp_qkv"), (r"rowgemm_kernel<\d+, 0, 4,", "fused_layer_attnout_mlp_qkv")]
+KINDS = [(r"(?<!pack_)layer16p_kernel<", "fused_layer_attnout_mlp_qkv"), (r"rowgemm_kernel<\d+, 0, 4,", "fused_layer_attnout_mlp_qkv")]
 for tag in sys.argv[1:]:
     bench_json = os.path.join(PROFILES, f"{tag}_bench_under_rocprofv3.json")
     stats_csv = os.path.join(PROFILES, f"{tag}_kernel_stats.csv")

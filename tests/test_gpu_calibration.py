@@ -141,12 +141,12 @@ def test_panel_path_calibrates_and_stays_inside_its_tolerance():
         ids, cu = torch.from_numpy(ids_np).to(enc.device), torch.from_numpy(cu_np).to(enc.device)
         prune, rank = enc.forward_packed_checked(ids, cu, cu_np, max_len)
         torch.cuda.synchronize()
-        outs[label] = (prune.cpu().numpy(), rank.cpu().numpy(), enc.effective_policy()["kernel_set"], enc.calibration)
+        outs[label] = (prune.cpu().numpy(), rank.cpu().numpy(), enc.effective_policy()["kernel_set"], enc.calibration, enc.effective_policy())
         enc.close()
-    ref_p, ref_r, ref_set, _ = outs["reference"]
+    ref_p, ref_r, ref_set = outs["reference"][:3]
     assert ref_set == "bf16x3"
     for label, slack in (("calibrated", 1e-4), ("calibrated 2e-4", 2e-4)):
-        p, r, chosen, cal = outs[label]
+        p, r, chosen, cal = outs[label][:4]
         assert cal["chosen_set"] == chosen and chosen != "bf16x3+wi-f16-f8-w", cal  # something cheaper than the default holds
         # measured on a different batch than the calibration's: allow 1.5 x the tolerance
         assert np.abs(p - ref_p).max() <= 1.5 * slack and np.abs(r - ref_r).max() <= 1.5 * slack, (label, chosen, float(np.abs(p - ref_p).max()))
@@ -154,6 +154,62 @@ def test_panel_path_calibrates_and_stays_inside_its_tolerance():
     # at 1e-4 and 19 layers: the MLP's two contractions carry the single-pass error (scripts/family_error_probe.py: 6 x the
     # other four families together) -- the attention side runs on the "f16" kernels, the MLP in the fp16 + e4m3 format
     assert outs["calibrated"][2] == "f16+mlp-f16-f8-w", outs["calibrated"][3]
+    # ... and only in the layers the tolerance needs it in (ABI 9: the search drops the correction layer by layer)
+    cal = outs["calibrated"][3]
+    kept = cal["mlp_correction_layers"]
+    assert 0 < len(kept) < dims.num_layers and kept == sorted(set(kept)), cal
+    assert 0.0 < cal["mlp_correction_err"] <= cal["tolerance"], cal
+    assert cal["candidates"]["f16+mlp-f16-f8-w"] <= cal["mlp_correction_err"] <= cal["candidates"]["f16"], cal
+    # the first-batch audit ran the reference set in between (engine._audit_first_batch): the mask is pinned again behind it
+    assert cal["audit"]["passed"] and outs["calibrated"][4]["mlp_correction_layers"] == kept, (cal, outs["calibrated"][4])
+
+
+def test_mlp_correction_layer_mask_through_the_c_abi():
+    """Kernel sets 8 / 9 layer by layer: with no layer kept the forward IS the "f16" set's (bit-identical), with every layer
+    kept it is the whole-depth set's; a mask needs set 8 / 9 pinned first; re-pinning a set resets the mask."""
+
+    import ctypes
+
+    from open_provence_amd import _lib
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pair_batch
+
+    dims = named_dims("base", num_layers=4, vocab_size=2048)
+    state = refinit_state_dict(dims, seed=5)
+    rows = [r[:n] for r, n in zip(synth_pair_batch(dims, 4, 256, seed=3), (256, 31, 130, 77))]
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc.load_state_dict(state, calibrate=False)
+
+    def forward():
+        p, r, _ = enc.forward_rows(rows)
+        torch.cuda.synchronize()
+        return p.cpu().numpy(), r.cpu().numpy()
+
+    def select_layers(mask):
+        return enc.lib.op_select_mlp_correction_layers(enc._handle, ctypes.c_uint64(mask))
+
+    assert select_layers(0b0101) == -4  # OP_ERR_STATE: no set 8 / 9 pinned
+    enc.select_kernel_set("f16")
+    f16_p, f16_r = forward()
+    assert "mlp_correction_layers" not in enc.effective_policy()
+    enc.select_kernel_set("f16+mlp-f16-f8-w")
+    assert enc.effective_policy()["mlp_correction_layers"] == [0, 1, 2, 3]
+    full_p, full_r = forward()
+    assert not np.array_equal(full_p, f16_p)
+    assert select_layers(0b0101) == 0
+    assert enc.effective_policy()["mlp_correction_layers"] == [0, 2]
+    part_p, part_r = forward()
+    assert not np.array_equal(part_p, f16_p) and not np.array_equal(part_p, full_p)
+    assert select_layers(0) == 0
+    none_p, none_r = forward()
+    assert np.array_equal(none_p, f16_p) and np.array_equal(none_r, f16_r)
+    assert select_layers(0b1111) == 0
+    all_p, all_r = forward()
+    assert np.array_equal(all_p, full_p) and np.array_equal(all_r, full_r)
+    assert select_layers(0b0010) == 0
+    enc.select_kernel_set("f16+mlp-f16-f8-w")  # pinning a set again: the whole depth
+    assert enc.effective_policy()["mlp_correction_layers"] == [0, 1, 2, 3]
+    enc.close()
 
 
 @pytest.mark.parametrize("weights", ["fp32", "bf16"])
