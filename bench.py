@@ -349,8 +349,8 @@ def main() -> None:
     parser.add_argument("--pipelines", type=int, default=0, choices=[0, 1, 2],
                         help="single GPU: the batch as this many independent launch sequences (each on its own HIP stream and "
                         "its own half of the CUs; 2 = HipEncoder.forward_packed_on).  0 = automatic: two for the "
-                        "row-stationary models (hidden <= 256: +3 %), one for the panel-path models (base / large / "
-                        "en-gte: two measure -0.7 %, their XCD-aware block maps assume all eight XCDs).  The per-kernel "
+                        "row-stationary models (hidden <= 256: +3 %%), one for the panel-path models (base / large / "
+                        "en-gte: two measure -0.7 %%, their XCD-aware block maps assume all eight XCDs).  The per-kernel "
                         "profile uses one")
     parser.add_argument("--no-trained-like", action="store_true", help="skip the trained-like checkpoint sub-record")
     parser.add_argument("--no-settle", action="store_true",

@@ -138,3 +138,10 @@ def test_bench_refuses_outputs_that_differ_from_the_stored_checksum(tmp_path, mo
     monkeypatch.setattr(bench, "_checksum_write_mode", True)
     assert bench.output_checksum(prune * 2, rank, "w|8x512|fp32")["stored"] == "written by this run"
     assert bench._checksums_seen["w|8x512|fp32"]["prune_abs_sum"] == pytest.approx(2 * plain["prune_abs_sum"])
+
+
+def test_bench_help_prints():
+    """``--help`` goes through argparse's %-formatting of every help string (a bare ``%`` in one raised instead of printing)."""
+
+    proc = subprocess.run([sys.executable, str(REPO_ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and "--steps" in proc.stdout and "--varlen" in proc.stdout, proc.stderr[-1500:]
