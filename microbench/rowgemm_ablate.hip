@@ -63,6 +63,11 @@ static void fill_e4m3(unsigned char* v, size_t n, unsigned seed, int max_exp_cod
   }
 }
 
+__global__ void abl_spin_kernel(unsigned long long ticks) {  // ticks of the 100 MHz counter
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 int main() {
   // ABL_ROWS: rows of the launch (default 131072 = 1024 blocks = 4 rounds of 256 CUs); 16384 = half the CUs, one round
   const int R = getenv("ABL_ROWS") ? atoi(getenv("ABL_ROWS")) : 131072;
@@ -259,13 +264,61 @@ int main() {
     hipLaunchKernelGGL((rowgemm_kernel<KS, RE_GEGLU, RP_KSTREAM, ABL_T, ABL_T, 1, 4, 2>), dim3(R / 128), dim3(256), 0, 0, p);
   };
 #endif
+  bool dual_mode = false;
+#if ABL_LAYER == 34
+  // ABL_DUAL=<offset us>: the same launch TWICE at once, on the two halves of the CUs (CU-masked streams), the second one behind a
+  // spin of <offset> us -- what the phases of a block cost when the other half of the chip is in another phase (round 6)
+  if (const char* dual = getenv("ABL_DUAL")) {
+    const double offset_us = atof(dual);
+    dual_mode = true;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int n_cus = prop.multiProcessorCount, words = (n_cus + 31) / 32;
+    hipStream_t half[2];
+    for (int part = 0; part < 2; ++part) {
+      std::vector<uint32_t> mask(words, 0u);
+      for (int c = 0; c < n_cus; ++c)
+        if ((getenv("ABL_DUAL_INTERLEAVE") ? c % 2 : c * 2 / n_cus) == part) mask[c / 32] |= 1u << (c % 32);
+      CHECK(hipExtStreamCreateWithCUMask(&half[part], (uint32_t)words, mask.data()));
+    }
+    auto launch_on = [&](hipStream_t st) {
+#ifdef ABL_H16
+      hipLaunchKernelGGL((layer16p_kernel<8, true, true, ABL_XT, ABL_XT>), dim3(R / 128), dim3(512), 0, st, lp);
+#else
+      hipLaunchKernelGGL((layer16p_kernel<8, true, false, ABL_XT, ABL_XT>), dim3(R / 128), dim3(512), 0, st, lp);
+#endif
+    };
+    double sum_ms = 0;
+    const int reps = 8;
+    for (int i = 0; i < reps + 2; ++i) {
+      CHECK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+      CHECK(hipDeviceSynchronize());
+      hipEvent_t a0, a1, b1;
+      CHECK(hipEventCreate(&a0)); CHECK(hipEventCreate(&a1)); CHECK(hipEventCreate(&b1));
+      CHECK(hipEventRecord(a0, half[0]));
+      launch_on(half[0]);
+      CHECK(hipEventRecord(a1, half[0]));
+      if (offset_us > 0) hipLaunchKernelGGL(abl_spin_kernel, dim3(1), dim3(64), 0, half[1], (unsigned long long)(offset_us * 100.0));
+      launch_on(half[1]);
+      CHECK(hipEventRecord(b1, half[1]));
+      CHECK(hipDeviceSynchronize());
+      float ta, tb;
+      CHECK(hipEventElapsedTime(&ta, a0, a1));
+      CHECK(hipEventElapsedTime(&tb, a0, b1));
+      if (i >= 2) sum_ms += (ta > tb ? ta : tb);
+    }
+    printf("dual launch, offset %.0f us: both done after %.1f us (avg of %d; includes the offset)\n", offset_us, sum_ms / reps * 1000.0, reps);
+  } else
+#endif
+  {
   for (int i = 0; i < 5; ++i) {
     CHECK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));  // keep the residual stream bounded
     launch();
   }
   CHECK(hipDeviceSynchronize());
+  }
   float best = 1e9f, sum = 0.f;
-  const int reps = 10;
+  const int reps = dual_mode ? 0 : 10;  // (dual mode: the stamps below are those of the two concurrent launches)
   for (int i = 0; i < reps; ++i) {
     CHECK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipEventRecord(e0));

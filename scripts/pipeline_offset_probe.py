@@ -53,6 +53,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--model", default="xsmall")
     ap.add_argument("--kernel-set", default="f16")
+    ap.add_argument("--locked", action="store_true", help="only: two sequences re-locked every step at a chosen offset")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
@@ -103,7 +104,52 @@ def main() -> None:
         dt = time.perf_counter() - t0 - (parts - 1) * offset_us * 1e-6  # the last sequence starts that much later
         return args.pairs * args.steps / dt
 
+    def run_locked(offset_us: float) -> float:
+        """Two sequences on the two CU halves, re-locked EVERY step: sequence 1 may not start a step earlier than `offset` after
+        sequence 0 started the same step (event of stream 0 + a spin on stream 1)."""
+
+        streams = masked_streams(device, 2, False)
+        per = len(rows) // 2
+        work = []
+        for j in range(2):
+            ids_np, cu_np, max_len = pack_rows(rows[j * per:(j + 1) * per])
+            ids, cu = torch.from_numpy(ids_np).to(device), torch.from_numpy(cu_np).to(device)
+            total, n = int(cu_np[-1]), len(cu_np) - 1
+            need = int(enc.lib.op_workspace_bytes(enc._handle, n, total, int(max_len)))
+            work.append((ids, cu, cu_np, n, total, int(max_len), torch.empty((total, 2), device=device), torch.empty((n, dims.num_labels), device=device),
+                         torch.empty(need + 256, dtype=torch.uint8, device=device)))
+        torch.cuda.synchronize()
+        events = [torch.cuda.Event() for _ in range(args.steps + 8)]
+
+        def step(i):
+            for j, (ids, cu, cu_np, n, total, max_len, prune, rank, ws) in enumerate(work):
+                if j == 0:
+                    events[i].record(streams[0])
+                else:
+                    streams[1].wait_event(events[i])
+                    if offset_us > 0:
+                        with torch.cuda.stream(streams[1]):
+                            torch.cuda._sleep(int(offset_us * cyc_per_us))
+                enc._forward_native(ids.data_ptr(), cu.data_ptr(), cu_np, n, total, max_len, prune.data_ptr(), rank.data_ptr(), None, ws, streams[j].cuda_stream)
+
+        for i in range(6):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(6 + i)
+        torch.cuda.synchronize()
+        return args.pairs * args.steps / (time.perf_counter() - t0)
+
     base = run(1, 0.0, False, unmasked=True)
+    if args.locked:
+        print(f"1 sequence, whole chip: {base:9.0f} pairs/s", flush=True)
+        v = run(2, 0.0, False)
+        print(f"2 sequences, contiguous CU masks, running free: {v:9.0f} pairs/s ({v / base - 1:+.1%})", flush=True)
+        for off in (0.0, 10.0, 20.0, 30.0, 40.0, 55.0, 70.0, 100.0, 150.0):
+            v = run_locked(off)
+            print(f"2 sequences, contiguous CU masks, re-locked every step at offset {off:5.0f} us: {v:9.0f} pairs/s ({v / base - 1:+.1%})", flush=True)
+        return
     print(f"1 sequence, whole chip: {base:9.0f} pairs/s", flush=True)
     for parts in (2, 4, 8):
         for interleave in (False, True):
