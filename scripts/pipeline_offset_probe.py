@@ -53,11 +53,12 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--model", default="xsmall")
     ap.add_argument("--kernel-set", default="f16")
+    ap.add_argument("--layers", type=int, default=0, help="model depth override (3: ONE wave-pair launch per step... a per-step lock is then a per-layer lock)")
     ap.add_argument("--locked", action="store_true", help="only: two sequences re-locked every step at a chosen offset")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
-    dims = named_dims(args.model)
+    dims = named_dims(args.model, num_layers=args.layers) if args.layers else named_dims(args.model)
     enc = HipEncoder(dims, device=device)
     enc.load_state_dict(refinit_state_dict(dims, seed=1234), calibrate=False, kernel_set=args.kernel_set)
     rows = synth_pair_batch(dims, args.pairs, args.seq_len, seed=1234)
