@@ -1,9 +1,3 @@
-set -x
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python bench.py > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err; tail -c 400 gpurun_out/r06_bench_default.json
-: > gpurun_out/r06_bench_configs.jsonl
-python bench.py --model base --steps 100 --warmup 5 --no-cpu-baseline --no-long --no-base --no-trained-like --no-worst-case --no-other-dtype >> gpurun_out/r06_bench_configs.jsonl 2>/dev/null
-python bench.py --model large --pairs 64 --seq-len 2048 --steps 100 --warmup 5 --no-cpu-baseline --no-long --no-base --no-trained-like --no-worst-case --no-other-dtype >> gpurun_out/r06_bench_configs.jsonl 2>/dev/null
-python bench.py --model en-gte --varlen --steps 100 --warmup 5 --no-cpu-baseline --no-long --no-base --no-trained-like --no-worst-case --no-other-dtype >> gpurun_out/r06_bench_configs.jsonl 2>/dev/null
-wc -l gpurun_out/r06_bench_configs.jsonl
-python scripts/trained_like_probe.py > gpurun_out/r06_trained_like_probe.txt 2>&1; tail -5 gpurun_out/r06_trained_like_probe.txt
+echo "# scripts/forward_fuzz.py --init refinit --models xsmall --trials 60 --flags NO_SMALL_BLOCKS: every ragged batch through the WAVE-PAIR whole-layer kernel (by default it runs from one 128-row block per CU upward); second run: the same batches on the 8 x 16 kernel (--flags NO_SMALL_BLOCKS,NO_LAYER_PAIRS)"
+python scripts/forward_fuzz.py --init refinit --models xsmall --trials 60 --flags NO_SMALL_BLOCKS 2>&1 | grep -v amdgpu.ids
+python scripts/forward_fuzz.py --init refinit --models xsmall --trials 60 --flags NO_SMALL_BLOCKS,NO_LAYER_PAIRS 2>&1 | grep -v amdgpu.ids

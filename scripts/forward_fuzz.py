@@ -42,12 +42,18 @@ def main() -> None:
     ap.add_argument("--init", default="o1", choices=["o1", "refinit"],
                     help="o1: synthetic O(1) weights (the all-terms kernel sets); refinit: the reference's initialisation -- the kernel "
                     "sets the load-time calibration picks (f16 on xsmall, f16+mlp-f16-f8-w on base at full depth, ...)")
+    ap.add_argument("--flags", default="", help="comma-separated OP_FLAG_* names without the prefix (e.g. NO_SMALL_BLOCKS,NO_LAYER_PAIRS)")
+    ap.add_argument("--models", default="xsmall,base,en-gte,large", help="comma-separated subset of the published shapes")
     ap.add_argument("--full-depth", action="store_true", help="base / en-gte / large at their published depth instead of 4 layers")
     args = ap.parse_args()
     torch.set_num_threads(16)
+    from open_provence_amd import _lib
+    flag_bits = 0
+    for name in filter(None, args.flags.split(",")):
+        flag_bits |= int(getattr(_lib, "OP_FLAG_" + name.strip()))
     rng = np.random.default_rng(args.seed)
     cut = {} if args.full_depth else {"num_hidden_layers": 4}
-    configs = [("xsmall", {}), ("base", cut), ("en-gte", cut), ("large", cut)]
+    configs = [c for c in [("xsmall", {}), ("base", cut), ("en-gte", cut), ("large", cut)] if c[0] in args.models.split(",")]
     bound = 8e-4 if args.init == "o1" else 3e-4  # calibrated sets: 1e-4 to the (hi, lo) bf16 kernels on the calibration batch
     failed = False
     for model, overrides in configs:
@@ -56,7 +62,7 @@ def main() -> None:
             state = (synth_state_dict if args.init == "o1" else refinit_state_dict)(dims, seed=7)
             if weights == "bf16":
                 state = {k: (v.to(torch.bfloat16).to(torch.float32) if v.ndim == 2 and "embeddings" not in k else v) for k, v in state.items()}
-            enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+            enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flag_bits)
             enc.load_state_dict(state)
             _SETS[(dims.hidden_size, weights)] = enc.effective_policy()["kernel_set"]
             worst, worst_at, tokens = 0.0, None, 0

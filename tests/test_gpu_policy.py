@@ -454,3 +454,40 @@ def test_wave_pair_layer_kernel_matches_the_8x16_kernel_and_the_oracle(kernel_se
             a, b = int(cu_np[i]), int(cu_np[i + 1])
             assert np.abs(outs["pairs"][0][a:b] - rp[j, : b - a]).max() < 3e-4, (i, b - a)
             assert np.abs(outs["pairs"][1][i] - rr[j]).max() < 3e-4
+
+
+def test_wave_pair_layer_kernel_on_small_ragged_batches():
+    """The wave-pair kernel at the sizes it does NOT run by default (fewer 128-row blocks than CUs; OP_FLAG_NO_SMALL_BLOCKS sends
+    them there): rows of 1 .. 645 tokens on and around every tiling granularity, partly empty last blocks, a one-row batch --
+    against the fp32 oracle, and different from the 8 x 16 kernel's bits (it did run).  scripts/forward_fuzz.py --flags
+    NO_SMALL_BLOCKS is the long form (profiles/r06_forward_fuzz_pairs.txt)."""
+
+    from open_provence_amd import _lib
+    from open_provence_amd.engine import HipEncoder
+    from open_provence_amd.synthetic import named_dims, pad_rows, refinit_state_dict, synth_pair_batch
+    from oracle.modernbert_oracle import oracle_forward
+
+    dims = named_dims("xsmall")
+    state = refinit_state_dict(dims, seed=11)
+    full = synth_pair_batch(dims, 12, 700, seed=5)
+    batches = [[full[i][:n] for i, n in enumerate((1, 2, 15, 17, 63, 127, 128, 129, 255, 385, 513, 645))], [full[3][:127]], [full[0][:236], full[1][:191], full[2][:384]]]
+    outs = {}
+    for label, flags in (("pairs", _lib.OP_FLAG_NO_SMALL_BLOCKS), ("8x16", _lib.OP_FLAG_NO_SMALL_BLOCKS | NO_LAYER_PAIRS)):
+        enc = HipEncoder(dims, device="cuda:0", flags=flags)
+        enc.load_state_dict(state, calibrate=False, kernel_set="f16")
+        outs[label] = []
+        for rows in batches:
+            p, r, _ = enc.forward_rows(rows)
+            torch.cuda.synchronize()
+            outs[label].append((p.cpu().numpy(), r.cpu().numpy()))
+        enc.close()
+    for b, rows in enumerate(batches):
+        ids, mask = pad_rows(rows)
+        with torch.no_grad():
+            ref = oracle_forward(state, dims, ids, mask)
+        m = mask.bool().numpy()
+        p, r = outs["pairs"][b]
+        assert np.isfinite(p).all() and np.isfinite(r).all()
+        assert np.abs(p - ref.pruning_logits.numpy()[m]).max() < 3e-4 and np.abs(r - ref.ranking_logits.numpy()).max() < 3e-4, b
+        assert np.abs(p - outs["8x16"][b][0]).max() < 6e-5
+    assert not np.array_equal(outs["pairs"][0][0], outs["8x16"][0][0])
