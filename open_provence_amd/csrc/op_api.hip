@@ -396,7 +396,7 @@ struct ChunkPass {
     // projection) as ONE kernel with h kept on chip; the all-terms set keeps the two fused kernels per layer.
     layer_fused = h->row_path && !h->emulate && opl::has_row_layer_fused(h->pi) && !(h->cfg.flags & OP_FLAG_NO_LAYER_FUSION);
     head_in_last_layer = layer_fused && h->cfg.pooling != OP_POOL_MEAN && !h->capture && !(h->cfg.flags & OP_FLAG_NO_HEAD_FUSION);
-    pair_layers = layer_fused && H == 256 && I % 64 == 0 && (f16 || h->pi == 2) && !h->capture && !small_blocks &&
+    pair_layers = layer_fused && H == 256 && I % 64 == 0 && (f16 || h->pi == 2) && !h->capture &&
                   !(h->cfg.flags & (OP_FLAG_NO_LAYER_PAIRS | OP_FLAG_LAYER_8X16 | OP_FLAG_LAYER_M32)) &&
                   h->layers[0].wo_pp[f16 ? 1 : 0] != nullptr;
   }
@@ -604,8 +604,9 @@ struct ChunkPass {
         OP_TRY(L.end());
         return OP_OK;
       }
-      // Single-pass kernel sets ("f16" / "bf16"), hidden = 256, at least a block per CU: the wave-pair kernel
-      // (opk_layer16p.hip.h).  The last layer keeps the 8 x 16 kernel (it ends with final_norm + the pruning head).  Between two
+      // Single-pass kernel sets ("f16" / "bf16"), hidden = 256: the wave-pair kernel (opk_layer16p.hip.h), at every batch size --
+      // below one 128-row block per CU too, where the other launches switch to 64-row blocks (small_blocks): 4 - 8 % faster
+      // forwards from 512 to 32 k tokens than the 8 x 16 kernel's 64-row form (profiles/r06_small_request.txt).  The last layer keeps the 8 x 16 kernel (it ends with final_norm + the pruning head).  Between two
       // wave-pair launches the residual stream is TILED (coalesced 1 KiB loads / stores): the first one reads rows, the last
       // one writes rows.  Hidden-state capture reads rows after every layer: it keeps the 8 x 16 kernel.
       if (pair_layers && with_qkv) {

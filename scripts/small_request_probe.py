@@ -23,12 +23,20 @@ from open_provence_amd.synthetic import named_dims, refinit_state_dict, synth_pa
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="xsmall")
+    ap.add_argument("--flags", default="", help="comma-separated OP_FLAG_* names without the prefix")
+    ap.add_argument("--sizes", default="", help="n x L pairs, e.g. 16x256,64x512 (default: the standard ladder)")
     args = ap.parse_args()
+    from open_provence_amd import _lib
+    flag_bits = 0
+    for name in filter(None, args.flags.split(",")):
+        flag_bits |= int(getattr(_lib, "OP_FLAG_" + name.strip()))
     dims = named_dims(args.model)
-    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=0)
+    enc = HipEncoder(dims, device="cuda:0", precision="bf16x3", flags=flag_bits)
     enc.load_state_dict(refinit_state_dict(dims, seed=7))
     print(args.model, "kernel set", enc.effective_policy()["kernel_set"], flush=True)
-    for n, L in ((1, 64), (1, 512), (4, 128), (8, 128), (16, 256), (32, 256), (64, 512)):
+    sizes = [tuple(int(v) for v in item.split("x")) for item in args.sizes.split(",") if item] or [(1, 64), (1, 512), (4, 128), (8, 128), (16, 256), (32, 256), (64, 512)]
+    print("flags", args.flags or "-", flush=True)
+    for n, L in sizes:
         rows = synth_pair_batch(dims, n, L, seed=3)
         ids_np, cu_np, max_len = pack_rows(rows)
         ids, cu = torch.from_numpy(ids_np).cuda(), torch.from_numpy(cu_np).cuda()
