@@ -417,7 +417,7 @@ NO_LAYER_PAIRS = 8192  # OP_FLAG_NO_LAYER_PAIRS: keep the 8 waves x 16 rows whol
 
 @pytest.mark.parametrize("kernel_set", ["f16", "bf16"])
 def test_wave_pair_layer_kernel_matches_the_8x16_kernel_and_the_oracle(kernel_set):
-    """Round 6: on the single-pass kernel sets a batch of more than one 128-row block per CU runs its whole-layer launches
+    """Round 6: on the single-pass kernel sets a batch (here: more than one 128-row block per CU) runs its whole-layer launches
     on the wave-pair kernel (opk_layer16p.hip.h: two waves per SIMD share a 32-row tile and split the output features; other
     weight packs, LayerNorm statistics combined from two halves, h and LN(x) exchanged through LDS, the residual stream
     tiled between launches).  Same terms as the 8 x 16 kernel it replaces: equal to it up to the summation order (fp16:
@@ -457,8 +457,7 @@ def test_wave_pair_layer_kernel_matches_the_8x16_kernel_and_the_oracle(kernel_se
 
 
 def test_wave_pair_layer_kernel_on_small_ragged_batches():
-    """The wave-pair kernel at the sizes it does NOT run by default (fewer 128-row blocks than CUs; OP_FLAG_NO_SMALL_BLOCKS sends
-    them there): rows of 1 .. 645 tokens on and around every tiling granularity, partly empty last blocks, a one-row batch --
+    """The wave-pair kernel below one 128-row block per CU (OP_FLAG_NO_SMALL_BLOCKS: the other launches on 128-row blocks too): rows of 1 .. 645 tokens on and around every tiling granularity, partly empty last blocks, a one-row batch --
     against the fp32 oracle, and different from the 8 x 16 kernel's bits (it did run).  scripts/forward_fuzz.py --flags
     NO_SMALL_BLOCKS is the long form (profiles/r06_forward_fuzz_pairs.txt)."""
 
@@ -472,8 +471,8 @@ def test_wave_pair_layer_kernel_on_small_ragged_batches():
     full = synth_pair_batch(dims, 12, 700, seed=5)
     batches = [[full[i][:n] for i, n in enumerate((1, 2, 15, 17, 63, 127, 128, 129, 255, 385, 513, 645))], [full[3][:127]], [full[0][:236], full[1][:191], full[2][:384]]]
     outs = {}
-    for label, flags in (("pairs", _lib.OP_FLAG_NO_SMALL_BLOCKS), ("8x16", _lib.OP_FLAG_NO_SMALL_BLOCKS | NO_LAYER_PAIRS)):
-        enc = HipEncoder(dims, device="cuda:0", flags=flags)
+    for label, flags in (("pairs", _lib.OP_FLAG_NO_SMALL_BLOCKS), ("8x16", _lib.OP_FLAG_NO_SMALL_BLOCKS | NO_LAYER_PAIRS), ("default", 0)):
+        enc = HipEncoder(dims, device="cuda:0", flags=flags)  # default: the wave-pair kernel between 64-row first / last launches
         enc.load_state_dict(state, calibrate=False, kernel_set="f16")
         outs[label] = []
         for rows in batches:
@@ -486,8 +485,9 @@ def test_wave_pair_layer_kernel_on_small_ragged_batches():
         with torch.no_grad():
             ref = oracle_forward(state, dims, ids, mask)
         m = mask.bool().numpy()
-        p, r = outs["pairs"][b]
-        assert np.isfinite(p).all() and np.isfinite(r).all()
-        assert np.abs(p - ref.pruning_logits.numpy()[m]).max() < 3e-4 and np.abs(r - ref.ranking_logits.numpy()).max() < 3e-4, b
-        assert np.abs(p - outs["8x16"][b][0]).max() < 6e-5
+        for label in ("pairs", "default"):
+            p, r = outs[label][b]
+            assert np.isfinite(p).all() and np.isfinite(r).all()
+            assert np.abs(p - ref.pruning_logits.numpy()[m]).max() < 3e-4 and np.abs(r - ref.ranking_logits.numpy()).max() < 3e-4, (label, b)
+            assert np.abs(p - outs["8x16"][b][0]).max() < 6e-5, (label, b)
     assert not np.array_equal(outs["pairs"][0][0], outs["8x16"][0][0])
