@@ -608,8 +608,8 @@ class HipEncoder:
         _lib.check(self.lib, self._handle, code, "op_forward_packed")
 
     def _split_streams(self) -> dict:
-        """Two HIP streams bound to disjoint halves of the device's CUs (hipExtStreamCreateWithCUMask; plain streams if
-        the runtime refuses) and a workspace per half, created once."""
+        """Two HIP streams bound to disjoint halves of the device's CUs (hipExtStreamCreateWithCUMask, alternate mask bits; plain
+        streams if the runtime refuses) and a workspace per half, created once."""
 
         st = self._split_state
         if st is None:
@@ -622,7 +622,14 @@ class HipEncoder:
                 words = (n_cus + 31) // 32
                 with torch.cuda.device(self.device):
                     for half in range(2):
-                        bits = [(c * 2 // n_cus) == half for c in range(n_cus)]
+                        # Which CUs a pipeline gets: ALTERNATE bits of the CU mask (round 6).  Contiguous halves of the bit index
+                        # -- rounds 2 - 5 -- leave the two launch sequences in one of two phase relations for a whole run:
+                        # 66.8 k pairs/s on average over 8 driver-style runs and 63.6 - 64.3 k (below ONE sequence) in 4 of 5
+                        # hundred-step runs; alternate bits 67.9 k (67.6 - 68.1) and 66.8 - 68.7 k
+                        # (profiles/r06_exp_phase_diversity.txt).  OPEN_PROVENCE_PIPELINE_MASK_GROUP=<g>: runs of g bits
+                        # alternate (measurement hook; 0 = the contiguous halves).
+                        group = int(os.environ.get("OPEN_PROVENCE_PIPELINE_MASK_GROUP", "1") or 0)
+                        bits = [((c // group) % 2 if group > 0 else (c * 2 // n_cus)) == half for c in range(n_cus)]
                         mask = (ctypes.c_uint32 * words)(
                             *[sum(1 << b for b in range(32) if w * 32 + b < n_cus and bits[w * 32 + b]) for w in range(words)]
                         )

@@ -1,2 +1,8 @@
-bash scripts/rocprof_pass.sh r06_xsmall_refinit > gpurun_out/r06_pass.log 2>&1; tail -3 gpurun_out/r06_pass.log | cut -c1-200
-bash scripts/rocprof_pass.sh r06_base_refinit --model base > gpurun_out/r06_pass_base.log 2>&1; tail -3 gpurun_out/r06_pass_base.log | cut -c1-200
+for r in 1 2 3 4 5 6 7 8; do for g in 4 1 0; do
+OPEN_PROVENCE_PIPELINE_MASK_GROUP=$g python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-long --no-base --no-trained-like --no-worst-case --no-other-dtype 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('group $g', round(d['value']), round(d['one_pipeline']['value']), round(d['step_ms']['p10'],3), round(d['step_ms']['median'],3), round(d['step_ms']['p90'],3), round(d['roofline']['frac'],4))
+"
+done; done

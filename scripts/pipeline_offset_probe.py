@@ -54,6 +54,8 @@ def main() -> None:
     ap.add_argument("--model", default="xsmall")
     ap.add_argument("--kernel-set", default="f16")
     ap.add_argument("--layers", type=int, default=0, help="model depth override (3: ONE wave-pair launch per step... a per-step lock is then a per-layer lock)")
+    ap.add_argument("--parts", default="2,4,8", help="numbers of sequences to try (free-running mode)")
+    ap.add_argument("--offsets", default="0,10,20,40,60,85,130")
     ap.add_argument("--locked", action="store_true", help="only: two sequences re-locked every step at a chosen offset")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
@@ -152,9 +154,9 @@ def main() -> None:
             print(f"2 sequences, contiguous CU masks, re-locked every step at offset {off:5.0f} us: {v:9.0f} pairs/s ({v / base - 1:+.1%})", flush=True)
         return
     print(f"1 sequence, whole chip: {base:9.0f} pairs/s", flush=True)
-    for parts in (2, 4, 8):
+    for parts in [int(v) for v in args.parts.split(',')]:
         for interleave in (False, True):
-            for off in (0.0, 10.0, 20.0, 40.0, 60.0, 85.0, 130.0):
+            for off in [float(v) for v in args.offsets.split(',')]:
                 v = run(parts, off, interleave)
                 print(f"{parts} sequences, {'interleaved' if interleave else 'contiguous '} CU masks, offset {off:5.0f} us x j: {v:9.0f} pairs/s ({v / base - 1:+.1%})", flush=True)
     v = run(2, 40.0, False, unmasked=True)
