@@ -56,6 +56,7 @@ def main() -> None:
     ap.add_argument("--layers", type=int, default=0, help="model depth override (3: ONE wave-pair launch per step... a per-step lock is then a per-layer lock)")
     ap.add_argument("--parts", default="2,4,8", help="numbers of sequences to try (free-running mode)")
     ap.add_argument("--offsets", default="0,10,20,40,60,85,130")
+    ap.add_argument("--interleave", action="store_true", help="locked mode: alternate CU-mask bits instead of contiguous halves")
     ap.add_argument("--locked", action="store_true", help="only: two sequences re-locked every step at a chosen offset")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
@@ -111,7 +112,7 @@ def main() -> None:
         """Two sequences on the two CU halves, re-locked EVERY step: sequence 1 may not start a step earlier than `offset` after
         sequence 0 started the same step (event of stream 0 + a spin on stream 1)."""
 
-        streams = masked_streams(device, 2, False)
+        streams = masked_streams(device, 2, args.interleave)
         per = len(rows) // 2
         work = []
         for j in range(2):
@@ -147,8 +148,8 @@ def main() -> None:
     base = run(1, 0.0, False, unmasked=True)
     if args.locked:
         print(f"1 sequence, whole chip: {base:9.0f} pairs/s", flush=True)
-        v = run(2, 0.0, False)
-        print(f"2 sequences, contiguous CU masks, running free: {v:9.0f} pairs/s ({v / base - 1:+.1%})", flush=True)
+        v = run(2, 0.0, args.interleave)
+        print(f"2 sequences, {'alternate bits' if args.interleave else 'contiguous'} CU masks, running free: {v:9.0f} pairs/s ({v / base - 1:+.1%})", flush=True)
         for off in (0.0, 10.0, 20.0, 30.0, 40.0, 55.0, 70.0, 100.0, 150.0):
             v = run_locked(off)
             print(f"2 sequences, contiguous CU masks, re-locked every step at offset {off:5.0f} us: {v:9.0f} pairs/s ({v / base - 1:+.1%})", flush=True)
