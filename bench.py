@@ -21,7 +21,7 @@ reference's GPU default `dtype=bfloat16` makes of them at load time, standalone.
 command and reported as the `bf16_checkpoint` sub-record.
 
 With the (hi, lo) bf16 kernel sets (``OPEN_PROVENCE_NO_F8=1``) a step on one GPU enqueues the batch as TWO independent
-launch sequences (the two halves of the pairs, each on its own HIP stream bound to one half of the CUs:
+launch sequences (the two halves of the pairs, each on its own HIP stream -- own hardware queue, the whole chip since round 6:
 ``HipEncoder.forward_packed_on``; +2.9 % pairs/s same-box in round 2) and the same batch as one launch sequence is timed
 right after and reported as ``one_pipeline``.  The default fp16 + e4m3 kernel sets run the batch as ONE launch sequence
 (two measure the same; ``--pipelines 2`` forces them).  The ranks of a multi-GPU run
@@ -347,8 +347,8 @@ def main() -> None:
     parser.add_argument("--varlen", action="store_true",
                         help="BASELINE.json configs[4]: lengths drawn from 128..2048 (p ~ 1/L) until pairs*seq_len tokens per GPU")
     parser.add_argument("--pipelines", type=int, default=0, choices=[0, 1, 2],
-                        help="single GPU: the batch as this many independent launch sequences (each on its own HIP stream and "
-                        "its own half of the CUs; 2 = HipEncoder.forward_packed_on).  0 = automatic: two for the "
+                        help="single GPU: the batch as this many independent launch sequences (each on its own HIP stream; "
+                        "2 = HipEncoder.forward_packed_on).  0 = automatic: two for the "
                         "row-stationary models (hidden <= 256: +3 %%), one for the panel-path models (base / large / "
                         "en-gte: two measure -0.7 %%, their XCD-aware block maps assume all eight XCDs).  The per-kernel "
                         "profile uses one")
@@ -413,8 +413,8 @@ def main() -> None:
     cu = torch.from_numpy(cu_np).to(device)
     total_tokens = int(cu_np[-1])
 
-    # The rank's pairs run as two independent launch sequences (contiguous halves, each on its own stream and its own
-    # half of the CUs -- HipEncoder.forward_packed_on explains why); a step enqueues both halves.  With more than one
+    # The rank's pairs run as two independent launch sequences (contiguous halves of the pairs, each on its own stream --
+    # HipEncoder.forward_packed_on explains why); a step enqueues both halves.  With more than one
     # rank each sequence is followed, on ITS stream, by the gather of its own half (ShardPlan.split: the same cut on
     # every rank, one plan per half), so the sequences never wait for each other: one gather behind both re-aligns
     # them every step and loses 7 %, one behind each keeps +1.9 % of the +2.9 % (measured on a one-rank RCCL group).
@@ -701,7 +701,7 @@ def main() -> None:
             "clock_settling": settle,
             "policy": policy,  # term masks evaluated per contraction family + the kernel set running them
             "parallelism": f"dp{world} (pairs sharded by token count, on-device fragment means, one RCCL gather of 4 B per fragment + ranking logits)" if world > 1
-            else ("single GPU, two independent half-batch launch sequences on CU-partitioned streams" if pipes else "single GPU"),
+            else ("single GPU, two independent half-batch launch sequences on two streams (own hardware queues, no CU partition)" if pipes else "single GPU"),
             # what the ranks exchange inside the timed step.  Rounds 1-3 gathered 4 B per TOKEN; since round 4 the product's
             # own exchange is timed (one fp32 per 32-token fragment): N > 1 figures are not comparable across that change
             "exchange": (f"fragment_means/{FRAGMENT_TOKENS}: one RCCL gather of 4 B per {FRAGMENT_TOKENS}-token fragment + ranking logits "

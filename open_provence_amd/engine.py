@@ -170,7 +170,7 @@ class HipEncoder:
         code = self.lib.op_create(ctypes.byref(cfg), ctypes.byref(handle))
         _lib.check(self.lib, None, code, "op_create")
         self._handle = handle
-        self._split_state: dict | None = None  # CU-partitioned streams + their workspaces (forward_packed_on)
+        self._split_state: dict | None = None  # the two pipeline streams + their workspaces (forward_packed_on)
         self._workspace: torch.Tensor | None = None
         self._capture: torch.Tensor | None = None
         self._capture_result: torch.Tensor | None = None
@@ -608,8 +608,8 @@ class HipEncoder:
         _lib.check(self.lib, self._handle, code, "op_forward_packed")
 
     def _split_streams(self) -> dict:
-        """Two HIP streams bound to disjoint halves of the device's CUs (hipExtStreamCreateWithCUMask, alternate mask bits; plain
-        streams if the runtime refuses) and a workspace per half, created once."""
+        """Two HIP streams of their own (hipExtStreamCreateWithCUMask with the full mask: own hardware queues, no CU partition since
+        round 6; plain streams if the runtime refuses) and a workspace per stream, created once."""
 
         st = self._split_state
         if st is None:
@@ -622,14 +622,17 @@ class HipEncoder:
                 words = (n_cus + 31) // 32
                 with torch.cuda.device(self.device):
                     for half in range(2):
-                        # Which CUs a pipeline gets: ALTERNATE bits of the CU mask (round 6).  Contiguous halves of the bit index
-                        # -- rounds 2 - 5 -- leave the two launch sequences in one of two phase relations for a whole run:
-                        # 66.8 k pairs/s on average over 8 driver-style runs and 63.6 - 64.3 k (below ONE sequence) in 4 of 5
-                        # hundred-step runs; alternate bits 67.9 k (67.6 - 68.1) and 66.8 - 68.7 k
-                        # (profiles/r06_exp_phase_diversity.txt).  OPEN_PROVENCE_PIPELINE_MASK_GROUP=<g>: runs of g bits
-                        # alternate (measurement hook; 0 = the contiguous halves).
-                        group = int(os.environ.get("OPEN_PROVENCE_PIPELINE_MASK_GROUP", "1") or 0)
-                        bits = [((c // group) % 2 if group > 0 else (c * 2 // n_cus)) == half for c in range(n_cus)]
+                        # Which CUs a pipeline gets (round 6): ALL of them -- two streams created through the CU-mask API (their
+                        # own hardware queues) with the full mask.  Halves of the chip (contiguous halves of the mask's bit index =
+                        # 16 CUs of every XCD each: rounds 2 - 5) leave the two launch sequences in one of two phase relations for
+                        # a whole run, the bad one BELOW one sequence (63.6 - 64.3 k pairs/s in 4 of 5 hundred-step runs on one
+                        # box, 68.8 k on another); unpartitioned, the blocks of the two sequences share the CUs as they come --
+                        # 66.8 - 69.5 k on both boxes, never below (profiles/r06_exp_phase_diversity.txt, section 6; which CUs a
+                        # mask really gives: microbench/cu_mask_probe.hip -- alternate bits or runs of 4 are NOT honoured as a
+                        # partition, both streams get all 256 CUs).  OPEN_PROVENCE_PIPELINE_MASK_GROUP: 0 = the contiguous
+                        # halves, g > 0 = runs of g bits alternate (measurement hook).
+                        group = int(os.environ.get("OPEN_PROVENCE_PIPELINE_MASK_GROUP", "-1") or 0)
+                        bits = [True if group < 0 else ((c // group) % 2 if group > 0 else (c * 2 // n_cus)) == half for c in range(n_cus)]
                         mask = (ctypes.c_uint32 * words)(
                             *[sum(1 << b for b in range(32) if w * 32 + b < n_cus and bits[w * 32 + b]) for w in range(words)]
                         )
@@ -652,13 +655,13 @@ class HipEncoder:
         max_seqlen: int,
         keep_prob: torch.Tensor | None = None,
     ) -> tuple[torch.Tensor, torch.Tensor]:
-        """``forward_packed`` enqueued on pipeline ``part`` (0 or 1): its own HIP stream, bound to one half of the
-        device's CUs, and its own workspace -- nothing is ordered against the caller's current stream or the other
+        """``forward_packed`` enqueued on pipeline ``part`` (0 or 1): its own HIP stream (own hardware queue; the whole chip
+        since round 6, see ``_split_streams``) and its own workspace -- nothing is ordered against the caller's current stream or the other
         pipeline (inputs must already be resident; wait on ``pipeline_stream(part)`` before reading the outputs).
 
         Why two pipelines: every CU of a launch is in the same phase at the same time -- all fetch, then all multiply
-        -- so HBM idles while the matrix pipes work and vice versa; two INDEPENDENT launch sequences on disjoint CUs
-        drift apart and fill each other's gaps (xsmall, 2 x 128 pairs x 512 against 1 x 256: +3 % pairs/s, same box).
+        -- so HBM idles while the matrix pipes work and vice versa; two INDEPENDENT launch sequences
+        drift apart and fill each other's gaps (xsmall, 2 x 128 pairs x 512 against 1 x 256: +3 .. +6 % pairs/s, same box).
         Forking and joining the halves inside every forward instead re-aligns them each time and loses 4 %."""
 
         if part not in (0, 1):

@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-long --no-base "$@" > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-long --no-base "$@" > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-long --no-base "$@" > $OUT/pmc_mfma.log 2>&1
+python scripts/trace_by_grid.py $OUT/trace > $OUT/trace_by_grid.log 2>&1
 python scripts/summarize_rocprof.py $OUT > $OUT/summary.txt 2>&1
 KEY=$(python - $OUT/bench_under_rocprof.log <<'PY'
 import json, sys
