@@ -1,4 +1,5 @@
-bash scripts/rocprof_pass.sh r06_xsmall_refinit > gpurun_out/r06_pass.log 2>&1
-python bench.py > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err
-python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_driver_style.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_driver_style2.json 2>/dev/null
+echo "# round 6: process() with DEFAULT arguments after the stream change (two unpartitioned launch sequences) and the ungated wave-pair kernel"
+for args in "--contexts 4096 --reps 8" "--contexts 2048 --reps 8" "--contexts 1024 --reps 5" "--contexts 256 --reps 5"; do
+echo "\$ python scripts/process_e2e.py --tokenizer wordpiece --stock-tokenizer $args"
+python scripts/process_e2e.py --tokenizer wordpiece --stock-tokenizer $args 2>&1 | grep "^{" | tail -1
+done
