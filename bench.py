@@ -419,10 +419,9 @@ def main() -> None:
     # every rank, one plan per half), so the sequences never wait for each other: one gather behind both re-aligns
     # them every step and loses 7 %, one behind each keeps +1.9 % of the +2.9 % (measured on a one-rank RCCL group).
     # The plain single-GPU line also carries the one-sequence figure (`one_pipeline`).
-    # (round 3: the fp16 + e4m3 whole-layer kernels take 132 KiB of LDS -- one block per CU whichever way the CUs are
-    # split -- and two sequences measure the same as one: 35.54 k vs 35.48 k, 43.13 k vs 43.03 k pairs/s; they run as one)
-    f8_set = policy["kernel_set"] in ("f16-f8", "f16-f8-w")
-    want_pipes = args.pipelines or (2 if (dims.hidden_size <= 256 and not f8_set) else 1)
+    # (rounds 3 - 5: on halves of the chip the fp16 + e4m3 whole-layer kernels measured the same as one sequence and ran as
+    # one; round 6, unpartitioned streams: 35.2 k -> 36.6 k pairs/s fp32-valued, 42.8 k -> 43.9 k bf16-valued on the O(1) weights)
+    want_pipes = args.pipelines or (2 if dims.hidden_size <= 256 else 1)
     n_pipes = want_pipes if (not args.varlen and len(rows) >= 2) else 1
     keep_dev = torch.empty(total_tokens, dtype=torch.float32, device=device)
 

@@ -1,5 +1,14 @@
-echo "# round 6: process() with DEFAULT arguments after the stream change (two unpartitioned launch sequences) and the ungated wave-pair kernel"
-for args in "--contexts 4096 --reps 8" "--contexts 2048 --reps 8" "--contexts 1024 --reps 5" "--contexts 256 --reps 5"; do
-echo "\$ python scripts/process_e2e.py --tokenizer wordpiece --stock-tokenizer $args"
-python scripts/process_e2e.py --tokenizer wordpiece --stock-tokenizer $args 2>&1 | grep "^{" | tail -1
-done
+for r in 1 2 3; do for pp in 1 2; do
+python bench.py --init o1 --pipelines $pp --steps 60 --warmup 5 --no-cpu-baseline --no-long --no-base --no-trained-like --no-worst-case --no-other-dtype 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('o1 fp32 pipelines $pp', round(d['value']), d['ms_per_step'], d['config']['policy']['kernel_set'], d['config']['output_checksum']['stored'])
+"
+python bench.py --init o1 --weights bf16 --pipelines $pp --steps 60 --warmup 5 --no-cpu-baseline --no-long --no-base --no-trained-like --no-worst-case --no-other-dtype 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('o1 bf16 pipelines $pp', round(d['value']), d['ms_per_step'], d['config']['policy']['kernel_set'], d['config']['output_checksum']['stored'])
+"
+done; done
