@@ -258,12 +258,14 @@ class HipEncoder:
             _lib.check(self.lib, self._handle, self.lib.op_select_mlp_correction_layers(self._handle, ctypes.c_uint64(mask)),
                        "op_select_mlp_correction_layers")
 
-    def calibrate(self, tolerance: float = 1e-4, rows: "Sequence[Sequence[int]] | None" = None, *, full_report: "bool | None" = None) -> dict:
+    def calibrate(self, tolerance: float = 1e-4, rows: "Sequence[Sequence[int]] | None" = None, *, full_report: "bool | None" = None,
+                  whole_depth: "bool | None" = None) -> dict:
         """``op_calibrate``: one batch (``rows`` of token ids -- a sample of real inputs -- or the library's synthetic
         batch) through the (hi, lo) bf16 kernels and through every kernel set cheaper than the default one; the
         cheapest whose logits stay within ``tolerance`` of them (and finite) is what the forward runs on from now on.
         Returns (and keeps as ``self.calibration``) the report: ``{"tolerance", "reference_set", "default_set",
-        "chosen_set", "candidates": {set name: max |logit difference|}, "rows", "tokens", "batch"}``."""
+        "chosen_set", "candidates": {set name: max |logit difference|}, "rows", "tokens", "batch"}`` -- plus, when the choice is
+        kernel set 8 / 9, ``"mlp_correction_layers"`` (the layers that keep the fp16 + e4m3 MLP) and ``"mlp_correction_err"``."""
 
         report = _lib.OpCalibration()
         report.struct_bytes = ctypes.sizeof(_lib.OpCalibration)
@@ -272,6 +274,11 @@ class HipEncoder:
         if full_report is None:
             full_report = os.environ.get("OPEN_PROVENCE_CALIBRATE_FULL", "").strip().lower() in ("1", "on", "true", "yes")
         report.flags = _lib.OP_CAL_FULL_REPORT if full_report else 0
+        # kernel sets 8 / 9 are refined layer by layer (ABI 9); whole_depth=True / OPEN_PROVENCE_CALIBRATE_WHOLE_DEPTH=1 keeps them whole
+        if whole_depth is None:
+            whole_depth = os.environ.get("OPEN_PROVENCE_CALIBRATE_WHOLE_DEPTH", "").strip().lower() in ("1", "on", "true", "yes")
+        if whole_depth:
+            report.flags |= _lib.OP_CAL_WHOLE_DEPTH
         if rows is not None:
             ids_np, cu_np, _ = pack_rows(rows)
             self.check_ids(ids_np)

@@ -142,6 +142,9 @@ def test_panel_path_calibrates_and_stays_inside_its_tolerance():
         prune, rank = enc.forward_packed_checked(ids, cu, cu_np, max_len)
         torch.cuda.synchronize()
         outs[label] = (prune.cpu().numpy(), rank.cpu().numpy(), enc.effective_policy()["kernel_set"], enc.calibration, enc.effective_policy())
+        if label == "calibrated":  # the same search with the per-layer refinement switched off: the set at whole depth
+            whole = enc.calibrate(1e-4, whole_depth=True)
+            assert whole["chosen_set"] == "f16+mlp-f16-f8-w" and whole["mlp_correction_layers"] == list(range(dims.num_layers)), whole
         enc.close()
     ref_p, ref_r, ref_set = outs["reference"][:3]
     assert ref_set == "bf16x3"
